@@ -1,0 +1,125 @@
+"""ctypes binding of libapk.so (include/apk.h) - the same C-ABI a cgo shim would bind.
+
+The library is built in-tree by `make -C algoplonk_amd/csrc` (or `__graft_entry__.build()`).  There is no
+fallback: if the shared object is missing, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libapk.so")
+
+APK_BN254 = 0
+APK_BLS12_381 = 1
+APK_OK = 0
+APK_ERR_ARG, APK_ERR_HIP, APK_ERR_STATE, APK_ERR_WITNESS = 1, 2, 3, 4
+G1_MAX = 96
+MAX_COMMITMENTS = 2
+NB_BLINDING = 9
+
+# every symbol include/apk.h declares (tests/test_abi.py checks the header against this list)
+SYMBOLS = [
+    "apk_last_error", "apk_abi_version", "apk_device_count", "apk_g1_bytes", "apk_fp_bytes",
+    "apk_ctx_create", "apk_ctx_destroy", "apk_ctx_get_vk", "apk_msm_g1", "apk_msm_g1_device", "apk_ntt",
+    "apk_prove", "apk_prove_device", "apk_g1_mul_batch", "apk_marshal_proof", "apk_marshal_public_inputs",
+    "apk_fe_from_be", "apk_fe_to_be", "apk_hash_fr", "apk_host_fe_op", "apk_host_g1_op",
+    "apk_device_alloc", "apk_device_free", "apk_device_upload", "apk_device_download",
+    "apk_stats_enable", "apk_stats_read",
+]
+
+
+class ApkError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("libapk error %d: %s" % (code, msg))
+        self.code = code
+
+
+class CircuitDesc(C.Structure):
+    _fields_ = [
+        ("curve", C.c_int), ("device", C.c_int), ("n", C.c_uint64), ("nb_public", C.c_uint32),
+        ("nb_commitments", C.c_uint32), ("srs_g1", C.c_void_p), ("srs_g1_lagrange", C.c_void_p),
+        ("ql", C.c_void_p), ("qr", C.c_void_p), ("qm", C.c_void_p), ("qo", C.c_void_p), ("qk", C.c_void_p),
+        ("perm", C.c_void_p), ("qcp", C.c_void_p * MAX_COMMITMENTS),
+        ("commitment_constraint_index", C.c_uint32 * MAX_COMMITMENTS), ("msm_window", C.c_int), ("slots", C.c_int),
+    ]
+
+
+class Vk(C.Structure):
+    _fields_ = [
+        ("ql", C.c_uint8 * G1_MAX), ("qr", C.c_uint8 * G1_MAX), ("qm", C.c_uint8 * G1_MAX), ("qo", C.c_uint8 * G1_MAX),
+        ("qk", C.c_uint8 * G1_MAX), ("s", (C.c_uint8 * G1_MAX) * 3), ("qcp", (C.c_uint8 * G1_MAX) * MAX_COMMITMENTS),
+        ("size_inv", C.c_uint8 * 32), ("generator", C.c_uint8 * 32), ("coset_shift", C.c_uint8 * 32),
+    ]
+
+
+class Proof(C.Structure):
+    _fields_ = [
+        ("curve", C.c_uint32), ("nb_commitments", C.c_uint32),
+        ("lro", (C.c_uint8 * G1_MAX) * 3), ("z", C.c_uint8 * G1_MAX), ("h", (C.c_uint8 * G1_MAX) * 3),
+        ("bsb22", (C.c_uint8 * G1_MAX) * MAX_COMMITMENTS), ("batched_h", C.c_uint8 * G1_MAX),
+        ("claimed_values", (C.c_uint8 * 32) * (6 + MAX_COMMITMENTS)), ("zshift_h", C.c_uint8 * G1_MAX),
+        ("zshift_value", C.c_uint8 * 32),
+        ("gamma", C.c_uint8 * 32), ("beta", C.c_uint8 * 32), ("alpha", C.c_uint8 * 32), ("zeta", C.c_uint8 * 32),
+        ("gamma_kzg", C.c_uint8 * 32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("msm_accumulate_ms", C.c_double), ("msm_accumulate_launches", C.c_uint64), ("msm_pairs", C.c_uint64),
+        ("msm_total_ms", C.c_double), ("msm_batches", C.c_uint64), ("ntt_ms", C.c_double), ("ntt_elements", C.c_uint64),
+        ("prove_ms", C.c_double), ("proofs", C.c_uint64),
+    ]
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libapk.so not found at %s - build it with `make -C algoplonk_amd/csrc` "
+            "(there is no CPU fallback for the HIP path)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, u64, i32, sz = C.c_void_p, C.c_uint64, C.c_int, C.c_size_t
+    lib.apk_last_error.restype = C.c_char_p
+    lib.apk_abi_version.restype = i32
+    lib.apk_device_count.argtypes = [C.POINTER(i32)]
+    lib.apk_g1_bytes.argtypes = [i32]; lib.apk_g1_bytes.restype = sz
+    lib.apk_fp_bytes.argtypes = [i32]; lib.apk_fp_bytes.restype = sz
+    lib.apk_ctx_create.argtypes = [C.POINTER(CircuitDesc), C.POINTER(vp)]
+    lib.apk_ctx_destroy.argtypes = [vp]; lib.apk_ctx_destroy.restype = None
+    lib.apk_ctx_get_vk.argtypes = [vp, C.POINTER(Vk)]
+    lib.apk_msm_g1.argtypes = [vp, i32, vp, u64, vp]
+    lib.apk_msm_g1_device.argtypes = [vp, i32, vp, u64, vp]
+    lib.apk_ntt.argtypes = [vp, i32, i32, i32, vp]
+    lib.apk_prove.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(Proof)]
+    lib.apk_prove_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(Proof)]
+    lib.apk_g1_mul_batch.argtypes = [i32, i32, vp, vp, u64, vp]
+    lib.apk_marshal_proof.argtypes = [C.POINTER(Proof), vp, sz, C.POINTER(sz)]
+    lib.apk_marshal_public_inputs.argtypes = [i32, vp, C.c_uint32, vp, sz]
+    lib.apk_fe_from_be.argtypes = [i32, i32, vp, vp]
+    lib.apk_fe_to_be.argtypes = [i32, i32, vp, vp]
+    lib.apk_hash_fr.argtypes = [i32, vp, vp]
+    lib.apk_host_fe_op.argtypes = [i32, i32, i32, vp, vp, vp]
+    lib.apk_host_g1_op.argtypes = [i32, i32, vp, vp, vp]
+    lib.apk_device_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+    lib.apk_device_free.argtypes = [vp, vp]
+    lib.apk_device_upload.argtypes = [vp, vp, vp, sz]
+    lib.apk_device_download.argtypes = [vp, vp, vp, sz]
+    lib.apk_stats_enable.argtypes = [vp, i32]
+    lib.apk_stats_read.argtypes = [vp, C.POINTER(Stats), i32]
+    return lib
+
+
+lib = _load()
+
+
+def check(code: int) -> None:
+    if code != APK_OK:
+        raise ApkError(code, (lib.apk_last_error() or b"").decode())
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(lib.apk_device_count(C.byref(n)))
+    return n.value

@@ -1,0 +1,39 @@
+// Curve-erased interface between the C-ABI (apk_api.cpp) and the per-curve HIP backends
+// (backend_impl.h, instantiated in backend_bn254.hip / backend_bls12381.hip).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/apk.h"
+
+namespace apk {
+
+void set_error(const char* fmt, ...);
+
+struct Backend {
+    virtual ~Backend() {}
+    virtual int init(const apk_circuit_desc* d) = 0;
+    virtual int get_vk(apk_vk* out) = 0;
+    virtual int msm(int basis, const void* scalars, uint64_t len, bool on_device, void* out) = 0;
+    virtual int ntt(int which, int inverse, int coset, void* data) = 0;
+    virtual int prove(const void* L, const void* R, const void* O, bool on_device, const void* pub, const void* blinding,
+                      const void* const* pi2, apk_proof* out) = 0;
+    virtual int dev_alloc(size_t bytes, void** p) = 0;
+    virtual int dev_free(void* p) = 0;
+    virtual int dev_upload(void* d, const void* s, size_t bytes) = 0;
+    virtual int dev_download(void* d, const void* s, size_t bytes) = 0;
+    virtual int stats_enable(int enable) = 0;
+    virtual int stats_read(apk_stats* out, int reset) = 0;
+};
+
+int g1_mul_batch_bn254(int device, const void* base, const void* scalars, uint64_t count, void* out);
+int g1_mul_batch_bls12381(int device, const void* base, const void* scalars, uint64_t count, void* out);
+Backend* make_backend_bn254();
+Backend* make_backend_bls12381();
+
+// host-only helpers implemented per curve (no GPU): used by marshal / conversions / hash_fr
+int host_fe_from_be(int curve, int field, const uint8_t* be, void* out);
+int host_fe_to_be(int curve, int field, const void* in, uint8_t* be);
+
+}  // namespace apk

@@ -1,0 +1,8 @@
+// BLS12-381 instantiation of the per-curve backend (Fr: 8 x 32-bit limbs, Fp: 12 x 32-bit limbs).
+#include "backend_impl.h"
+namespace apk {
+Backend* make_backend_bls12381() { return new CurveBackend<FrBLS12381, FpBLS12381, APK_BLS12_381>(); }
+int g1_mul_batch_bls12381(int device, const void* base, const void* scalars, uint64_t count, void* out) {
+    return g1_mul_batch_impl<FrBLS12381, FpBLS12381>(device, base, scalars, count, out);
+}
+}  // namespace apk

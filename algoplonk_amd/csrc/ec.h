@@ -1,0 +1,127 @@
+// G1 arithmetic for y^2 = x^3 + b (a = 0; BN254 b=3, BLS12-381 b=4 - the formulas never touch b) in
+// extended Jacobian ("XYZZ") coordinates: x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2, infinity <=> ZZ == 0.
+// Mixed addition costs 8M+2S, full addition 12M+2S, doubling 6M+3S; no inversions until the final
+// affine conversion.  Affine points use gnark's in-memory form {X, Y} in Montgomery limbs with
+// (0, 0) as infinity, so SRS buffers cross the C-ABI untouched.
+//
+// Replaces (device side) gnark-crypto v0.20.1 ecc/<curve>/g1.go point arithmetic that
+// G1Affine.MultiExp runs on [UPSTREAM; reached from /root/reference/algoplonk.go:89 via kzg.Commit].
+#pragma once
+#include "ff.h"
+
+template <class FP>
+struct Affine {
+    Fe<FP> x, y;
+    APK_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
+    APK_HD static Affine inf() { return Affine{Fe<FP>::zero(), Fe<FP>::zero()}; }
+};
+
+template <class FP>
+struct XYZZ {
+    using F = Fe<FP>;
+    F X, Y, ZZ, ZZZ;
+
+    APK_HD bool is_inf() const { return ZZ.is_zero(); }
+    APK_HD static XYZZ inf() { return XYZZ{F::one(), F::one(), F::zero(), F::zero()}; }
+    APK_HD static XYZZ from_affine(const Affine<FP>& p) {
+        if (p.is_inf()) return inf();
+        return XYZZ{p.x, p.y, F::one(), F::one()};
+    }
+    APK_HD void neg_inplace() { Y = F::neg(Y); }
+
+    // 2 * (affine p)
+    APK_HD static XYZZ dbl_affine(const Affine<FP>& p) {
+        if (p.is_inf() || p.y.is_zero()) return inf();
+        F U = F::dbl(p.y);
+        F V = F::sqr(U);
+        F W = U * V;
+        F S = p.x * V;
+        F xx = F::sqr(p.x);
+        F M = F::add(F::dbl(xx), xx);
+        XYZZ r;
+        r.X = F::sub(F::sub(F::sqr(M), S), S);
+        r.Y = F::sub(M * F::sub(S, r.X), W * p.y);
+        r.ZZ = V;
+        r.ZZZ = W;
+        return r;
+    }
+
+    APK_HD static XYZZ dbl(const XYZZ& p) {
+        if (p.is_inf() || p.Y.is_zero()) return inf();
+        F U = F::dbl(p.Y);
+        F V = F::sqr(U);
+        F W = U * V;
+        F S = p.X * V;
+        F xx = F::sqr(p.X);
+        F M = F::add(F::dbl(xx), xx);
+        XYZZ r;
+        r.X = F::sub(F::sub(F::sqr(M), S), S);
+        r.Y = F::sub(M * F::sub(S, r.X), W * p.Y);
+        r.ZZ = V * p.ZZ;
+        r.ZZZ = W * p.ZZZ;
+        return r;
+    }
+
+    // this += q (affine).  `negate` flips q's sign (signed-digit buckets).
+    APK_HD void madd(const Affine<FP>& q_in, bool negate = false) {
+        if (q_in.is_inf()) return;
+        Affine<FP> q = q_in;
+        if (negate) q.y = F::neg(q.y);
+        if (is_inf()) {
+            X = q.x; Y = q.y; ZZ = F::one(); ZZZ = F::one();
+            return;
+        }
+        F U2 = q.x * ZZ;
+        F S2 = q.y * ZZZ;
+        F Pd = F::sub(U2, X);
+        F R = F::sub(S2, Y);
+        if (Pd.is_zero()) {
+            if (R.is_zero()) { *this = dbl_affine(q); return; }
+            *this = inf();
+            return;
+        }
+        F PP = F::sqr(Pd);
+        F PPP = Pd * PP;
+        F Q = X * PP;
+        F X3 = F::sub(F::sub(F::sub(F::sqr(R), PPP), Q), Q);
+        F Y3 = F::sub(R * F::sub(Q, X3), Y * PPP);
+        X = X3;
+        Y = Y3;
+        ZZ = ZZ * PP;
+        ZZZ = ZZZ * PPP;
+    }
+
+    // this += q
+    APK_HD void add(const XYZZ& q) {
+        if (q.is_inf()) return;
+        if (is_inf()) { *this = q; return; }
+        F U1 = X * q.ZZ;
+        F U2 = q.X * ZZ;
+        F S1 = Y * q.ZZZ;
+        F S2 = q.Y * ZZZ;
+        F Pd = F::sub(U2, U1);
+        F R = F::sub(S2, S1);
+        if (Pd.is_zero()) {
+            if (R.is_zero()) { *this = dbl(q); return; }
+            *this = inf();
+            return;
+        }
+        F PP = F::sqr(Pd);
+        F PPP = Pd * PP;
+        F Q = U1 * PP;
+        F X3 = F::sub(F::sub(F::sub(F::sqr(R), PPP), Q), Q);
+        F Y3 = F::sub(R * F::sub(Q, X3), S1 * PPP);
+        X = X3;
+        Y = Y3;
+        ZZ = (ZZ * q.ZZ) * PP;
+        ZZZ = (ZZZ * q.ZZZ) * PPP;
+    }
+
+    APK_HD Affine<FP> to_affine() const {
+        if (is_inf()) return Affine<FP>::inf();
+        // 1/ZZZ gives both: 1/ZZ = ZZZ^-1 * ZZZ / ZZ ... simpler: two field ops from one inversion
+        F zzz_inv = F::inv(ZZZ);
+        F zz_inv = F::sqr(zzz_inv * ZZ);  // (ZZ/ZZZ)^2 = 1/Z^2 = 1/ZZ
+        return Affine<FP>{X * zz_inv, Y * zzz_inv};
+    }
+};

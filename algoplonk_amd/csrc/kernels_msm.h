@@ -1,0 +1,277 @@
+// Pippenger multi-scalar multiplication over G1 for a FIXED base set (the KZG SRS), gfx950.
+//
+// What it replaces: gnark-crypto v0.20.1 `G1Affine.MultiExp` [UPSTREAM, not vendored], reached from
+// /root/reference/algoplonk.go:89 (plonk.Prove -> kzg.Commit / kzg.Open) and from
+// /root/reference/setup/setup.go:107,149 (plonk.Setup -> 8+k trace commitments).  SURVEY.md §8a row a4.
+//
+// MI355X-first design (NOT gnark's goroutine-per-window CPU algorithm):
+//   * the SRS is fixed per circuit and HBM is 288 GB, so every window's multiple 2^(c*j) * P_i is
+//     precomputed once ("windowed point tables").  All W windows then feed ONE set of 2^(c-1) buckets:
+//     no per-window reduction, no final double-and-add over windows.
+//   * scalars are recoded into signed c-bit digits; (digit, point) pairs are counting-sorted by bucket with
+//     L2 atomics (histogram -> single-block scan -> scatter);
+//   * bucket accumulation is cut into fixed-size work units (<= K entries of one bucket per lane) so a
+//     skewed bucket cannot serialise a wave; unit partials are merged by 16-lane groups with
+//     wavefront shuffles;
+//   * the weighted bucket sum  sum_k k*B_k  is evaluated bit-wise (sum_b 2^b * sum_{k: bit b} B_k):
+//     LDS tree reductions, critical path ~2*log2(#buckets) point operations instead of 2*#buckets.
+// Several MSMs over the same bases (e.g. [L],[R],[O]) run as one batch: bucket id = msm*NB + bucket.
+#pragma once
+#include "ec.h"
+
+namespace apk {
+
+constexpr int MSM_MAX_BATCH = 4;
+constexpr int MSM_UNIT = 16;        // entries per accumulation work unit
+constexpr int MSM_COMBINE_LANES = 16;
+constexpr int MSM_RED_THREADS = 256;
+constexpr int MSM_RED_MAXCHUNK = 8;
+
+struct MsmBatchArgs {
+    const void* scalars[MSM_MAX_BATCH];  // device, Fr Montgomery, len[b] elements
+    uint32_t len[MSM_MAX_BATCH];
+    uint32_t offset[MSM_MAX_BATCH];      // first base index used by msm b (bases [offset, offset+len))
+    uint32_t batch;
+};
+
+// ---- signed-digit recoding ---------------------------------------------------------------------------
+// canonical scalar limbs -> W digits d_j in [-2^(c-1), 2^(c-1)), s = sum d_j 2^(c j)
+template <int N>
+__device__ __forceinline__ uint32_t window_bits(const uint32_t (&s)[N], int bit, int c) {
+    int w = bit >> 5, o = bit & 31;
+    uint64_t v = s[w];
+    if (w + 1 < N) v |= (uint64_t)s[w + 1] << 32;
+    return (uint32_t)(v >> o) & ((1u << c) - 1u);
+}
+
+template <class FR, bool SCATTER>
+__global__ void __launch_bounds__(256) msm_digits_kernel(MsmBatchArgs a, int c, int W, uint32_t nb, uint32_t n_max,
+                                                         uint32_t* __restrict__ counters,  // hist or cursor
+                                                         uint32_t* __restrict__ sorted) {
+    using Fr = Fe<FR>;
+    const uint32_t b = blockIdx.y;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.len[b]) return;
+    Fr s = Fr::from_mont(reinterpret_cast<const Fr*>(a.scalars[b])[i]);
+    const uint32_t half = 1u << (c - 1);
+    uint32_t carry = 0;
+    const uint32_t base_idx = a.offset[b] + i;
+    for (int j = 0; j < W; j++) {
+        int bit = j * c;
+        uint32_t d = (bit < 32 * Fr::N ? window_bits<Fr::N>(s.l, bit, c) : 0u) + carry;
+        uint32_t neg = 0;
+        if (d > half) { d = (1u << c) - d; neg = 1; carry = 1; }  // d in (half, 2^c] -> -(2^c - d)
+        else carry = 0;
+        if (d == 0) continue;  // also the d == 2^c case (digit 0, carry 1)
+        uint32_t bucket = b * nb + (d - 1);
+        if (!SCATTER) {
+            atomicAdd(&counters[bucket], 1u);
+        } else {
+            uint32_t pos = atomicAdd(&counters[bucket], 1u);
+            sorted[pos] = ((uint32_t)j * n_max + base_idx) | (neg << 31);
+        }
+    }
+}
+
+// ---- single-block exclusive scans: bucket offsets and work-unit offsets --------------------------------
+// offsets[k] = sum_{i<k} hist[i]; cursor = copy of offsets; unit_off[k] = sum_{i<k} ceil(hist[i]/UNIT)
+template <int UNIT>
+__global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t* __restrict__ hist, uint32_t total,
+                                                        uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
+                                                        uint32_t* __restrict__ unit_off) {
+    __shared__ uint32_t s_cnt[1024];
+    __shared__ uint32_t s_unit[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (total + 1023u) / 1024u;
+    const uint32_t lo = min(t * per, total), hi = min(lo + per, total);
+    uint32_t sc = 0, su = 0;
+    for (uint32_t i = lo; i < hi; i++) { uint32_t h = hist[i]; sc += h; su += (h + UNIT - 1) / UNIT; }
+    s_cnt[t] = sc; s_unit[t] = su;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t vc = 0, vu = 0;
+        if (t >= d) { vc = s_cnt[t - d]; vu = s_unit[t - d]; }
+        __syncthreads();
+        s_cnt[t] += vc; s_unit[t] += vu;
+        __syncthreads();
+    }
+    uint32_t bc = s_cnt[t] - sc, bu = s_unit[t] - su;  // exclusive prefix of this thread's chunk
+    for (uint32_t i = lo; i < hi; i++) {
+        uint32_t h = hist[i];
+        offsets[i] = bc; cursor[i] = bc; unit_off[i] = bu;
+        bc += h; bu += (h + UNIT - 1) / UNIT;
+    }
+    if (t == 1023) { offsets[total] = s_cnt[1023]; unit_off[total] = s_unit[1023]; }
+}
+
+// ---- bucket accumulation: one lane per work unit ---------------------------------------------------------
+template <class FP>
+__global__ void __launch_bounds__(128) msm_accumulate_kernel(const Affine<FP>* __restrict__ table,
+                                                             const uint32_t* __restrict__ sorted,
+                                                             const uint32_t* __restrict__ offsets,
+                                                             const uint32_t* __restrict__ unit_off,
+                                                             uint32_t total_buckets, uint32_t max_units,
+                                                             XYZZ<FP>* __restrict__ partial) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= max_units) return;
+    const uint32_t total_units = unit_off[total_buckets];
+    if (u >= total_units) return;
+    // bucket = last k with unit_off[k] <= u  (empty buckets have unit_off[k] == unit_off[k+1])
+    uint32_t lo = 0, hi = total_buckets;  // invariant: unit_off[lo] <= u < unit_off[hi]
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (unit_off[mid] <= u) lo = mid; else hi = mid;
+    }
+    const uint32_t k = lo;
+    const uint32_t slice = u - unit_off[k];
+    const uint32_t beg = offsets[k] + slice * MSM_UNIT;
+    const uint32_t end = min(beg + MSM_UNIT, offsets[k + 1]);
+    XYZZ<FP> acc = XYZZ<FP>::inf();
+    for (uint32_t e = beg; e < end; e++) {
+        uint32_t v = sorted[e];
+        Affine<FP> p = table[v & 0x7fffffffu];
+        acc.madd(p, (v >> 31) != 0);
+    }
+    partial[u] = acc;
+}
+
+template <class FP>
+__device__ __forceinline__ XYZZ<FP> shfl_down_point(const XYZZ<FP>& p, int delta, int width) {
+    XYZZ<FP> r;
+    constexpr int N = Fe<FP>::N;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        r.X.l[i] = __shfl_down(p.X.l[i], delta, width);
+        r.Y.l[i] = __shfl_down(p.Y.l[i], delta, width);
+        r.ZZ.l[i] = __shfl_down(p.ZZ.l[i], delta, width);
+        r.ZZZ.l[i] = __shfl_down(p.ZZZ.l[i], delta, width);
+    }
+    return r;
+}
+
+// merge a bucket's unit partials: MSM_COMBINE_LANES lanes per bucket, strided sums + shuffle tree
+template <class FP>
+__global__ void __launch_bounds__(256) msm_combine_kernel(const XYZZ<FP>* __restrict__ partial,
+                                                          const uint32_t* __restrict__ unit_off, uint32_t total_buckets,
+                                                          XYZZ<FP>* __restrict__ bucket_sum) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t k = gid / MSM_COMBINE_LANES;
+    const uint32_t lane = gid % MSM_COMBINE_LANES;
+    XYZZ<FP> acc = XYZZ<FP>::inf();
+    uint32_t beg = 0, end = 0;
+    if (k < total_buckets) { beg = unit_off[k]; end = unit_off[k + 1]; }
+    for (uint32_t u = beg + lane; u < end; u += MSM_COMBINE_LANES) acc.add(partial[u]);
+    // all lanes of the wave take part in every shuffle; groups with nothing to add see infinities
+    const uint32_t n_units = end - beg;
+    uint64_t need = __ballot(n_units > 1);
+    if (need) {
+#pragma unroll
+        for (int d = MSM_COMBINE_LANES / 2; d >= 1; d >>= 1) {
+            XYZZ<FP> o = shfl_down_point(acc, d, MSM_COMBINE_LANES);
+            if (lane < (uint32_t)d && n_units > (uint32_t)d) acc.add(o);
+        }
+    }
+    if (k < total_buckets && lane == 0) bucket_sum[k] = acc;
+}
+
+// ---- weighted bucket reduction, bit-wise --------------------------------------------------------------
+// grid (chunk, bit, msm): S[msm][bit][chunk] = sum of B_k (k = idx+1) with bit `bit` of k set, idx in chunk
+template <class FP>
+__global__ void __launch_bounds__(MSM_RED_THREADS) msm_bitsum_kernel(const XYZZ<FP>* __restrict__ bucket_sum, uint32_t nb,
+                                                                     uint32_t nchunk, uint32_t nbits,
+                                                                     XYZZ<FP>* __restrict__ bit_partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    XYZZ<FP>* sm = reinterpret_cast<XYZZ<FP>*>(smem_raw);
+    const uint32_t chunk = blockIdx.x, bit = blockIdx.y, m = blockIdx.z;
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = nb / nchunk;
+    const uint32_t lo = chunk * per, hi = lo + per;
+    XYZZ<FP> acc = XYZZ<FP>::inf();
+    for (uint32_t idx = lo + t; idx < hi; idx += MSM_RED_THREADS) {
+        if (((idx + 1) >> bit) & 1u) acc.add(bucket_sum[m * nb + idx]);
+    }
+    sm[t] = acc;
+    __syncthreads();
+    for (uint32_t d = MSM_RED_THREADS / 2; d >= 1; d >>= 1) {
+        if (t < d) {
+            XYZZ<FP> o = sm[t + d];
+            acc.add(o);
+            sm[t] = acc;
+        }
+        __syncthreads();
+    }
+    if (t == 0) bit_partial[(m * nbits + bit) * nchunk + chunk] = acc;
+}
+
+// one workgroup per msm: sum chunks per bit, scale by 2^bit, sum over bits, convert to affine
+template <class FP>
+__global__ void __launch_bounds__(256) msm_final_kernel(const XYZZ<FP>* __restrict__ bit_partial, uint32_t nchunk,
+                                                        uint32_t nbits, Affine<FP>* __restrict__ result,
+                                                        XYZZ<FP>* __restrict__ result_xyzz) {
+    __shared__ XYZZ<FP> sm[256];
+    const uint32_t m = blockIdx.x;
+    const uint32_t t = threadIdx.x;
+    const uint32_t bit = t / MSM_RED_MAXCHUNK, chunk = t % MSM_RED_MAXCHUNK;
+    XYZZ<FP> acc = XYZZ<FP>::inf();
+    if (bit < nbits)
+        for (uint32_t ch = chunk; ch < nchunk; ch += MSM_RED_MAXCHUNK) acc.add(bit_partial[(m * nbits + bit) * nchunk + ch]);
+    sm[t] = acc;
+    __syncthreads();
+    for (uint32_t d = MSM_RED_MAXCHUNK / 2; d >= 1; d >>= 1) {
+        if (chunk < d) { XYZZ<FP> o = sm[t + d]; acc.add(o); sm[t] = acc; }
+        __syncthreads();
+    }
+    if (chunk == 0) {
+        for (uint32_t i = 0; i < bit && i < nbits; i++) acc = XYZZ<FP>::dbl(acc);
+        sm[t] = acc;
+    }
+    __syncthreads();
+    // tree over bits: entries at t = bit*MAXCHUNK
+    for (uint32_t d = 16; d >= 1; d >>= 1) {
+        if (chunk == 0 && bit < d && bit + d < 32) {
+            XYZZ<FP> o = sm[(bit + d) * MSM_RED_MAXCHUNK];
+            acc.add(o);
+            sm[t] = acc;
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        if (result_xyzz) result_xyzz[m] = acc;
+        result[m] = acc.to_affine();
+    }
+}
+
+// ---- table construction: table[j*n + i] = 2^(c j) * P_i (affine) ----------------------------------------
+template <class FP>
+__global__ void __launch_bounds__(256) msm_table_kernel(const Affine<FP>* __restrict__ bases, uint32_t n, int c, int W,
+                                                        Affine<FP>* __restrict__ table) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<FP> p = bases[i];
+    table[i] = p;
+    for (int j = 1; j < W; j++) {
+        XYZZ<FP> q = XYZZ<FP>::dbl_affine(p);
+        for (int k = 1; k < c; k++) q = XYZZ<FP>::dbl(q);
+        p = q.to_affine();
+        table[(size_t)j * n + i] = p;
+    }
+}
+
+// ---- out[i] = scalars[i] * base : SRS generation from a known tau (gnark test/unsafekzg, setup/setup.go:103) ----
+template <class FR, class FP>
+__global__ void __launch_bounds__(256) g1_mul_batch_kernel(Affine<FP> base, const Fe<FR>* __restrict__ scalars, uint32_t count,
+                                                           Affine<FP>* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Fe<FR> s = Fe<FR>::from_mont(scalars[i]);
+    XYZZ<FP> acc = XYZZ<FP>::inf();
+    for (int w = Fe<FR>::N - 1; w >= 0; w--) {
+        for (int b = 31; b >= 0; b--) {
+            acc = XYZZ<FP>::dbl(acc);
+            if ((s.l[w] >> b) & 1u) acc.madd(base);
+        }
+    }
+    out[i] = acc.to_affine();
+}
+
+}  // namespace apk

@@ -1,0 +1,123 @@
+// Radix-2 NTT / iNTT over Fr, natural order in -> natural order out, gfx950.
+//
+// What it replaces: gnark-crypto v0.20.1 ecc/<curve>/fr/fft `Domain.FFT / FFTInverse` (+ coset variants)
+// [UPSTREAM, not vendored], reached only through plonk.Prove (/root/reference/algoplonk.go:89).  The
+// domain generator and coset shift are the VK's `Generator` / `CosetShift`
+// (/root/reference/verifier/templateLogicSigBN254.go:57,68).  SURVEY.md §8a row a6.
+//
+// Design: decimation-in-time over a bit-reversed gather.  The log2(N) butterfly stages are cut into
+// passes of <= NTT_PASS_BITS stages; inside a pass a workgroup owns a tile of NTT_TILE = 2048 elements in
+// LDS (64 KiB) - 2^s "mid" positions x C adjacent groups, so global traffic is C*32-byte contiguous runs -
+// and runs its s stages out of LDS.  Each pass is one read + one write of the vector (64 B/element,
+// SURVEY.md §8d).  Optional fused pre-/post-multiplication by a table (coset powers, 1/N) and a zero-padded
+// short input remove the separate scaling / padding passes.
+#pragma once
+#include "ff.h"
+
+namespace apk {
+
+constexpr int NTT_TILE_LOG = 11;  // 2048 elements * 32 B = 64 KiB LDS
+constexpr int NTT_PASS_BITS = 10; // max stages per pass (C = 2^(11-s) adjacent groups -> C*32-B contiguous runs)
+constexpr int NTT_THREADS = 256;
+
+__device__ __forceinline__ uint32_t bitrev32(uint32_t x, int bits) { return __brev(x) >> (32 - bits); }
+
+struct NttPassArgs {
+    int log_n;
+    int t0, t1;          // stages [t0, t1)
+    uint32_t in_len;     // elements >= in_len read as zero (first pass only)
+    int first, last;     // first pass gathers bit-reversed + pre-multiplies; last pass post-multiplies
+    uint32_t out_len;    // last pass: elements >= out_len are not written
+};
+
+// tw[j] = w^j for j < N/2 (w = omega or omega^-1), Montgomery form
+template <class FR>
+__global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fe<FR>* __restrict__ in, Fe<FR>* __restrict__ out,
+                                                               const Fe<FR>* __restrict__ tw,
+                                                               const Fe<FR>* __restrict__ pre,   // or null
+                                                               const Fe<FR>* __restrict__ post,  // or null
+                                                               const Fe<FR>* __restrict__ scale, // or null: one element
+                                                               NttPassArgs a) {
+    using Fr = Fe<FR>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Fr* sm = reinterpret_cast<Fr*>(smem_raw);
+    const int s = a.t1 - a.t0;
+    const int tile_log = min(NTT_TILE_LOG, a.log_n);
+    const int clog = tile_log - s;  // log2(groups per tile)
+    const uint32_t C = 1u << clog;
+    const uint32_t tile_elems = 1u << tile_log;
+    const uint32_t g0 = blockIdx.x << clog;  // first group id of this tile
+    const uint32_t lomask = (1u << a.t0) - 1u;
+
+    // load: element e of the tile = (mid, c) with c fastest
+    for (uint32_t e = threadIdx.x; e < tile_elems; e += NTT_THREADS) {
+        uint32_t c = e & (C - 1), mid = e >> clog;
+        uint32_t g = g0 + c;
+        uint32_t idx = ((g >> a.t0) << a.t1) | (mid << a.t0) | (g & lomask);
+        Fr v;
+        if (a.first) {
+            uint32_t src = bitrev32(idx, a.log_n);
+            if (src < a.in_len) {
+                v = in[src];
+                if (pre) v = v * pre[src];
+            } else {
+                v = Fr::zero();
+            }
+        } else {
+            v = in[idx];
+        }
+        sm[e] = v;
+    }
+    __syncthreads();
+    // s butterfly stages; butterfly id -> (pair index within group, c)
+    const uint32_t nbf = tile_elems >> 1;
+    for (int q = 0; q < s; q++) {
+        const int t = a.t0 + q;
+        for (uint32_t bf = threadIdx.x; bf < nbf; bf += NTT_THREADS) {
+            uint32_t c = bf & (C - 1), pr = bf >> clog;
+            uint32_t low = pr & ((1u << q) - 1u);
+            uint32_t mid0 = ((pr >> q) << (q + 1)) | low;
+            uint32_t mid1 = mid0 | (1u << q);
+            uint32_t g = g0 + c;
+            // twiddle exponent: (index mod 2^t) * N / 2^(t+1)
+            uint32_t imod = (low << a.t0) | (g & lomask);
+            uint32_t tidx = imod << (a.log_n - 1 - t);
+            Fr w = tw[tidx];
+            uint32_t e0 = (mid0 << clog) | c, e1 = (mid1 << clog) | c;
+            Fr u = sm[e0];
+            Fr v = sm[e1] * w;
+            sm[e0] = u + v;
+            sm[e1] = u - v;
+        }
+        __syncthreads();
+    }
+    for (uint32_t e = threadIdx.x; e < tile_elems; e += NTT_THREADS) {
+        uint32_t c = e & (C - 1), mid = e >> clog;
+        uint32_t g = g0 + c;
+        uint32_t idx = ((g >> a.t0) << a.t1) | (mid << a.t0) | (g & lomask);
+        Fr v = sm[e];
+        if (a.last) {
+            if (idx >= a.out_len) continue;
+            if (post) v = v * post[idx];
+            if (scale) v = v * scale[0];
+        }
+        out[idx] = v;
+    }
+}
+
+// tw[j] = w^j, j < count: each thread exponentiates its block start then walks
+template <class FR>
+__global__ void __launch_bounds__(256) powers_kernel(Fe<FR>* __restrict__ out, uint32_t count, Fe<FR> w, Fe<FR> scale) {
+    using Fr = Fe<FR>;
+    constexpr uint32_t PER = 16;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t start = t * PER;
+    if (start >= count) return;
+    Fr cur = Fr::pow_u64(w, start) * scale;
+    for (uint32_t k = 0; k < PER && start + k < count; k++) {
+        out[start + k] = cur;
+        cur = cur * w;
+    }
+}
+
+}  // namespace apk

@@ -1,0 +1,307 @@
+// Element-wise / scan / reduction kernels over Fr vectors used between the NTTs and MSMs of one proof.
+//
+// What they replace (all [UPSTREAM gnark v0.15.0 backend/plonk/<curve>/prove.go + gnark-crypto fr/iop,
+// not vendored]; the formulas themselves are pinned by the reference's verifier template, cited per kernel):
+//   * grand product Z            SURVEY.md §8a row a8; challenge use /root/reference/verifier/templateLogicSigBN254.go:204-215,232-254
+//   * quotient numerator / Z_H   row a7; identity = SURVEY.md App. E (templateLogicSigBN254.go:203-278)
+//   * Horner evaluations, folding and (f - f(z))/(X - z)    row a9; order pinned at templateLogicSigBN254.go:289-320
+// All are HBM-streaming kernels: 32 B/element/operand, one read of each operand and one write.
+#pragma once
+#include "ff.h"
+
+namespace apk {
+
+constexpr int POLY_THREADS = 256;
+constexpr int SCAN_PER_THREAD = 8;
+constexpr int SCAN_BLOCK = POLY_THREADS * SCAN_PER_THREAD;  // 2048 elements per block
+
+template <class FR>
+struct Fr4 { Fe<FR> v[4]; };
+
+// ---- small helpers ------------------------------------------------------------------------------------------
+template <class FR>
+__global__ void fill_zero_kernel(Fe<FR>* p, uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) p[i] = Fe<FR>::zero();
+}
+
+// p(X) += b(X) (X^n - 1), deg b = d-1 <= 2;  p has capacity n+d, p[n..n+d) must be zero on entry
+template <class FR>
+__global__ void blind_kernel(Fe<FR>* p, uint32_t n, Fr4<FR> b, int d) {
+    int i = threadIdx.x;
+    if (i < d) {
+        p[i] = p[i] - b.v[i];
+        p[n + i] = b.v[i];
+    }
+}
+
+// out[i] = a[i] * b[i]  (b indexed with offset/stride so tables can be reused)
+template <class FR>
+__global__ void mul_kernel(Fe<FR>* out, const Fe<FR>* a, const Fe<FR>* b, uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = a[i] * b[i];
+}
+
+// ---- grand product ------------------------------------------------------------------------------------------
+// ratio[i] = prod_j (w_j[i] + beta*u^j*omega^i + gamma) / prod_j (w_j[i] + beta*S_j[i] + gamma)
+// omega^i comes from the size-n twiddle table (tw[i] for i < n/2, -tw[i-n/2] above).
+// One lane inverts GP_CHUNK denominators with one Fermat inversion (Montgomery's trick).
+constexpr int GP_CHUNK = 8;
+template <class FR>
+__global__ void __launch_bounds__(POLY_THREADS) gp_ratio_kernel(const Fe<FR>* __restrict__ L, const Fe<FR>* __restrict__ R,
+                                                                const Fe<FR>* __restrict__ O, const Fe<FR>* __restrict__ S1,
+                                                                const Fe<FR>* __restrict__ S2, const Fe<FR>* __restrict__ S3,
+                                                                const Fe<FR>* __restrict__ tw, uint32_t n, Fe<FR> beta,
+                                                                Fe<FR> gamma, Fe<FR> beta_u, Fe<FR> beta_u2,
+                                                                Fe<FR>* __restrict__ ratio) {
+    using Fr = Fe<FR>;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t base = t * GP_CHUNK;
+    if (base >= n) return;
+    Fr num[GP_CHUNK], pre[GP_CHUNK], den[GP_CHUNK];
+    Fr run = Fr::one();
+#pragma unroll
+    for (int k = 0; k < GP_CHUNK; k++) {
+        uint32_t i = base + k;
+        if (i < n) {
+            Fr w = i < n / 2 ? tw[i] : Fr::neg(tw[i - n / 2]);
+            Fr l = L[i] + gamma, r = R[i] + gamma, o = O[i] + gamma;
+            num[k] = (l + beta * w) * (r + beta_u * w) * (o + beta_u2 * w);
+            den[k] = (l + beta * S1[i]) * (r + beta * S2[i]) * (o + beta * S3[i]);
+        } else {
+            num[k] = Fr::one();
+            den[k] = Fr::one();
+        }
+        pre[k] = run;
+        run = run * den[k];
+    }
+    Fr inv = Fr::inv(run);
+#pragma unroll
+    for (int k = GP_CHUNK - 1; k >= 0; k--) {
+        uint32_t i = base + k;
+        Fr dinv = inv * pre[k];
+        inv = inv * den[k];
+        if (i < n) ratio[i] = num[k] * dinv;
+    }
+}
+
+// ---- generic scans over Fr: op = multiply (grand product) or add (suffix sums for the KZG quotient) ------
+struct OpMul { template <class F> __device__ static F apply(const F& a, const F& b) { return a * b; }
+               template <class F> __device__ static F identity() { return F::one(); } };
+struct OpAdd { template <class F> __device__ static F apply(const F& a, const F& b) { return a + b; }
+               template <class F> __device__ static F identity() { return F::zero(); } };
+
+// logical index i -> memory index: forward (i) or reversed (count-1-i) so the same code does suffix scans
+__device__ __forceinline__ uint32_t scan_idx(uint32_t i, uint32_t count, bool rev) { return rev ? count - 1 - i : i; }
+
+// phase 1: per-block inclusive scan in place; block totals out
+template <class FR, class OP>
+__global__ void __launch_bounds__(POLY_THREADS) scan_block_kernel(Fe<FR>* __restrict__ data, uint32_t count, bool rev,
+                                                                  Fe<FR>* __restrict__ block_tot) {
+    using Fr = Fe<FR>;
+    __shared__ Fr sm[POLY_THREADS];
+    const uint32_t t = threadIdx.x;
+    const uint32_t base = blockIdx.x * SCAN_BLOCK + t * SCAN_PER_THREAD;
+    Fr v[SCAN_PER_THREAD];
+    Fr run = OP::template identity<Fr>();
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; k++) {
+        uint32_t i = base + k;
+        Fr x = i < count ? data[scan_idx(i, count, rev)] : OP::template identity<Fr>();
+        run = OP::apply(run, x);
+        v[k] = run;
+    }
+    sm[t] = run;
+    __syncthreads();
+    Fr mine = run;
+    for (uint32_t d = 1; d < POLY_THREADS; d <<= 1) {
+        Fr o = OP::template identity<Fr>();
+        if (t >= d) o = sm[t - d];
+        __syncthreads();
+        mine = OP::apply(o, mine);
+        sm[t] = mine;
+        __syncthreads();
+    }
+    Fr excl = t == 0 ? OP::template identity<Fr>() : sm[t - 1];
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; k++) {
+        uint32_t i = base + k;
+        if (i < count) data[scan_idx(i, count, rev)] = OP::apply(excl, v[k]);
+    }
+    if (t == POLY_THREADS - 1) block_tot[blockIdx.x] = mine;
+}
+
+// phase 2: single block, exclusive scan of block totals in place (nblocks <= POLY_THREADS * 64)
+template <class FR, class OP>
+__global__ void __launch_bounds__(POLY_THREADS) scan_totals_kernel(Fe<FR>* __restrict__ tot, uint32_t nblocks) {
+    using Fr = Fe<FR>;
+    __shared__ Fr sm[POLY_THREADS];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (nblocks + POLY_THREADS - 1) / POLY_THREADS;
+    const uint32_t lo = min(t * per, nblocks), hi = min(lo + per, nblocks);
+    Fr run = OP::template identity<Fr>();
+    for (uint32_t i = lo; i < hi; i++) run = OP::apply(run, tot[i]);
+    sm[t] = run;
+    __syncthreads();
+    Fr mine = run;
+    for (uint32_t d = 1; d < POLY_THREADS; d <<= 1) {
+        Fr o = OP::template identity<Fr>();
+        if (t >= d) o = sm[t - d];
+        __syncthreads();
+        mine = OP::apply(o, mine);
+        sm[t] = mine;
+        __syncthreads();
+    }
+    Fr acc = t == 0 ? OP::template identity<Fr>() : sm[t - 1];
+    for (uint32_t i = lo; i < hi; i++) {
+        Fr x = tot[i];
+        tot[i] = acc;  // exclusive
+        acc = OP::apply(acc, x);
+    }
+}
+
+// phase 3: fold the block prefix in.  `shift` turns the inclusive scan into the exclusive one the grand
+// product wants: out[0] = identity, out[i] = inclusive[i-1] (forward scans only).
+template <class FR, class OP>
+__global__ void __launch_bounds__(POLY_THREADS) scan_apply_kernel(const Fe<FR>* __restrict__ data, uint32_t count, bool rev,
+                                                                  const Fe<FR>* __restrict__ block_excl,
+                                                                  Fe<FR>* __restrict__ out, int shift) {
+    using Fr = Fe<FR>;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Fr v = OP::apply(block_excl[i / SCAN_BLOCK], data[scan_idx(i, count, rev)]);
+    if (shift) {
+        if (i + 1 < count) out[i + 1] = v;
+        if (i == 0) out[0] = OP::template identity<Fr>();
+    } else {
+        out[scan_idx(i, count, rev)] = v;
+    }
+}
+
+// ---- quotient numerator on the 4n coset, divided by Z_H ---------------------------------------------------
+// gate + alpha*(Z(wX) prod(w_j + beta S_j + gamma) - Z(X) prod(w_j + beta u^j X + gamma)) + alpha^2 L_0 (Z - 1)
+// (the linearised twin is templateLogicSigBN254.go:203-278).
+template <class FR>
+struct QuotientArgs {
+    const Fe<FR>*l, *r, *o, *z, *qk;                // per proof, 4n evaluations
+    const Fe<FR>*ql, *qr, *qm, *qo, *s1, *s2, *s3;  // per circuit
+    const Fe<FR>*x, *l0;                            // coset points, L_0 on the coset
+    const Fe<FR>* qcp[2];
+    const Fe<FR>* pi2[2];
+    int nb_commit;
+    Fe<FR> alpha, beta, gamma, beta_u, beta_u2, alpha2;
+    Fe<FR> zh_inv[4];
+    uint32_t n4;
+};
+
+template <class FR>
+__global__ void __launch_bounds__(POLY_THREADS) quotient_kernel(QuotientArgs<FR> a, Fe<FR>* __restrict__ out) {
+    using Fr = Fe<FR>;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n4) return;
+    Fr l = a.l[i], r = a.r[i], o = a.o[i], z = a.z[i];
+    uint32_t is = i + 4 < a.n4 ? i + 4 : i + 4 - a.n4;
+    Fr zs = a.z[is];
+    Fr gate = a.ql[i] * l + a.qr[i] * r + a.qm[i] * (l * r) + a.qo[i] * o + a.qk[i];
+    for (int k = 0; k < a.nb_commit; k++) gate = gate + a.qcp[k][i] * a.pi2[k][i];
+    Fr lg = l + a.gamma, rg = r + a.gamma, og = o + a.gamma;
+    Fr x = a.x[i];
+    Fr pa = zs * (lg + a.beta * a.s1[i]) * (rg + a.beta * a.s2[i]) * (og + a.beta * a.s3[i]);
+    Fr pb = z * (lg + a.beta * x) * (rg + a.beta_u * x) * (og + a.beta_u2 * x);
+    Fr loc = a.l0[i] * (z - Fr::one());
+    Fr num = gate + a.alpha * (pa - pb) + a.alpha2 * loc;
+    out[i] = num * a.zh_inv[i & 3];
+}
+
+// ---- evaluation: partial[p][block] = sum_i f_p[i] * pw[i] -------------------------------------------------
+constexpr int EVAL_MAX = 12;
+template <class FR>
+struct EvalArgs {
+    const Fe<FR>* f[EVAL_MAX];
+    uint32_t len[EVAL_MAX];
+    int count;
+};
+constexpr int EVAL_PER_THREAD = 8;
+constexpr int EVAL_BLOCK = POLY_THREADS * EVAL_PER_THREAD;
+
+template <class FR>
+__global__ void __launch_bounds__(POLY_THREADS) eval_partial_kernel(EvalArgs<FR> a, const Fe<FR>* __restrict__ pw,
+                                                                    uint32_t nblocks, Fe<FR>* __restrict__ partial) {
+    using Fr = Fe<FR>;
+    __shared__ Fr sm[POLY_THREADS];
+    const int p = blockIdx.y;
+    const uint32_t t = threadIdx.x;
+    const Fr* f = a.f[p];
+    const uint32_t len = a.len[p];
+    Fr acc = Fr::zero();
+    for (int k = 0; k < EVAL_PER_THREAD; k++) {
+        uint32_t i = blockIdx.x * EVAL_BLOCK + k * POLY_THREADS + t;
+        if (i < len) acc = acc + f[i] * pw[i];
+    }
+    sm[t] = acc;
+    __syncthreads();
+    for (uint32_t d = POLY_THREADS / 2; d >= 1; d >>= 1) {
+        if (t < d) { acc = acc + sm[t + d]; sm[t] = acc; }
+        __syncthreads();
+    }
+    if (t == 0) partial[p * nblocks + blockIdx.x] = acc;
+}
+
+template <class FR>
+__global__ void __launch_bounds__(POLY_THREADS) eval_final_kernel(const Fe<FR>* __restrict__ partial, uint32_t nblocks,
+                                                                  Fe<FR>* __restrict__ result) {
+    using Fr = Fe<FR>;
+    __shared__ Fr sm[POLY_THREADS];
+    const int p = blockIdx.x;
+    const uint32_t t = threadIdx.x;
+    Fr acc = Fr::zero();
+    for (uint32_t i = t; i < nblocks; i += POLY_THREADS) acc = acc + partial[p * nblocks + i];
+    sm[t] = acc;
+    __syncthreads();
+    for (uint32_t d = POLY_THREADS / 2; d >= 1; d >>= 1) {
+        if (t < d) { acc = acc + sm[t + d]; sm[t] = acc; }
+        __syncthreads();
+    }
+    if (t == 0) result[p] = acc;
+}
+
+// ---- out[i] = sum_k coef[k] * f_k[i]  (linearised polynomial, folded opening polynomial) -------------------
+constexpr int LC_MAX = 14;
+template <class FR>
+struct LinCombArgs {
+    const Fe<FR>* f[LC_MAX];
+    uint32_t len[LC_MAX];
+    Fe<FR> coef[LC_MAX];
+    int count;
+    uint32_t out_len;
+};
+
+template <class FR>
+__global__ void __launch_bounds__(POLY_THREADS) lincomb_kernel(LinCombArgs<FR> a, Fe<FR>* __restrict__ out) {
+    using Fr = Fe<FR>;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.out_len) return;
+    Fr acc = Fr::zero();
+    for (int k = 0; k < a.count; k++)
+        if (i < a.len[k]) acc = acc + a.coef[k] * a.f[k][i];
+    out[i] = acc;
+}
+
+// q[j] = zinv_pw[j+1] * suffix[j+1], j < len-1   where suffix[i] = sum_{k>=i} f[k] z^k
+template <class FR>
+__global__ void __launch_bounds__(POLY_THREADS) div_finish_kernel(const Fe<FR>* __restrict__ suffix,
+                                                                  const Fe<FR>* __restrict__ zinv_pw, uint32_t len,
+                                                                  Fe<FR>* __restrict__ q) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j + 1 >= len) return;
+    q[j] = suffix[j + 1] * zinv_pw[j + 1];
+}
+
+// z == 0 fallback: q[j] = f[j+1]
+template <class FR>
+__global__ void shift_down_kernel(const Fe<FR>* __restrict__ f, uint32_t len, Fe<FR>* __restrict__ q) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j + 1 < len) q[j] = f[j + 1];
+}
+
+}  // namespace apk

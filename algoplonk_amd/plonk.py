@@ -1,0 +1,167 @@
+"""`plonk.Setup` / `plonk.Prove` as the reference calls them (/root/reference/setup/setup.go:107,149 and
+/root/reference/algoplonk.go:89), bound to libapk's C-ABI.  Everything heavy runs in the HIP library; this module
+only packs arrays into gnark's in-memory layout and unpacks the proof struct.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+from . import ecc, frontend
+from . import _lib
+from ._lib import lib, check
+from .setup import SRS
+
+
+@dataclass
+class VerifyingKey:
+    """Fields the generated verifiers consume (verifier/templateLogicSigBN254.go:21-28,50-72)."""
+    curve: ecc.ID
+    Size: int
+    SizeInv: int
+    Generator: int
+    CosetShift: int
+    NbPublicVariables: int
+    Ql: ecc.Point
+    Qr: ecc.Point
+    Qm: ecc.Point
+    Qo: ecc.Point
+    Qk: ecc.Point
+    S: List[ecc.Point]
+    Qcp: List[ecc.Point]
+    CommitmentConstraintIndexes: List[int]
+    KzgG1: ecc.Point
+    tau: Optional[int] = None   # TestOnly setups: stands in for Kzg.G2 = ([1]G2, [tau]G2)
+
+
+class ProvingKey:
+    """Owns the libapk circuit context (SRS tables, trace polynomials, workspaces resident in HBM)."""
+
+    def __init__(self, curve: ecc.ID, ctx: int, n: int, nb_public: int):
+        self.curve = curve
+        self._ctx = C.c_void_p(ctx)
+        self.n = n
+        self.nb_public = nb_public
+
+    @property
+    def ctx(self) -> C.c_void_p:
+        if not self._ctx:
+            raise RuntimeError("proving key was closed")
+        return self._ctx
+
+    def close(self) -> None:
+        if self._ctx:
+            lib.apk_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p(None)
+
+    def __del__(self):  # best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # primitives of SURVEY.md §8a rows a4 / a6, exposed for tests and benchmarks
+    def msm(self, scalars: Sequence[int], basis: int = 0) -> ecc.Point:
+        cv = self.curve
+        buf = cv.fr_vector(scalars)
+        out = C.create_string_buffer(2 * cv.fp_bytes)
+        check(lib.apk_msm_g1(self.ctx, basis, buf, len(scalars), out))
+        return cv.g1_from_bytes(out.raw)
+
+    def ntt(self, values: Sequence[int], which: int = 0, inverse: bool = False, coset: bool = False) -> List[int]:
+        cv = self.curve
+        buf = C.create_string_buffer(cv.fr_vector(values), len(values) * 32)
+        check(lib.apk_ntt(self.ctx, which, int(inverse), int(coset), buf))
+        return cv.fr_vector_decode(buf.raw)
+
+    def stats(self, reset: bool = False) -> "_lib.Stats":
+        st = _lib.Stats()
+        check(lib.apk_stats_read(self.ctx, C.byref(st), int(reset)))
+        return st
+
+    def enable_stats(self, on: bool = True) -> None:
+        check(lib.apk_stats_enable(self.ctx, int(on)))
+
+
+@dataclass
+class Proof:
+    """gnark plonk_{bn254,bls12381}.Proof, field for field (helper.go:35-84; bsb22_test.go:71-93)."""
+    curve: ecc.ID
+    raw: "_lib.Proof"
+
+    def _pt(self, slot) -> ecc.Point:
+        return self.curve.g1_from_bytes(bytes(slot))
+
+    def _fr(self, slot) -> int:
+        return self.curve.fr_from_mont_bytes(bytes(slot))
+
+    @property
+    def LRO(self): return [self._pt(self.raw.lro[i]) for i in range(3)]
+    @property
+    def Z(self): return self._pt(self.raw.z)
+    @property
+    def H(self): return [self._pt(self.raw.h[i]) for i in range(3)]
+    @property
+    def Bsb22Commitments(self): return [self._pt(self.raw.bsb22[i]) for i in range(self.raw.nb_commitments)]
+    @property
+    def BatchedProofH(self): return self._pt(self.raw.batched_h)
+    @property
+    def ClaimedValues(self): return [self._fr(self.raw.claimed_values[i]) for i in range(6 + self.raw.nb_commitments)]
+    @property
+    def ZShiftedOpeningH(self): return self._pt(self.raw.zshift_h)
+    @property
+    def ZShiftedOpeningClaimedValue(self): return self._fr(self.raw.zshift_value)
+    @property
+    def challenges(self): return {k: self._fr(getattr(self.raw, k)) for k in ("gamma", "beta", "alpha", "zeta", "gamma_kzg")}
+
+
+def Setup(ccs: frontend.ConstraintSystem, srs: SRS, device: int = 0, msm_window: int = 0, slots: int = 1):
+    """plonk.Setup(ccs, srs, lagrangeSrs) (setup/setup.go:107,149): returns (ProvingKey, VerifyingKey)."""
+    cv = srs.curve
+    tr = frontend.build_trace(ccs)
+    if tr.n != srs.n:
+        raise ValueError("SRS sized for n=%d, circuit needs n=%d" % (srs.n, tr.n))
+    cols = [cv.fr_vector(c) for c in (tr.ql, tr.qr, tr.qm, tr.qo, tr.qk)]
+    perm = (C.c_int64 * len(tr.perm))(*tr.perm)
+    d = _lib.CircuitDesc()
+    d.curve, d.device, d.n = cv.abi, device, tr.n
+    d.nb_public, d.nb_commitments = ccs.GetNbPublicVariables(), 0
+    keep = [srs.g1, srs.g1_lagrange] + cols
+    d.srs_g1 = C.cast(C.c_char_p(srs.g1), C.c_void_p)
+    d.srs_g1_lagrange = C.cast(C.c_char_p(srs.g1_lagrange), C.c_void_p) if srs.g1_lagrange else None
+    d.ql, d.qr, d.qm, d.qo, d.qk = (C.cast(C.c_char_p(c), C.c_void_p) for c in cols)
+    d.perm = C.cast(perm, C.c_void_p)
+    d.msm_window, d.slots = msm_window, slots
+    ctx = C.c_void_p()
+    check(lib.apk_ctx_create(C.byref(d), C.byref(ctx)))
+    del keep
+    pk = ProvingKey(cv, ctx.value, tr.n, ccs.GetNbPublicVariables())
+    raw = _lib.Vk()
+    check(lib.apk_ctx_get_vk(pk.ctx, C.byref(raw)))
+    P = lambda slot: cv.g1_from_bytes(bytes(slot))
+    F = lambda slot: cv.fr_from_mont_bytes(bytes(slot))
+    vk = VerifyingKey(
+        curve=cv, Size=tr.n, SizeInv=F(raw.size_inv), Generator=F(raw.generator), CosetShift=F(raw.coset_shift),
+        NbPublicVariables=ccs.GetNbPublicVariables(), Ql=P(raw.ql), Qr=P(raw.qr), Qm=P(raw.qm), Qo=P(raw.qo), Qk=P(raw.qk),
+        S=[P(raw.s[i]) for i in range(3)], Qcp=[], CommitmentConstraintIndexes=[],
+        KzgG1=cv.g1_from_bytes(srs.g1[: 2 * cv.fp_bytes]), tau=srs.tau)
+    return pk, vk
+
+
+def Prove(ccs: frontend.ConstraintSystem, pk: ProvingKey, witness: frontend.Witness,
+          blinding: Optional[Sequence[int]] = None) -> Proof:
+    """plonk.Prove(ccs, pk, witness) (/root/reference/algoplonk.go:89).  `blinding` = the 9 scalars gnark draws
+    from crypto/rand; drawn from os.urandom when omitted."""
+    cv = pk.curve
+    solution = frontend.solve(ccs, witness)
+    L, R, O = frontend.wire_columns(ccs, solution)
+    if blinding is None:
+        blinding = [int.from_bytes(os.urandom(48), "big") % cv.r for _ in range(_lib.NB_BLINDING)]
+    if len(blinding) != _lib.NB_BLINDING:
+        raise ValueError("need %d blinding scalars" % _lib.NB_BLINDING)
+    out = _lib.Proof()
+    check(lib.apk_prove(pk.ctx, cv.fr_vector(L), cv.fr_vector(R), cv.fr_vector(O), cv.fr_vector(witness.public),
+                        cv.fr_vector(blinding), None, C.byref(out)))
+    return Proof(cv, out)

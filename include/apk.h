@@ -1,0 +1,180 @@
+/* libapk - C-ABI of the MI355X-native PLONK prover path for AlgoPlonk.
+ *
+ * Drop-in boundary.  The reference has no FFI of its own: the hot path is the Go call
+ *     proof, err := plonk.Prove(cc.Ccs, cc.Pk, witness)         /root/reference/algoplonk.go:89
+ * (second call site /root/reference/testutils/testutils.go:47) and the one-time
+ *     plonk.Setup(ccs, srs, lagrangeSrs)                         /root/reference/setup/setup.go:107,149
+ * A cgo shim replaces those calls with the entry points below.  Every buffer uses
+ * gnark's in-memory layout so the shim passes unsafe.Pointer(&slice[0]) with zero copies:
+ *   - Fr / Fp element : little-endian limbs, Montgomery form (gnark-crypto fr.Element / fp.Element);
+ *                       32 bytes for Fr (both curves), 32 (BN254) / 48 (BLS12-381) bytes for Fp
+ *   - G1 affine       : X || Y, each an Fp element as above; (0,0) is the point at infinity
+ * No torch types, no C++ types: plain pointers and sizes.  All functions return APK_OK (0) or an error
+ * code; apk_last_error() gives the message for the calling thread.  Nothing panics or aborts across the
+ * boundary (the reference wraps errors with fmt.Errorf, algoplonk.go:90-92).
+ *
+ * There is NO CPU fallback: every compute entry point fails with APK_ERR_HIP when no gfx950 device is
+ * usable.  The oracle under oracle/ is test infrastructure and is never linked into this library.
+ */
+#ifndef APK_H
+#define APK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APK_ABI_VERSION 1
+
+/* curve ids: the two curves the AVM supports (algoplonk.go:39-41) */
+#define APK_BN254 0
+#define APK_BLS12_381 1
+
+#define APK_OK 0
+#define APK_ERR_ARG 1      /* bad argument (unknown curve, n not a power of two, null pointer ...) */
+#define APK_ERR_HIP 2      /* HIP runtime failure, including "no device" */
+#define APK_ERR_STATE 3    /* call not valid for this context (e.g. Lagrange MSM without a Lagrange SRS) */
+#define APK_ERR_WITNESS 4  /* the witness does not satisfy the circuit (quotient not a polynomial) */
+
+#define APK_FR_BYTES 32
+#define APK_G1_MAX_BYTES 96       /* BLS12-381 affine; BN254 uses the first 64 bytes of a slot */
+#define APK_MAX_COMMITMENTS 2     /* BSB22 commitments per circuit (reference documents 0/1/2: README.md:27-30) */
+#define APK_NB_BLINDING 9         /* bl0,bl1, br0,br1, bo0,bo1, bz0,bz1,bz2 */
+
+typedef struct apk_ctx apk_ctx;
+
+const char* apk_last_error(void);
+int apk_abi_version(void);
+/* number of visible HIP devices (0 and APK_OK when the runtime loads but no GPU is present) */
+int apk_device_count(int* count);
+/* bytes of one G1 affine point / one Fp element for a curve id; 0 for an unknown id */
+size_t apk_g1_bytes(int curve);
+size_t apk_fp_bytes(int curve);
+
+/* ---- circuit context: replaces plonk.Setup's output + the per-proof trace rebuild ----------------------
+ * One context per (device, curve, circuit).  It owns, resident in HBM: the KZG SRS with its windowed point
+ * tables, the trace polynomials (Lagrange, canonical and 4n-coset forms), the permutation polynomials, the NTT
+ * twiddles and `slots` independent proving workspaces.  Inputs are copied; the caller keeps ownership
+ * (SURVEY.md §8b "nothing is retained by the callee").
+ */
+typedef struct {
+    int curve;                 /* APK_BN254 / APK_BLS12_381 */
+    int device;                /* HIP device ordinal */
+    uint64_t n;                /* domain size: NextPowerOfTwo(nbConstraints + nbPublic), >= 8 (setup/setup.go:113-114) */
+    uint32_t nb_public;        /* VK NbPublicVariables */
+    uint32_t nb_commitments;   /* BSB22 commitments (<= APK_MAX_COMMITMENTS) */
+    const void* srs_g1;        /* n+3 G1 affine: canonical SRS  = gnark kzg.ProvingKey.G1 (setup/setup.go:113-114) */
+    const void* srs_g1_lagrange; /* n G1 affine: Lagrange SRS (setup/setup.go:124,138); NULL if nb_commitments == 0 */
+    const void* ql;            /* trace columns in Lagrange form, n Fr each  = gnark plonk.Trace{Ql,Qr,Qm,Qo,Qk} */
+    const void* qr;
+    const void* qm;
+    const void* qo;
+    const void* qk;            /* public rows zero */
+    const int64_t* perm;       /* 3n entries = gnark Trace.S */
+    const void* qcp[APK_MAX_COMMITMENTS];               /* n Fr each */
+    uint32_t commitment_constraint_index[APK_MAX_COMMITMENTS]; /* VK CommitmentConstraintIndexes */
+    int msm_window;            /* signed-digit window bits; 0 = choose from n */
+    int slots;                 /* concurrent proofs in flight on this context; 0 = 1 */
+} apk_circuit_desc;
+
+int apk_ctx_create(const apk_circuit_desc* desc, apk_ctx** out);
+void apk_ctx_destroy(apk_ctx* ctx);
+
+/* Verifying-key commitments produced during context creation (the 8+k MSMs of plonk.Setup).
+ * Each slot is APK_G1_MAX_BYTES wide, gnark in-memory affine form. Order: Ql,Qr,Qm,Qo,Qk,S1,S2,S3,Qcp_0.. */
+typedef struct {
+    uint8_t ql[APK_G1_MAX_BYTES], qr[APK_G1_MAX_BYTES], qm[APK_G1_MAX_BYTES], qo[APK_G1_MAX_BYTES], qk[APK_G1_MAX_BYTES];
+    uint8_t s[3][APK_G1_MAX_BYTES];
+    uint8_t qcp[APK_MAX_COMMITMENTS][APK_G1_MAX_BYTES];
+    uint8_t size_inv[APK_FR_BYTES], generator[APK_FR_BYTES], coset_shift[APK_FR_BYTES]; /* Fr, Montgomery */
+} apk_vk;
+int apk_ctx_get_vk(apk_ctx* ctx, apk_vk* out);
+
+/* ---- primitives (row a4 / a6 of SURVEY.md §8a) --------------------------------------------------------- */
+/* kzg.Commit: sum scalars[i] * SRS[i].  basis 0 = canonical SRS (len <= n+3), 1 = Lagrange SRS (len <= n).
+ * scalars: host memory, `len` Fr in Montgomery form.  out: one G1 affine (apk_g1_bytes). */
+int apk_msm_g1(apk_ctx* ctx, int basis, const void* scalars, uint64_t len, void* out);
+/* same, scalars already resident in device memory (what bench.py times: inputs in HBM) */
+int apk_msm_g1_device(apk_ctx* ctx, int basis, const void* d_scalars, uint64_t len, void* out);
+/* fft.Domain.FFT / FFTInverse on the context's size-n (which=0) or size-4n (which=1) domain, natural order in
+ * and out; coset != 0 evaluates on / interpolates from the coset CosetShift * <omega>.  data: host, in place. */
+int apk_ntt(apk_ctx* ctx, int which, int inverse, int coset, void* data);
+
+/* ---- the prover: replaces plonk.Prove (algoplonk.go:89) ------------------------------------------------ */
+typedef struct {
+    uint32_t curve;
+    uint32_t nb_commitments;
+    uint8_t lro[3][APK_G1_MAX_BYTES];                      /* Proof.LRO */
+    uint8_t z[APK_G1_MAX_BYTES];                           /* Proof.Z */
+    uint8_t h[3][APK_G1_MAX_BYTES];                        /* Proof.H */
+    uint8_t bsb22[APK_MAX_COMMITMENTS][APK_G1_MAX_BYTES];  /* Proof.Bsb22Commitments */
+    uint8_t batched_h[APK_G1_MAX_BYTES];                   /* Proof.BatchedProof.H */
+    uint8_t claimed_values[6 + APK_MAX_COMMITMENTS][APK_FR_BYTES]; /* Proof.BatchedProof.ClaimedValues: lin,l,r,o,s1,s2,qcp.. */
+    uint8_t zshift_h[APK_G1_MAX_BYTES];                    /* Proof.ZShiftedOpening.H */
+    uint8_t zshift_value[APK_FR_BYTES];                    /* Proof.ZShiftedOpening.ClaimedValue */
+    /* diagnostics (not part of gnark's Proof): the Fiat-Shamir challenges, Fr Montgomery */
+    uint8_t gamma[APK_FR_BYTES], beta[APK_FR_BYTES], alpha[APK_FR_BYTES], zeta[APK_FR_BYTES], gamma_kzg[APK_FR_BYTES];
+} apk_proof;
+
+/* Inputs (host memory, gnark layout): the solved wire columns L,R,O in Lagrange form (n Fr each) - what gnark's
+ * solver leaves in `SparseR1CSSolution{L,R,O}`; the public inputs (nb_public Fr) = fullWitness[:nbPublic];
+ * the 9 blinding scalars (APK_NB_BLINDING Fr) that gnark draws from crypto/rand - explicit here so proofs are
+ * reproducible; pi2 = BSB22 committed columns (Lagrange, n Fr each, hiding entries placed) or NULL.
+ * Blocks the calling thread; safe to call from several threads (each takes a free slot). */
+int apk_prove(apk_ctx* ctx, const void* L, const void* R, const void* O, const void* public_inputs,
+              const void* blinding, const void* const* pi2, apk_proof* out);
+
+/* Variant with L,R,O already resident in device memory (n Fr each). */
+int apk_prove_device(apk_ctx* ctx, const void* d_L, const void* d_R, const void* d_O, const void* public_inputs,
+                     const void* blinding, const void* const* d_pi2, apk_proof* out);
+
+/* ---- test-only SRS generation: the device half of gnark's test/unsafekzg.NewSRS (setup/setup.go:102-108) ---
+ * out[i] = scalars[i] * base.  Host buffers; scalars Fr Montgomery; base/out G1 affine.  The caller supplies
+ * tau^i (canonical SRS) or L_i(tau) (Lagrange SRS) as the scalars. */
+int apk_g1_mul_batch(int curve, int device, const void* base, const void* scalars, uint64_t count, void* out);
+
+/* ---- wire formats (host only, no GPU needed): replace MarshalProof / MarshalPublicInputs ----------------- */
+/* helper.go:13-24,27-88: 768 + 96k bytes (BN254) / 1056 + 128k bytes (BLS12-381).  Returns the length in *len. */
+int apk_marshal_proof(const apk_proof* proof, uint8_t* out, size_t cap, size_t* len);
+/* helper.go:91-110: nb_public * 32 big-endian canonical bytes. */
+int apk_marshal_public_inputs(int curve, const void* public_inputs, uint32_t nb_public, uint8_t* out, size_t cap);
+/* Montgomery <-> canonical big-endian conversions for Fr (field=0) and Fp (field=1) elements; host only. */
+int apk_fe_from_be(int curve, int field, const uint8_t* be, void* out);
+int apk_fe_to_be(int curve, int field, const void* in, uint8_t* be);
+/* hash_to_field with DST "BSB22-Plonk" over a marshalled G1 point (templateLogicSigBN254.go:386-397); host only. */
+int apk_hash_fr(int curve, const void* g1_affine, void* out_fr);
+
+/* ---- diagnostics: run the library's own field / curve templates on the HOST (no GPU).  The kernels are built
+ * from the same templates, so the CPU-only test tier can pin the formulas against the oracle.
+ * field ops: 0 add, 1 sub, 2 mul (Montgomery), 3 inverse, 4 neg.  field: 0 = Fr, 1 = Fp.
+ * g1 ops: 0 mixed add p+q, 1 full XYZZ add p+q, 2 double p, 3 scalar mul q*p (q = Fr Montgomery). */
+int apk_host_fe_op(int curve, int field, int op, const void* a, const void* b, void* out);
+int apk_host_g1_op(int curve, int op, const void* p, const void* q, void* out);
+
+/* ---- device memory helpers for callers that keep inputs resident (bench, batched proofs) ------------------ */
+int apk_device_alloc(apk_ctx* ctx, size_t bytes, void** d_ptr);
+int apk_device_free(apk_ctx* ctx, void* d_ptr);
+int apk_device_upload(apk_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int apk_device_download(apk_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+
+/* ---- timing hooks used by bench.py: HIP-event time of the dominant kernel on the stream it runs on ------- */
+typedef struct {
+    double msm_accumulate_ms;  /* sum of msm_accumulate_kernel durations since the last reset */
+    uint64_t msm_accumulate_launches;
+    uint64_t msm_pairs;        /* (scalar, point) pairs those launches covered */
+    double msm_total_ms;       /* whole MSM batches (digits .. final) */
+    uint64_t msm_batches;
+    double ntt_ms;             /* all NTT passes */
+    uint64_t ntt_elements;     /* elements transformed (sum of sizes) */
+    double prove_ms;           /* wall time inside apk_prove* */
+    uint64_t proofs;
+} apk_stats;
+int apk_stats_enable(apk_ctx* ctx, int enable); /* enabling inserts hipEvents around the kernels above */
+int apk_stats_read(apk_ctx* ctx, apk_stats* out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APK_H */
