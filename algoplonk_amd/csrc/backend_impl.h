@@ -380,13 +380,13 @@ class CurveBackend : public Backend {
         // domain constants on the host (gnark fft.NewDomain [UPSTREAM]; generator = VK Generator,
         // templateLogicSigBN254.go:57; shift = VK CosetShift :68)
         Fr root = root_of_unity();
-        const int adicity = CURVE_ID == 0 ? 28 : 32;
+        const int adicity = FRP::ADICITY;
         omega4_ = root;
         for (int i = 0; i < adicity - (int)log_n_ - 2; i++) omega4_ = Fr::sqr(omega4_);
         omega_ = Fr::sqr(Fr::sqr(omega4_));
         omega_inv_ = Fr::inv(omega_);
         omega4_inv_ = Fr::inv(omega4_);
-        shift_ = fr_u64(CURVE_ID == 0 ? 5 : 7);
+        shift_ = fr_u64(FRP::COSET_SHIFT);
         shift_inv_ = Fr::inv(shift_);
         n_inv_ = Fr::inv(fr_u64(n_));
         n4_inv_ = Fr::inv(fr_u64(n4_));
@@ -441,13 +441,10 @@ class CurveBackend : public Backend {
     }
 
     static Fr root_of_unity() {
-        // primitive 2^28 (BN254) / 2^32 (BLS12-381) root of unity in Fr [UPSTREAM gnark-crypto fr/fft], canonical
-        // big-endian; verified numerically in SURVEY.md App. C
-        static const uint8_t bn[32] = {0x2a, 0x3c, 0x09, 0xf0, 0xa5, 0x8a, 0x7e, 0x85, 0x00, 0xe0, 0xa7, 0xeb, 0x8e, 0xf6, 0x27, 0x78,
-                                       0x68, 0x64, 0x1c, 0x4b, 0x28, 0x29, 0x85, 0x95, 0x6f, 0x36, 0x2d, 0x72, 0xd7, 0x63, 0x31, 0x70};
-        static const uint8_t bl[32] = {0x16, 0xa2, 0xa1, 0x9e, 0xdf, 0xe8, 0x1f, 0x20, 0xd0, 0x9b, 0x68, 0x19, 0x22, 0xc8, 0x13, 0xb4,
-                                       0xb6, 0x36, 0x83, 0x50, 0x8c, 0x22, 0x80, 0xb9, 0x38, 0x29, 0x97, 0x1f, 0x43, 0x9f, 0x0d, 0x2b};
-        return fr_from_be(CURVE_ID == 0 ? bn : bl);
+        // primitive 2^ADICITY-th root of unity (generated constant, tools/gen_params.py)
+        Fr a;
+        for (int i = 0; i < Fr::N; i++) a.l[i] = FRP::root(i);
+        return Fr::to_mont(a);
     }
 
     // ---- trace polynomials, permutation polynomials, their coset evaluations and the VK commitments ----------

@@ -161,6 +161,12 @@ def NewWitness(assignment: Circuit, field_mod: int) -> Witness:
 def solve(ccs: ConstraintSystem, w: Witness) -> List[int]:
     """Full variable assignment (gnark's constraint solver, SURVEY.md §3.3 R1 `solveConstraints`)."""
     s = w.Vector() + [0] * (ccs.nb_variables - len(w.public) - len(w.secret))
+    if ccs.solver == "gates":
+        # every constraint defines its own output wire: c = ql*a + qr*b + qm*a*b + qk  (qo = -1)
+        r = ccs.field
+        for ql, qr, qm, qo, qk, xa, xb, xc in ccs.constraints:
+            s[xc] = (ql * s[xa] + qr * s[xb] + qm * s[xa] % r * s[xb] + qk) % r
+        return s
     for wire, fn in ccs.solver:
         s[wire] = fn(s)
     return s

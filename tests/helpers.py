@@ -41,6 +41,6 @@ def random_chain_ccs(cv, log_n: int, seed: int, nb_public: int = 2) -> Tuple[fro
         a, b = sol[xa], sol[xb]
         cons.append((ql, qr, qm, r - 1, qk, xa, xb, nv))
         sol.append((ql * a + qr * b + qm * a % r * b + qk) % r)
-    ccs = frontend.ConstraintSystem(r, ["p%d" % i for i in range(nb_public)], ["s0", "s1"], cons, [], len(sol))
+    ccs = frontend.ConstraintSystem(r, ["p%d" % i for i in range(nb_public)], ["s0", "s1"], cons, "gates", len(sol))
     w = frontend.Witness(r, sol[:nb_public], sol[nb_public:nb_public + 2])
     return ccs, w, sol
