@@ -129,7 +129,7 @@ class CurveBackend : public Backend {
         DevBuf pi2_lag[APK_MAX_COMMITMENTS], pi2_can[APK_MAX_COMMITMENTS], epi2[APK_MAX_COMMITMENTS];
         DevBuf scratch_in;  // upload staging for primitives
         // MSM workspace
-        DevBuf hist, offsets, cursor, unit_off, sorted, partial, bucket_sum, bit_partial, result, result_xyzz;
+        DevBuf counts, hist, offsets, cursor, unit_off, sorted, partial, bucket_sum, bit_partial, result, result_xyzz;
         void* h_pinned = nullptr;  // small pinned staging for results
     };
 
@@ -139,6 +139,8 @@ class CurveBackend : public Backend {
     uint32_t nb_public_ = 0, nb_commit_ = 0;
     uint32_t cci_[APK_MAX_COMMITMENTS] = {0, 0};
     int c_ = 0, W_ = 0;
+    MsmWindows win_{};
+    uint32_t msm_G_max_ = 256;
     uint32_t NB_ = 0;
     Fr omega_, omega_inv_, omega4_, omega4_inv_, shift_, shift_inv_, n_inv_, n4_inv_;
     Fr zh_inv_[4];
@@ -178,8 +180,12 @@ class CurveBackend : public Backend {
                 const Fr* pre, const Fr* post, const Fr* scale) {
         const int log_n = which ? (int)log_n_ + 2 : (int)log_n_;
         const Fr* tw = which ? (inverse ? ptr<Fr>(twi_4n_) : ptr<Fr>(tw_4n_)) : (inverse ? ptr<Fr>(twi_n_) : ptr<Fr>(tw_n_));
-        const int tile_log = log_n < NTT_TILE_LOG ? log_n : NTT_TILE_LOG;
-        const int max_s = tile_log < NTT_PASS_BITS ? tile_log : NTT_PASS_BITS;
+        // small transforms are latency-bound: 512-element tiles (16 KiB LDS) give >= 256 workgroups at 2^17;
+        // large ones are bandwidth-bound: 2048-element tiles and fewer passes
+        int tile_log = log_n <= 19 ? 9 : NTT_TILE_LOG;
+        int max_s = log_n <= 19 ? 7 : 9;
+        if (tile_log > log_n) tile_log = log_n;
+        if (max_s > tile_log) max_s = tile_log;
         const int passes = (log_n + max_s - 1) / max_s;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         Slot* owner = nullptr;
@@ -191,7 +197,7 @@ class CurveBackend : public Backend {
         for (int p = 0; p < passes; p++) {
             int s = (log_n - t0 + (passes - p) - 1) / (passes - p);
             NttPassArgs a;
-            a.log_n = log_n; a.t0 = t0; a.t1 = t0 + s;
+            a.log_n = log_n; a.tile_log = tile_log; a.t0 = t0; a.t1 = t0 + s;
             a.first = (p == 0); a.last = (p == passes - 1);
             a.in_len = in_len; a.out_len = out_len;
             const uint32_t grid = 1u << (log_n - tile_log);
@@ -221,7 +227,7 @@ class CurveBackend : public Backend {
     int build_tables(hipStream_t st, const Aff* d_bases, uint32_t count, MsmTables& T) {
         CHK(T.table.alloc((size_t)count * W_ * sizeof(Aff)));
         T.n_bases = count;
-        msm_table_kernel<FPP><<<cdiv(count, 256), 256, 0, st>>>(d_bases, count, c_, W_, ptr<Aff>(T.table));
+        msm_table_kernel<FPP><<<cdiv(count, 256), 256, 0, st>>>(d_bases, count, win_, ptr<Aff>(T.table));
         KCHK();
         T.built = true;
         return APK_OK;
@@ -240,19 +246,22 @@ class CurveBackend : public Backend {
         const uint32_t total_buckets = a.batch * NB_;
         const uint32_t max_units = (uint32_t)(entries / MSM_UNIT) + total_buckets;
         if (stats_on_) HIPCHK(hipEventRecord(s.ev0, st));
-        HIPCHK(hipMemsetAsync(s.hist.p, 0, (size_t)total_buckets * 4, st));
-        dim3 gd(cdiv(maxlen, 256), a.batch);
-        if (maxlen) {
-            msm_digits_kernel<FRP, false><<<gd, 256, 0, st>>>(a, c_, W_, NB_, T.n_bases, ptr<uint32_t>(s.hist), nullptr);
-            KCHK();
-        }
-        msm_scan_kernel<MSM_UNIT><<<1, 1024, 0, st>>>(ptr<uint32_t>(s.hist), total_buckets, ptr<uint32_t>(s.offsets), ptr<uint32_t>(s.cursor),
-                                            ptr<uint32_t>(s.unit_off));
+        // counting sort by bucket: LDS-private histograms per scalar slice, column scan, bucket scan, scatter
+        uint32_t G = cdiv(maxlen, 2048);
+        if (G < 1) G = 1;
+        if (G > msm_G_max_) G = msm_G_max_;
+        dim3 gd(G, a.batch);
+        const size_t lds = (size_t)NB_ * 4;
+        msm_digits_kernel<FRP, false><<<gd, 256, lds, st>>>(a, win_, NB_, T.n_bases, G, ptr<uint32_t>(s.counts), nullptr, nullptr);
         KCHK();
-        if (maxlen) {
-            msm_digits_kernel<FRP, true><<<gd, 256, 0, st>>>(a, c_, W_, NB_, T.n_bases, ptr<uint32_t>(s.cursor), ptr<uint32_t>(s.sorted));
-            KCHK();
-        }
+        msm_colscan_kernel<0><<<cdiv(total_buckets, 256), 256, 0, st>>>(ptr<uint32_t>(s.counts), NB_, G, total_buckets, ptr<uint32_t>(s.hist));
+        KCHK();
+        msm_scan_kernel<MSM_UNIT><<<1, 1024, 0, st>>>(ptr<uint32_t>(s.hist), total_buckets, ptr<uint32_t>(s.offsets), ptr<uint32_t>(s.cursor),
+                                                       ptr<uint32_t>(s.unit_off));
+        KCHK();
+        msm_digits_kernel<FRP, true><<<gd, 256, lds, st>>>(a, win_, NB_, T.n_bases, G, ptr<uint32_t>(s.counts), ptr<uint32_t>(s.offsets),
+                                                            ptr<uint32_t>(s.sorted));
+        KCHK();
         if (stats_on_) HIPCHK(hipEventRecord(s.ev2, st));
         msm_accumulate_kernel<FPP><<<cdiv(max_units, 128), 128, 0, st>>>(ptr<Aff>(T.table), ptr<uint32_t>(s.sorted), ptr<uint32_t>(s.offsets),
                                                                         ptr<uint32_t>(s.unit_off), total_buckets, max_units, ptr<Pt>(s.partial));
@@ -312,6 +321,7 @@ class CurveBackend : public Backend {
         const uint32_t tb = MSM_MAX_BATCH * NB_;
         CHK(s.hist.alloc((size_t)(tb + 1) * 4)); CHK(s.offsets.alloc((size_t)(tb + 1) * 4)); CHK(s.cursor.alloc((size_t)(tb + 1) * 4));
         CHK(s.unit_off.alloc((size_t)(tb + 1) * 4));
+        CHK(s.counts.alloc((size_t)tb * msm_G_max_ * 4));
         CHK(s.sorted.alloc(entries * 4));
         CHK(s.partial.alloc((entries / MSM_UNIT + tb) * sizeof(Pt)));
         CHK(s.bucket_sum.alloc((size_t)tb * sizeof(Pt)));
@@ -375,6 +385,18 @@ class CurveBackend : public Backend {
         if (c_ < 2 || c_ > 16) { set_error("msm_window %d out of [2,16]", c_); return APK_ERR_ARG; }
         W_ = (FRP::BITS + 1 + c_ - 1) / c_;
         NB_ = 1u << (c_ - 1);
+        {   // spread the BITS+1 bits over W_ windows of width c_ or c_-1
+            const int bits = FRP::BITS + 1;
+            const int base = bits / W_, extra = bits % W_;
+            win_.W = W_;
+            int o = 0;
+            for (int j = 0; j < W_; j++) {
+                win_.off[j] = (uint16_t)o;
+                win_.width[j] = (uint8_t)(base + (j < extra ? 1 : 0));
+                o += win_.width[j];
+            }
+            win_.off[W_] = (uint16_t)o;
+        }
         if ((uint64_t)(n_ + 3) * W_ >= (1ull << 31)) { set_error("n*windows exceeds 2^31 table entries"); return APK_ERR_ARG; }
 
         // domain constants on the host (gnark fft.NewDomain [UPSTREAM]; generator = VK Generator,
@@ -428,6 +450,10 @@ class CurveBackend : public Backend {
         }
         HIPCHK(hipDeviceSynchronize());
         srs.release();
+        if ((size_t)NB_ * 4 > 65536) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, NB_ * 4));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NB_ * 4));
+        }
         // proving slots
         int nslots = d->slots > 0 ? d->slots : 1;
         if (nslots > 16) nslots = 16;

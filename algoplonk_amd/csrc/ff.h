@@ -179,13 +179,95 @@ struct Fe {
         uint32_t w[2] = {(uint32_t)e, (uint32_t)(e >> 32)};
         return pow(a, w, 2);
     }
-    // Fermat inversion a^(p-2); inv(0) = 0
-    APK_HD static Fe inv(const Fe& a) {
+    // Fermat inversion a^(p-2); inv(0) = 0.  ~1.5*BITS multiplications: kept as the cross-check for inv().
+    APK_HD static Fe inv_fermat(const Fe& a) {
         uint32_t e[N];
 #pragma unroll
         for (int i = 0; i < N; i++) e[i] = P::pm2(i);
         if (a.is_zero()) return a;
         return pow(a, e, N);
+    }
+
+    // ---- Montgomery inverse (Kaliski 1995): binary extended Euclid on plain limbs, then <= 3 Montgomery
+    // products to fix the power of two.  ~2*BITS shift/subtract steps on N limbs, i.e. roughly a tenth of
+    // the dependent-instruction chain of Fermat's a^(p-2); that chain, not throughput, is what a lone lane
+    // (final affine conversion, batch-inversion seeds) pays for.  inv(0) = 0.
+    APK_HD static bool ge_raw(const uint32_t* x, const uint32_t* y) {
+        for (int i = N - 1; i >= 0; i--) {
+            if (x[i] != y[i]) return x[i] > y[i];
+        }
+        return true;
+    }
+    APK_HD static void sub_raw(uint32_t* x, const uint32_t* y) {  // x -= y
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            uint64_t t = (uint64_t)x[i] - y[i] - borrow;
+            x[i] = (uint32_t)t;
+            borrow = (uint32_t)(t >> 63);
+        }
+    }
+    APK_HD static void add_raw(uint32_t* x, const uint32_t* y) {  // x += y (no overflow: values < 2p < R)
+        uint32_t carry = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            uint64_t t = (uint64_t)x[i] + y[i] + carry;
+            x[i] = (uint32_t)t;
+            carry = (uint32_t)(t >> 32);
+        }
+    }
+    APK_HD static void shr1_raw(uint32_t* x) {
+#pragma unroll
+        for (int i = 0; i < N - 1; i++) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
+        x[N - 1] >>= 1;
+    }
+    APK_HD static void shl1_raw(uint32_t* x) {
+#pragma unroll
+        for (int i = N - 1; i > 0; i--) x[i] = (x[i] << 1) | (x[i - 1] >> 31);
+        x[0] <<= 1;
+    }
+    APK_HD static Fe inv(const Fe& a) {
+        if (a.is_zero()) return a;
+        uint32_t u[N], v[N], r[N], s[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) { u[i] = P::mod(i); v[i] = a.l[i]; r[i] = 0; s[i] = 0; }
+        s[0] = 1;
+        int k = 0;
+        for (;;) {
+            uint32_t vz = 0;
+#pragma unroll
+            for (int i = 0; i < N; i++) vz |= v[i];
+            if (vz == 0) break;
+            if ((u[0] & 1u) == 0) { shr1_raw(u); shl1_raw(s); }
+            else if ((v[0] & 1u) == 0) { shr1_raw(v); shl1_raw(r); }
+            else if (!ge_raw(v, u)) { sub_raw(u, v); shr1_raw(u); add_raw(r, s); shl1_raw(s); }   // u > v
+            else { sub_raw(v, u); shr1_raw(v); add_raw(s, r); shl1_raw(r); }
+            k++;
+        }
+        // r = a^-1 * 2^k (mod p) up to sign: result = p - r (after one conditional subtraction)
+        Fe x;
+        {
+            uint32_t m[N];
+#pragma unroll
+            for (int i = 0; i < N; i++) m[i] = P::mod(i);
+            if (ge_raw(r, m)) sub_raw(r, m);
+            sub_raw(m, r);
+#pragma unroll
+            for (int i = 0; i < N; i++) x.l[i] = m[i];
+        }
+        // x = abar^-1 * 2^k with BITS <= k <= 2*BITS.  Bring it to abar^-1 * R (plain inverse of the plain
+        // value when the input is in Montgomery form), then one more product by R^2 re-enters Montgomery form.
+        constexpr int M = 32 * N;
+        Fe r2;
+#pragma unroll
+        for (int i = 0; i < N; i++) r2.l[i] = P::r2(i);
+        if (k <= M) { x = mul(x, r2); k += M; }      // x = abar^-1 * 2^k, now M < k <= 2M
+        Fe pw;
+        const int e = 2 * M - k;                      // 0 <= e < M
+#pragma unroll
+        for (int i = 0; i < N; i++) pw.l[i] = (i == (e >> 5)) ? (1u << (e & 31)) : 0u;
+        x = mul(x, pw);                               // abar^-1 * 2^(2M) * R^-1 = abar^-1 * R
+        return mul(x, r2);                            // (a R)^-1 * R * R = a^-1 * R
     }
 };
 

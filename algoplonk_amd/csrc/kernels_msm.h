@@ -27,6 +27,16 @@ constexpr int MSM_COMBINE_LANES = 16;
 constexpr int MSM_RED_THREADS = 256;
 constexpr int MSM_RED_MAXCHUNK = 8;
 
+// Signed-digit windows.  Widths differ by at most one bit (c or c-1) so the BITS+1 scalar bits are spread evenly:
+// with equal widths the top window can be left with 1-3 significant bits, and every scalar then lands in the same
+// two or three buckets (measured: 9x slower bucket merge at c = 12 for uniform scalars).
+constexpr int MSM_MAX_WINDOWS = 40;
+struct MsmWindows {
+    int W;
+    uint16_t off[MSM_MAX_WINDOWS + 1];  // first bit of window j; off[W] = BITS + 1
+    uint8_t width[MSM_MAX_WINDOWS];
+};
+
 struct MsmBatchArgs {
     const void* scalars[MSM_MAX_BATCH];  // device, Fr Montgomery, len[b] elements
     uint32_t len[MSM_MAX_BATCH];
@@ -38,39 +48,78 @@ struct MsmBatchArgs {
 // canonical scalar limbs -> W digits d_j in [-2^(c-1), 2^(c-1)), s = sum d_j 2^(c j)
 template <int N>
 __device__ __forceinline__ uint32_t window_bits(const uint32_t (&s)[N], int bit, int c) {
-    int w = bit >> 5, o = bit & 31;
-    uint64_t v = s[w];
-    if (w + 1 < N) v |= (uint64_t)s[w + 1] << 32;
+    const int w = bit >> 5, o = bit & 31;
+    uint32_t lo = 0, hi = 0;  // select limbs w, w+1 with compares so the limbs stay in registers
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        lo = (i == w) ? s[i] : lo;
+        hi = (i == w + 1) ? s[i] : hi;
+    }
+    uint64_t v = ((uint64_t)hi << 32) | lo;
     return (uint32_t)(v >> o) & ((1u << c) - 1u);
 }
 
+// Counting sort of the (digit, point) pairs by bucket WITHOUT global atomics (device-scope atomics leave the XCD's
+// L2 and were 25 % of an MSM): a workgroup owns a contiguous slice of the scalars and a private LDS histogram.
+//   SCATTER = false : counts[(b*G + g)*nb + k] = entries of slice g of msm b that fall into bucket k
+//   SCATTER = true  : LDS cursors start at offsets[b*nb+k] + (exclusive prefix of counts over g); every entry takes
+//                     the next slot of its bucket with an LDS atomic and is written to `sorted`
 template <class FR, bool SCATTER>
-__global__ void __launch_bounds__(256) msm_digits_kernel(MsmBatchArgs a, int c, int W, uint32_t nb, uint32_t n_max,
-                                                         uint32_t* __restrict__ counters,  // hist or cursor
+__global__ void __launch_bounds__(256) msm_digits_kernel(MsmBatchArgs a, MsmWindows win, uint32_t nb, uint32_t n_max, uint32_t G,
+                                                         uint32_t* __restrict__ counts,         // [batch][G][nb]
+                                                         const uint32_t* __restrict__ offsets,  // SCATTER only
                                                          uint32_t* __restrict__ sorted) {
     using Fr = Fe<FR>;
-    const uint32_t b = blockIdx.y;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.len[b]) return;
-    Fr s = Fr::from_mont(reinterpret_cast<const Fr*>(a.scalars[b])[i]);
-    const uint32_t half = 1u << (c - 1);
-    uint32_t carry = 0;
-    const uint32_t base_idx = a.offset[b] + i;
-    for (int j = 0; j < W; j++) {
-        int bit = j * c;
-        uint32_t d = (bit < 32 * Fr::N ? window_bits<Fr::N>(s.l, bit, c) : 0u) + carry;
-        uint32_t neg = 0;
-        if (d > half) { d = (1u << c) - d; neg = 1; carry = 1; }  // d in (half, 2^c] -> -(2^c - d)
-        else carry = 0;
-        if (d == 0) continue;  // also the d == 2^c case (digit 0, carry 1)
-        uint32_t bucket = b * nb + (d - 1);
-        if (!SCATTER) {
-            atomicAdd(&counters[bucket], 1u);
-        } else {
-            uint32_t pos = atomicAdd(&counters[bucket], 1u);
-            sorted[pos] = ((uint32_t)j * n_max + base_idx) | (neg << 31);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t* lds = reinterpret_cast<uint32_t*>(smem_raw);
+    const uint32_t g = blockIdx.x, b = blockIdx.y;
+    uint32_t* row = counts + ((size_t)b * G + g) * nb;
+    for (uint32_t k = threadIdx.x; k < nb; k += blockDim.x) lds[k] = SCATTER ? offsets[b * nb + k] + row[k] : 0u;
+    __syncthreads();
+    const uint32_t len = a.len[b];
+    const uint32_t per = (len + G - 1) / G;
+    const uint32_t lo = min(g * per, len), hi = min(lo + per, len);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        Fr s = Fr::from_mont(reinterpret_cast<const Fr*>(a.scalars[b])[i]);
+        uint32_t carry = 0;
+        const uint32_t base_idx = a.offset[b] + i;
+        for (int j = 0; j < win.W; j++) {
+            const int bit = win.off[j], c = win.width[j];
+            const uint32_t half = 1u << (c - 1);
+            uint32_t d = (bit < 32 * Fr::N ? window_bits<Fr::N>(s.l, bit, c) : 0u) + carry;
+            uint32_t neg = 0;
+            if (d > half) { d = (1u << c) - d; neg = 1; carry = 1; }  // d in (half, 2^c] -> -(2^c - d)
+            else carry = 0;
+            if (d == 0) continue;  // also the d == 2^c case (digit 0, carry 1)
+            if (!SCATTER) {
+                atomicAdd(&lds[d - 1], 1u);
+            } else {
+                uint32_t pos = atomicAdd(&lds[d - 1], 1u);
+                sorted[pos] = ((uint32_t)j * n_max + base_idx) | (neg << 31);
+            }
         }
     }
+    if (!SCATTER) {
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < nb; k += blockDim.x) row[k] = lds[k];
+    }
+}
+
+// per bucket: exclusive prefix of the slice counts over g (in place) and the bucket total
+template <int DUMMY>
+__global__ void __launch_bounds__(256) msm_colscan_kernel(uint32_t* __restrict__ counts, uint32_t nb, uint32_t G, uint32_t total_buckets,
+                                                          uint32_t* __restrict__ hist) {
+    const uint32_t kk = blockIdx.x * blockDim.x + threadIdx.x;  // b*nb + k
+    if (kk >= total_buckets) return;
+    const uint32_t b = kk / nb, k = kk % nb;
+    uint32_t run = 0;
+    for (uint32_t g = 0; g < G; g++) {
+        uint32_t* p = counts + ((size_t)b * G + g) * nb + k;
+        uint32_t v = *p;
+        *p = run;
+        run += v;
+    }
+    hist[kk] = run;
 }
 
 // ---- single-block exclusive scans: bucket offsets and work-unit offsets --------------------------------
@@ -241,17 +290,17 @@ __global__ void __launch_bounds__(256) msm_final_kernel(const XYZZ<FP>* __restri
     }
 }
 
-// ---- table construction: table[j*n + i] = 2^(c j) * P_i (affine) ----------------------------------------
+// ---- table construction: table[j*n + i] = 2^(off[j]) * P_i (affine) ----------------------------------------
 template <class FP>
-__global__ void __launch_bounds__(256) msm_table_kernel(const Affine<FP>* __restrict__ bases, uint32_t n, int c, int W,
+__global__ void __launch_bounds__(256) msm_table_kernel(const Affine<FP>* __restrict__ bases, uint32_t n, MsmWindows win,
                                                         Affine<FP>* __restrict__ table) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Affine<FP> p = bases[i];
     table[i] = p;
-    for (int j = 1; j < W; j++) {
+    for (int j = 1; j < win.W; j++) {
         XYZZ<FP> q = XYZZ<FP>::dbl_affine(p);
-        for (int k = 1; k < c; k++) q = XYZZ<FP>::dbl(q);
+        for (int k = 1; k < win.width[j - 1]; k++) q = XYZZ<FP>::dbl(q);
         p = q.to_affine();
         table[(size_t)j * n + i] = p;
     }

@@ -16,7 +16,7 @@
 
 namespace apk {
 
-constexpr int NTT_TILE_LOG = 11;  // 2048 elements * 32 B = 64 KiB LDS
+constexpr int NTT_TILE_LOG = 11;  // largest tile: 2048 elements * 32 B = 64 KiB LDS (used for log_n > 19)
 constexpr int NTT_PASS_BITS = 10; // max stages per pass (C = 2^(11-s) adjacent groups -> C*32-B contiguous runs)
 constexpr int NTT_THREADS = 256;
 
@@ -24,6 +24,7 @@ __device__ __forceinline__ uint32_t bitrev32(uint32_t x, int bits) { return __br
 
 struct NttPassArgs {
     int log_n;
+    int tile_log;        // log2(elements per workgroup tile)
     int t0, t1;          // stages [t0, t1)
     uint32_t in_len;     // elements >= in_len read as zero (first pass only)
     int first, last;     // first pass gathers bit-reversed + pre-multiplies; last pass post-multiplies
@@ -42,7 +43,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fe<FR>* __r
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Fr* sm = reinterpret_cast<Fr*>(smem_raw);
     const int s = a.t1 - a.t0;
-    const int tile_log = min(NTT_TILE_LOG, a.log_n);
+    const int tile_log = a.tile_log;
     const int clog = tile_log - s;  // log2(groups per tile)
     const uint32_t C = 1u << clog;
     const uint32_t tile_elems = 1u << tile_log;

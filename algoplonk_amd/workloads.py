@@ -1,0 +1,80 @@
+"""Synthetic workloads of BASELINE.md §2 (seeded, no network, no ceremony files): the circuits and witnesses that
+bench.py and the full-size tests prove.  Host-side only - produces the arrays gnark's frontend + solver would hand
+to the prover (trace columns, permutation, solved L/R/O, public inputs, blinding scalars).
+"""
+from __future__ import annotations
+
+import hashlib
+from dataclasses import dataclass
+from typing import List, Tuple
+
+from . import ecc, frontend
+
+MASK64 = (1 << 64) - 1
+
+
+class SplitMix64:
+    """Same generator as the oracle's ("SplitMix64 -> Fr by rejection")."""
+
+    def __init__(self, seed: int):
+        self.s = seed & MASK64
+
+    def next(self) -> int:
+        self.s = (self.s + 0x9E3779B97F4A7C15) & MASK64
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+        return z ^ (z >> 31)
+
+    def fr(self, r: int) -> int:
+        bits = r.bit_length()
+        while True:
+            v = 0
+            for i in range(4):
+                v |= self.next() << (64 * i)
+            v &= (1 << bits) - 1
+            if v < r:
+                return v
+
+    def below(self, n: int) -> int:
+        lim = (1 << 64) - ((1 << 64) % n)
+        while True:
+            v = self.next()
+            if v < lim:
+                return v % n
+
+
+def tau_from_seed(seed: int, r: int) -> int:
+    return int.from_bytes(hashlib.sha256(seed.to_bytes(8, "big")).digest(), "big") % r
+
+
+@dataclass
+class Workload:
+    name: str
+    curve: ecc.ID
+    ccs: frontend.ConstraintSystem
+    witness: frontend.Witness
+    solution: List[int]
+    blinding: List[int]
+    tau: int
+
+
+def random_circuit(curve: ecc.ID, log_n: int, seed: int, nb_public: int = 2) -> Workload:
+    """BASELINE.json configs[1]/[2]: n - nb_public random gates c = ql*a + qr*b + qm*a*b + qk over earlier wires."""
+    r = curve.r
+    n = 1 << log_n
+    g = SplitMix64(seed)
+    sol = [g.fr(r) for _ in range(nb_public + 2)]
+    cons = []
+    for _ in range(n - nb_public):
+        nv = len(sol)
+        xa, xb = g.below(nv), g.below(nv)
+        ql, qr, qm, qk = g.fr(r), g.fr(r), g.fr(r), g.fr(r)
+        a, b = sol[xa], sol[xb]
+        cons.append((ql, qr, qm, r - 1, qk, xa, xb, nv))
+        sol.append((ql * a + qr * b + qm * a % r * b + qk) % r)
+    ccs = frontend.ConstraintSystem(r, ["p%d" % i for i in range(nb_public)], ["s0", "s1"], cons, "gates", len(sol))
+    w = frontend.Witness(r, sol[:nb_public], sol[nb_public:nb_public + 2])
+    gb = SplitMix64(seed ^ 0xB11D)
+    return Workload("%s random circuit, 2^%d constraints" % (curve.name, log_n), curve, ccs, w, sol,
+                    [gb.fr(r) for _ in range(9)], tau_from_seed(seed, r))
