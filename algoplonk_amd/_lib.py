@@ -22,7 +22,7 @@ NB_BLINDING = 9
 # every symbol include/apk.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
     "apk_last_error", "apk_abi_version", "apk_device_count", "apk_g1_bytes", "apk_fp_bytes",
-    "apk_ctx_create", "apk_ctx_destroy", "apk_ctx_get_vk", "apk_msm_g1", "apk_msm_g1_device", "apk_ntt",
+    "apk_ctx_create", "apk_ctx_destroy", "apk_msm_ctx_create", "apk_ctx_get_vk", "apk_msm_g1", "apk_msm_g1_device", "apk_ntt",
     "apk_prove", "apk_prove_device", "apk_g1_mul_batch", "apk_marshal_proof", "apk_marshal_public_inputs",
     "apk_fe_from_be", "apk_fe_to_be", "apk_hash_fr", "apk_host_fe_op", "apk_host_g1_op",
     "apk_device_alloc", "apk_device_free", "apk_device_upload", "apk_device_download",
@@ -88,6 +88,7 @@ def _load() -> C.CDLL:
     lib.apk_fp_bytes.argtypes = [i32]; lib.apk_fp_bytes.restype = sz
     lib.apk_ctx_create.argtypes = [C.POINTER(CircuitDesc), C.POINTER(vp)]
     lib.apk_ctx_destroy.argtypes = [vp]; lib.apk_ctx_destroy.restype = None
+    lib.apk_msm_ctx_create.argtypes = [i32, i32, vp, u64, i32, C.POINTER(vp)]
     lib.apk_ctx_get_vk.argtypes = [vp, C.POINTER(Vk)]
     lib.apk_msm_g1.argtypes = [vp, i32, vp, u64, vp]
     lib.apk_msm_g1_device.argtypes = [vp, i32, vp, u64, vp]

@@ -183,6 +183,19 @@ int apk_ctx_create(const apk_circuit_desc* d, apk_ctx** out) {
     return APK_OK;
 }
 
+int apk_msm_ctx_create(int curve, int device, const void* bases, uint64_t count, int msm_window, apk_ctx** out) {
+    if (!bases || !out) { set_error("null argument"); return APK_ERR_ARG; }
+    *out = nullptr;
+    Backend* be = nullptr;
+    if (curve == APK_BN254) be = make_backend_bn254();
+    else if (curve == APK_BLS12_381) be = make_backend_bls12381();
+    else { set_error("unsupported curve: %d", curve); return APK_ERR_ARG; }
+    int r = be->init_msm_only(device, bases, count, msm_window);
+    if (r != APK_OK) { delete be; return r; }
+    *out = new apk_ctx{be, curve};
+    return APK_OK;
+}
+
 void apk_ctx_destroy(apk_ctx* ctx) {
     if (!ctx) return;
     delete ctx->be;

@@ -14,6 +14,7 @@ void set_error(const char* fmt, ...);
 struct Backend {
     virtual ~Backend() {}
     virtual int init(const apk_circuit_desc* d) = 0;
+    virtual int init_msm_only(int device, const void* bases, uint64_t count, int msm_window) = 0;
     virtual int get_vk(apk_vk* out) = 0;
     virtual int msm(int basis, const void* scalars, uint64_t len, bool on_device, void* out) = 0;
     virtual int ntt(int which, int inverse, int coset, void* data) = 0;

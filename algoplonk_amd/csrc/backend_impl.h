@@ -141,6 +141,8 @@ class CurveBackend : public Backend {
     int c_ = 0, W_ = 0;
     MsmWindows win_{};
     uint32_t msm_G_max_ = 256;
+    bool msm_only_ = false;
+    uint32_t msm_bases_ = 0;  // bases the MSM workspaces are sized for
     uint32_t NB_ = 0;
     Fr omega_, omega_inv_, omega4_, omega4_inv_, shift_, shift_inv_, n_inv_, n4_inv_;
     Fr zh_inv_[4];
@@ -303,6 +305,10 @@ class CurveBackend : public Backend {
         HIPCHK(hipEventCreate(&s.ev3));
         HIPCHK(hipHostMalloc(&s.h_pinned, 4096, hipHostMallocDefault));
         const size_t fn = (size_t)n_ * sizeof(Fr), fn3 = (size_t)(n_ + 4) * sizeof(Fr), f4 = (size_t)n4_ * sizeof(Fr);
+        if (msm_only_) {
+            CHK(s.scratch_in.alloc((size_t)msm_bases_ * sizeof(Fr)));
+            return alloc_msm_workspace(s, 1);
+        }
         CHK(s.wl.alloc(fn)); CHK(s.wr.alloc(fn)); CHK(s.wo.alloc(fn));
         CHK(s.cl.alloc(fn3)); CHK(s.cr.alloc(fn3)); CHK(s.co.alloc(fn3)); CHK(s.cz.alloc(fn3));
         CHK(s.qk_lag.alloc(fn)); CHK(s.qk_can.alloc(fn));
@@ -316,9 +322,13 @@ class CurveBackend : public Backend {
         CHK(s.eval_result.alloc(EVAL_MAX * sizeof(Fr)));
         for (uint32_t k = 0; k < nb_commit_; k++) { CHK(s.pi2_lag[k].alloc(fn)); CHK(s.pi2_can[k].alloc(fn)); CHK(s.epi2[k].alloc(f4)); }
         CHK(s.scratch_in.alloc(f4));
-        // MSM workspace sized for a full batch over n+3 bases
-        const uint64_t entries = (uint64_t)MSM_MAX_BATCH * (n_ + 3) * W_;
-        const uint32_t tb = MSM_MAX_BATCH * NB_;
+        return alloc_msm_workspace(s, MSM_MAX_BATCH);
+    }
+
+    // MSM workspace sized for `batch` MSMs over all bases
+    int alloc_msm_workspace(Slot& s, uint32_t batch) {
+        const uint64_t entries = (uint64_t)batch * msm_bases_ * W_;
+        const uint32_t tb = batch * NB_;
         CHK(s.hist.alloc((size_t)(tb + 1) * 4)); CHK(s.offsets.alloc((size_t)(tb + 1) * 4)); CHK(s.cursor.alloc((size_t)(tb + 1) * 4));
         CHK(s.unit_off.alloc((size_t)(tb + 1) * 4));
         CHK(s.counts.alloc((size_t)tb * msm_G_max_ * 4));
@@ -326,7 +336,7 @@ class CurveBackend : public Backend {
         CHK(s.partial.alloc((entries / MSM_UNIT + tb) * sizeof(Pt)));
         CHK(s.bucket_sum.alloc((size_t)tb * sizeof(Pt)));
         const uint32_t nchunk = NB_ > 2048 ? NB_ / 2048 : 1;
-        CHK(s.bit_partial.alloc((size_t)MSM_MAX_BATCH * c_ * nchunk * sizeof(Pt)));
+        CHK(s.bit_partial.alloc((size_t)batch * c_ * nchunk * sizeof(Pt)));
         CHK(s.result.alloc(MSM_MAX_BATCH * sizeof(Aff)));
         CHK(s.result_xyzz.alloc(MSM_MAX_BATCH * sizeof(Pt)));
         return APK_OK;
@@ -356,7 +366,63 @@ class CurveBackend : public Backend {
         return APK_OK;
     }
 
+    int choose_window(int requested, int log_size) {
+        c_ = requested;
+        if (c_ == 0) {
+            const char* env = getenv("APK_MSM_WINDOW");
+            if (env) c_ = atoi(env);
+        }
+        if (c_ == 0) { c_ = log_size - 4; if (c_ < 8) c_ = 8; if (c_ > 16) c_ = 16; }
+        if (c_ < 7 || c_ > 16) { set_error("msm_window %d out of [7,16]", c_); return APK_ERR_ARG; }
+        W_ = (FRP::BITS + 1 + c_ - 1) / c_;
+        NB_ = 1u << (c_ - 1);
+        {   // spread the BITS+1 bits over W_ windows of width c_ or c_-1
+            const int bits = FRP::BITS + 1;
+            const int base = bits / W_, extra = bits % W_;
+            win_.W = W_;
+            int o = 0;
+            for (int j = 0; j < W_; j++) {
+                win_.off[j] = (uint16_t)o;
+                win_.width[j] = (uint8_t)(base + (j < extra ? 1 : 0));
+                o += win_.width[j];
+            }
+            win_.off[W_] = (uint16_t)o;
+        }
+        if ((uint64_t)msm_bases_ * W_ >= (1ull << 31)) { set_error("bases*windows exceeds 2^31 table entries"); return APK_ERR_ARG; }
+        return APK_OK;
+    }
+
     // ---------------------------------------------------------------------------------------------- init
+    // MSM-only context: SRS tables + one MSM workspace per slot, no circuit (single sharded MSM, BASELINE config 4)
+    int init_msm_only(int device, const void* bases, uint64_t count, int msm_window) override {
+        if (!bases || count == 0 || count >= (1ull << 27)) { set_error("msm context: bad base count"); return APK_ERR_ARG; }
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev == 0) { set_error("no HIP device available (%s); libapk has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e)); return APK_ERR_HIP; }
+        if (device < 0 || device >= ndev) { set_error("device %d out of range (%d devices)", device, ndev); return APK_ERR_ARG; }
+        device_ = device;
+        HIPCHK(hipSetDevice(device_));
+        msm_only_ = true;
+        msm_bases_ = (uint32_t)count;
+        n_ = (uint32_t)count;
+        int lg = 0;
+        while ((1ull << lg) < count) lg++;
+        CHK(choose_window(msm_window, lg));
+        if ((size_t)NB_ * 4 > 65536) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, NB_ * 4));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NB_ * 4));
+        }
+        DevBuf srs;
+        CHK(srs.alloc(count * sizeof(Aff)));
+        HIPCHK(hipMemcpy(srs.p, bases, count * sizeof(Aff), hipMemcpyHostToDevice));
+        CHK(build_tables(nullptr, ptr<Aff>(srs), (uint32_t)count, tab_can_));
+        HIPCHK(hipDeviceSynchronize());
+        Slot* s = new Slot();
+        slots_.push_back(s);
+        CHK(alloc_slot(*s));
+        return APK_OK;
+    }
+
     int init(const apk_circuit_desc* d) override {
         if (d->n < 8 || (d->n & (d->n - 1)) || d->n > (1ull << 24)) { set_error("n=%llu must be a power of two in [8, 2^24]", (unsigned long long)d->n); return APK_ERR_ARG; }
         if (d->nb_commitments > APK_MAX_COMMITMENTS) { set_error("at most %d BSB22 commitments", APK_MAX_COMMITMENTS); return APK_ERR_ARG; }
@@ -376,29 +442,8 @@ class CurveBackend : public Backend {
         nb_public_ = d->nb_public;
         nb_commit_ = d->nb_commitments;
         for (uint32_t k = 0; k < nb_commit_; k++) cci_[k] = d->commitment_constraint_index[k];
-        c_ = d->msm_window;
-        if (c_ == 0) {
-            const char* env = getenv("APK_MSM_WINDOW");
-            if (env) c_ = atoi(env);
-        }
-        if (c_ == 0) { c_ = (int)log_n_ - 4; if (c_ < 8) c_ = 8; if (c_ > 16) c_ = 16; }
-        if (c_ < 2 || c_ > 16) { set_error("msm_window %d out of [2,16]", c_); return APK_ERR_ARG; }
-        W_ = (FRP::BITS + 1 + c_ - 1) / c_;
-        NB_ = 1u << (c_ - 1);
-        {   // spread the BITS+1 bits over W_ windows of width c_ or c_-1
-            const int bits = FRP::BITS + 1;
-            const int base = bits / W_, extra = bits % W_;
-            win_.W = W_;
-            int o = 0;
-            for (int j = 0; j < W_; j++) {
-                win_.off[j] = (uint16_t)o;
-                win_.width[j] = (uint8_t)(base + (j < extra ? 1 : 0));
-                o += win_.width[j];
-            }
-            win_.off[W_] = (uint16_t)o;
-        }
-        if ((uint64_t)(n_ + 3) * W_ >= (1ull << 31)) { set_error("n*windows exceeds 2^31 table entries"); return APK_ERR_ARG; }
-
+        msm_bases_ = n_ + 3;
+        CHK(choose_window(d->msm_window, (int)log_n_));
         // domain constants on the host (gnark fft.NewDomain [UPSTREAM]; generator = VK Generator,
         // templateLogicSigBN254.go:57; shift = VK CosetShift :68)
         Fr root = root_of_unity();
@@ -477,6 +522,7 @@ class CurveBackend : public Backend {
     int setup_trace(const apk_circuit_desc* d);
 
     int get_vk(apk_vk* out) override {
+        if (msm_only_) { set_error("MSM-only context has no verifying key"); return APK_ERR_STATE; }
         memset(out, 0, sizeof *out);
         uint8_t* dst[8 + APK_MAX_COMMITMENTS] = {out->ql, out->qr, out->qm, out->qo, out->qk, out->s[0], out->s[1], out->s[2], out->qcp[0], out->qcp[1]};
         for (uint32_t i = 0; i < 8 + nb_commit_; i++) memcpy(dst[i], &vk_pts_[i], sizeof(Aff));
@@ -508,6 +554,7 @@ class CurveBackend : public Backend {
     }
 
     int ntt(int which, int inverse, int coset, void* data) override {
+        if (msm_only_) { set_error("MSM-only context has no NTT domain"); return APK_ERR_STATE; }
         HIPCHK(hipSetDevice(device_));
         SlotGuard g(this);
         Slot& s = *g.s;
@@ -696,6 +743,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::setup_trace(const apk_circuit_desc* d) {
 template <class FRP, class FPP, int CURVE_ID>
 int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const void* O, bool on_device, const void* pub,
                                             const void* blinding, const void* const* pi2, apk_proof* out) {
+    if (msm_only_) { set_error("MSM-only context cannot prove"); return APK_ERR_STATE; }
     HIPCHK(hipSetDevice(device_));
     auto t_start = std::chrono::steady_clock::now();
     if (!L || !R || !O || !blinding || !out || (nb_public_ && !pub) || (nb_commit_ && !pi2)) { set_error("null argument to apk_prove"); return APK_ERR_ARG; }

@@ -162,6 +162,13 @@ def main() -> None:
         except Exception as e:  # the baseline is reported, never required for the GPU number
             cpu_baseline = {"value": None, "unit": "proofs/sec", "cores": 0, "kind": "port", "sample": "unavailable: %s" % e}
 
+    gpu_proof_sha = None
+    if rank == 0:
+        import hashlib
+        from algoplonk_amd import MarshalProof
+        gpu_proof_sha = hashlib.sha256(MarshalProof(plonk.Proof(cv, proofs[0]))).hexdigest()[:16]
+        if cpu_baseline and cpu_baseline.get("proof_sha256_prefix"):
+            cpu_baseline["matches_gpu_proof"] = cpu_baseline["proof_sha256_prefix"] == gpu_proof_sha
     if rank == 0:
         line = {
             "metric": "proofs/sec", "value": round(value, 4), "unit": "proofs/sec", "n_gpus": world, "steps": args.steps,
@@ -174,7 +181,7 @@ def main() -> None:
             "msm_ms": round(msm_s * 1e3, 4), "setup_s": round(setup_s, 2),
             "msm_batch_avg_ms": round(st.msm_total_ms / max(st.msm_batches, 1), 4),
             "ntt_ms_per_proof": round(st.ntt_ms / max(st.proofs, 1), 4),
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "proof_sha256_prefix": gpu_proof_sha, "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

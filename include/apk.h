@@ -81,6 +81,12 @@ typedef struct {
 
 int apk_ctx_create(const apk_circuit_desc* desc, apk_ctx** out);
 void apk_ctx_destroy(apk_ctx* ctx);
+/* MSM-only context over an arbitrary base set (`count` G1 affine, host memory): windowed tables + one MSM
+ * workspace, no circuit.  Used to shard ONE large MSM by index range across GPUs (BASELINE.json configs[3]):
+ * each rank builds a context over its slice of the SRS, runs apk_msm_g1 on its slice of the scalars, and the
+ * partial sums (one point per rank) are all-gathered and added (algoplonk_amd/parallel.py).  apk_msm_g1* with
+ * basis 0 and the device-memory helpers work on it; apk_prove / apk_ntt / apk_ctx_get_vk return APK_ERR_STATE. */
+int apk_msm_ctx_create(int curve, int device, const void* bases, uint64_t count, int msm_window, apk_ctx** out);
 
 /* Verifying-key commitments produced during context creation (the 8+k MSMs of plonk.Setup).
  * Each slot is APK_G1_MAX_BYTES wide, gnark in-memory affine form. Order: Ql,Qr,Qm,Qo,Qk,S1,S2,S3,Qcp_0.. */

@@ -1,0 +1,45 @@
+"""ORACLE (test infrastructure): ctypes loader for oracle/liboracle.so (the plain-C restatement, apk_oracle.c).
+Same gnark in-memory layouts as include/apk.h, so tests feed identical buffers to both sides."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "liboracle.so")
+
+
+class Circuit(C.Structure):
+    _fields_ = [("curve", C.c_int), ("n", C.c_uint64), ("nb_public", C.c_uint32), ("srs", C.c_void_p),
+                ("ql", C.c_void_p), ("qr", C.c_void_p), ("qm", C.c_void_p), ("qo", C.c_void_p), ("qk", C.c_void_p),
+                ("perm", C.c_void_p)]
+
+
+def load() -> C.CDLL:
+    if not os.path.exists(_PATH):
+        subprocess.check_call(["make", "-C", _HERE])
+    lib = C.CDLL(_PATH)
+    vp = C.c_void_p
+    lib.orc_msm.argtypes = [C.c_int, vp, vp, C.c_uint64, C.c_int, vp]
+    lib.orc_ntt.argtypes = [C.c_int, vp, C.c_uint64, C.c_int, C.c_int]
+    lib.orc_prove.argtypes = [C.POINTER(Circuit), vp, vp, vp, vp, vp, C.c_int, vp, C.POINTER(C.c_uint64), vp]
+    return lib
+
+
+def prove(lib, curve_id: int, n: int, nb_public: int, srs: bytes, cols, perm, L: bytes, R: bytes, O: bytes, pub: bytes,
+          blinding: bytes, threads: int = 1):
+    """cols = (ql, qr, qm, qo, qk) Montgomery byte strings; perm = list of ints (3n).  Returns (rc, blob, challenges)."""
+    keep = [srs] + list(cols)
+    permarr = (C.c_int64 * len(perm))(*perm)
+    c = Circuit()
+    c.curve, c.n, c.nb_public = curve_id, n, nb_public
+    c.srs = C.cast(C.c_char_p(srs), C.c_void_p)
+    c.ql, c.qr, c.qm, c.qo, c.qk = (C.cast(C.c_char_p(x), C.c_void_p) for x in cols)
+    c.perm = C.cast(permarr, C.c_void_p)
+    blob = C.create_string_buffer(1200)
+    ln = C.c_uint64(0)
+    ch = C.create_string_buffer(160)
+    rc = lib.orc_prove(C.byref(c), L, R, O, pub, blinding, threads, blob, C.byref(ln), ch)
+    del keep
+    return rc, blob.raw[: ln.value], [int.from_bytes(ch.raw[32 * i: 32 * i + 32], "big") for i in range(5)]
