@@ -95,7 +95,7 @@ def Run(ccs: frontend.ConstraintSystem, setupConfig, device: int = 0, seed: Opti
         tau = int.from_bytes(os.urandom(48) if seed is None else seed.to_bytes(48, "big"), "big") % info.Curve.r
         if tau < 2:
             tau += 2
-        srs = setup.unsafe_srs(info.Curve, n, tau, device=device)
+        srs = setup.unsafe_srs(info.Curve, n, tau, device=device, lagrange=bool(ccs.commitments))
     else:
         srs = setup.trusted_srs(info, n)
     return plonk.Setup(ccs, srs, device=device, msm_window=msm_window, slots=slots)

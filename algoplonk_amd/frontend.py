@@ -63,6 +63,9 @@ class ConstraintSystem:
     constraints: List[Tuple[int, int, int, int, int, int, int, int]]  # ql,qr,qm,qo,qk, xa,xb,xc
     solver: List[Tuple[int, Callable[[List[int]], int]]]              # (wire, value from earlier wires)
     nb_variables: int
+    # BSB22 (frontend.Committer): per commitment (rows of the committed constraints, row of the commitment constraint)
+    # = gnark constraint.PlonkCommitment{Committed, CommitmentIndex} [UPSTREAM]
+    commitments: List[Tuple[List[int], int]] = field(default_factory=list)
 
     def GetNbPublicVariables(self) -> int:
         return len(self.public_names)
@@ -85,6 +88,7 @@ class API:
         self.next_wire = nb_inputs
         self.constraints: List[Tuple[int, int, int, int, int, int, int, int]] = []
         self.solver: List[Tuple[int, Callable[[List[int]], int]]] = []
+        self.commitments: List[Tuple[List[int], int]] = []
 
     def _new(self, fn: Callable[[List[int]], int]) -> Variable:
         w = self.next_wire
@@ -120,6 +124,31 @@ class API:
     def AssertIsEqual(self, a: Variable, b: Variable) -> None:
         self.constraints.append((1, self.r - 1, 0, 0, 0, a.wire, b.wire, 0))
 
+    def AssertIsDifferent(self, a: Variable, zero: int = 0) -> None:
+        """Only the `AssertIsDifferent(x, 0)` form the reference's circuits use (bsb22_test.go:34): x * inv == 1."""
+        if zero != 0:
+            raise NotImplementedError("AssertIsDifferent is implemented against the constant 0 only")
+        r = self.r
+        inv = self._new(lambda s, a=a.wire: pow(s[a], -1, r))
+        self.constraints.append((0, 0, 1, 0, r - 1, a.wire, inv.wire, 0))
+
+    def Commit(self, *vs: Variable) -> Variable:
+        """frontend.Committer.Commit (bsb22_test.go:30): gnark's scs builder emits, per committed variable, the
+        constraint  -v + qcp*pi2 = 0  and then  -cmt + qk = 0  whose qk the prover and the verifier inject as
+        hash_fr([pi2])  [UPSTREAM frontend/cs/scs]."""
+        r = self.r
+        rows = []
+        for v in vs:
+            rows.append(len(self.constraints))
+            self.constraints.append((r - 1, 0, 0, 0, 0, v.wire, 0, 0))
+        k = len(self.commitments)
+        cmt = self.next_wire
+        self.next_wire += 1
+        self.solver.append((cmt, ("commit", k)))
+        self.commitments.append((rows, len(self.constraints)))
+        self.constraints.append((r - 1, 0, 0, 0, 0, cmt, 0, 0))
+        return Variable(cmt)
+
 
 def Compile(field_mod: int, circuit: Circuit) -> ConstraintSystem:
     """frontend.Compile(curve.ScalarField(), scs.NewBuilder, circuit) (/root/reference/algoplonk.go:50)."""
@@ -130,7 +159,7 @@ def Compile(field_mod: int, circuit: Circuit) -> ConstraintSystem:
     for i, name in enumerate(pub + sec):
         setattr(shadow, name, Variable(i))
     shadow.define(api)
-    return ConstraintSystem(field_mod, pub, sec, api.constraints, api.solver, api.next_wire)
+    return ConstraintSystem(field_mod, pub, sec, api.constraints, api.solver, api.next_wire, api.commitments)
 
 
 @dataclass
@@ -158,8 +187,10 @@ def NewWitness(assignment: Circuit, field_mod: int) -> Witness:
     return Witness(field_mod, vals[: len(pub)], vals[len(pub):])
 
 
-def solve(ccs: ConstraintSystem, w: Witness) -> List[int]:
-    """Full variable assignment (gnark's constraint solver, SURVEY.md §3.3 R1 `solveConstraints`)."""
+def solve(ccs: ConstraintSystem, w: Witness, commit_hint=None, hiding=None, pi2_out=None) -> List[int]:
+    """Full variable assignment (gnark's constraint solver, SURVEY.md §3.3 R1 `solveConstraints`).
+    BSB22: `commit_hint(column) -> Fr` is gnark's hint (commit the column over the Lagrange SRS, hash the point with
+    hash_fr); `hiding[k]` = the two random entries gnark places in the column; the columns are appended to pi2_out."""
     s = w.Vector() + [0] * (ccs.nb_variables - len(w.public) - len(w.secret))
     if ccs.solver == "gates":
         # every constraint defines its own output wire: c = ql*a + qr*b + qm*a*b + qk  (qo = -1)
@@ -167,8 +198,23 @@ def solve(ccs: ConstraintSystem, w: Witness) -> List[int]:
         for ql, qr, qm, qo, qk, xa, xb, xc in ccs.constraints:
             s[xc] = (ql * s[xa] + qr * s[xb] + qm * s[xa] % r * s[xb] + qk) % r
         return s
+    n, nbp = ccs.domain_size(), ccs.GetNbPublicVariables()
     for wire, fn in ccs.solver:
-        s[wire] = fn(s)
+        if isinstance(fn, tuple) and fn[0] == "commit":
+            if commit_hint is None:
+                raise ValueError("circuit uses Commit: a commitment hint is required to solve it")
+            k = fn[1]
+            rows, cidx = ccs.commitments[k]
+            col = [0] * n
+            for row in rows:
+                col[nbp + row] = s[ccs.constraints[row][5]]
+            col[nbp + cidx] = hiding[k][0]
+            col[nbp + ccs.GetNbConstraints() - 1] = hiding[k][1]
+            s[wire] = commit_hint(col)
+            if pi2_out is not None:
+                pi2_out.append(col)
+        else:
+            s[wire] = fn(s)
     return s
 
 
@@ -183,6 +229,7 @@ class Trace:
     qo: List[int]
     qk: List[int]
     perm: List[int]
+    qcp: List[List[int]] = field(default_factory=list)
 
 
 def build_trace(ccs: ConstraintSystem) -> Trace:
@@ -208,7 +255,13 @@ def build_trace(ccs: ConstraintSystem) -> Trace:
     for i, v in enumerate(lro):
         if perm[i] == -1:
             perm[i] = last[v]
-    return Trace(n, ql, qr, qm, qo, qk, perm)
+    qcp = []
+    for rows, _ in ccs.commitments:
+        col = [0] * n
+        for row in rows:
+            col[nbp + row] = 1
+        qcp.append(col)
+    return Trace(n, ql, qr, qm, qo, qk, perm, qcp)
 
 
 def wire_columns(ccs: ConstraintSystem, solution: Sequence[int]) -> Tuple[List[int], List[int], List[int]]:

@@ -127,8 +127,17 @@ def Setup(ccs: frontend.ConstraintSystem, srs: SRS, device: int = 0, msm_window:
     perm = (C.c_int64 * len(tr.perm))(*tr.perm)
     d = _lib.CircuitDesc()
     d.curve, d.device, d.n = cv.abi, device, tr.n
-    d.nb_public, d.nb_commitments = ccs.GetNbPublicVariables(), 0
-    keep = [srs.g1, srs.g1_lagrange] + cols
+    nbc = len(ccs.commitments)
+    if nbc > _lib.MAX_COMMITMENTS:
+        raise ValueError("at most %d BSB22 commitments" % _lib.MAX_COMMITMENTS)
+    if nbc and not srs.g1_lagrange:
+        raise ValueError("circuits with BSB22 commitments need the Lagrange SRS")
+    d.nb_public, d.nb_commitments = ccs.GetNbPublicVariables(), nbc
+    qcp_cols = [cv.fr_vector(c) for c in tr.qcp]
+    for k in range(nbc):
+        d.qcp[k] = C.cast(C.c_char_p(qcp_cols[k]), C.c_void_p)
+        d.commitment_constraint_index[k] = ccs.commitments[k][1]
+    keep = [srs.g1, srs.g1_lagrange] + cols + qcp_cols
     d.srs_g1 = C.cast(C.c_char_p(srs.g1), C.c_void_p)
     d.srs_g1_lagrange = C.cast(C.c_char_p(srs.g1_lagrange), C.c_void_p) if srs.g1_lagrange else None
     d.ql, d.qr, d.qm, d.qo, d.qk = (C.cast(C.c_char_p(c), C.c_void_p) for c in cols)
@@ -145,23 +154,41 @@ def Setup(ccs: frontend.ConstraintSystem, srs: SRS, device: int = 0, msm_window:
     vk = VerifyingKey(
         curve=cv, Size=tr.n, SizeInv=F(raw.size_inv), Generator=F(raw.generator), CosetShift=F(raw.coset_shift),
         NbPublicVariables=ccs.GetNbPublicVariables(), Ql=P(raw.ql), Qr=P(raw.qr), Qm=P(raw.qm), Qo=P(raw.qo), Qk=P(raw.qk),
-        S=[P(raw.s[i]) for i in range(3)], Qcp=[], CommitmentConstraintIndexes=[],
+        S=[P(raw.s[i]) for i in range(3)], Qcp=[P(raw.qcp[k]) for k in range(nbc)],
+        CommitmentConstraintIndexes=[ccs.commitments[k][1] for k in range(nbc)],
         KzgG1=cv.g1_from_bytes(srs.g1[: 2 * cv.fp_bytes]), tau=srs.tau)
     return pk, vk
 
 
 def Prove(ccs: frontend.ConstraintSystem, pk: ProvingKey, witness: frontend.Witness,
-          blinding: Optional[Sequence[int]] = None) -> Proof:
+          blinding: Optional[Sequence[int]] = None, hiding=None) -> Proof:
     """plonk.Prove(ccs, pk, witness) (/root/reference/algoplonk.go:89).  `blinding` = the 9 scalars gnark draws
     from crypto/rand; drawn from os.urandom when omitted."""
     cv = pk.curve
-    solution = frontend.solve(ccs, witness)
+    nbc = len(ccs.commitments)
+    if hiding is None:
+        hiding = [(int.from_bytes(os.urandom(48), "big") % cv.r, int.from_bytes(os.urandom(48), "big") % cv.r) for _ in range(nbc)]
+
+    def commit_hint(col):
+        # gnark's bsb22 hint: kzg.Commit(column, Lagrange SRS) on the GPU, then hash_to_field (host)
+        pt = C.create_string_buffer(2 * cv.fp_bytes)
+        check(lib.apk_msm_g1(pk.ctx, 1, cv.fr_vector(col), len(col), pt))
+        out = C.create_string_buffer(32)
+        check(lib.apk_hash_fr(cv.abi, pt, out))
+        return cv.fr_from_mont_bytes(out.raw)
+
+    pi2_cols: List[List[int]] = []
+    solution = frontend.solve(ccs, witness, commit_hint if nbc else None, hiding, pi2_cols)
     L, R, O = frontend.wire_columns(ccs, solution)
     if blinding is None:
         blinding = [int.from_bytes(os.urandom(48), "big") % cv.r for _ in range(_lib.NB_BLINDING)]
     if len(blinding) != _lib.NB_BLINDING:
         raise ValueError("need %d blinding scalars" % _lib.NB_BLINDING)
     out = _lib.Proof()
+    pi2_bufs = [cv.fr_vector(col) for col in pi2_cols]
+    pi2_arr = None
+    if nbc:
+        pi2_arr = (C.c_void_p * nbc)(*[C.cast(C.c_char_p(b), C.c_void_p) for b in pi2_bufs])
     check(lib.apk_prove(pk.ctx, cv.fr_vector(L), cv.fr_vector(R), cv.fr_vector(O), cv.fr_vector(witness.public),
-                        cv.fr_vector(blinding), None, C.byref(out)))
+                        cv.fr_vector(blinding), pi2_arr, C.byref(out)))
     return Proof(cv, out)

@@ -26,6 +26,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# one hardware queue per in-flight proof stream (the ROCm default of 4 serialises 16 streams onto 4 queues:
+# 172 -> 205 proofs/s measured); must be set before the HIP runtime initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -37,7 +40,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=17)
     ap.add_argument("--curve", default="bn254", choices=["bn254", "bls12_381"])
-    ap.add_argument("--inflight", type=int, default=4, help="independent proofs per step (context slots)")
+    ap.add_argument("--inflight", type=int, default=16, help="independent proofs per step (context slots)")
     ap.add_argument("--msm-window", type=int, default=0)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -134,9 +137,18 @@ def main() -> None:
     acc_avg_ms = st.msm_accumulate_ms / max(st.msm_accumulate_launches, 1)
     pairs_per_launch = st.msm_pairs / max(st.msm_accumulate_launches, 1)
     achieved = pairs_per_launch * pair_bytes / (acc_avg_ms * 1e-3) / 1e9 if acc_avg_ms > 0 else 0.0
+    # HBM bytes per launch from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
+    # corrected as MI355X_MICROARCH.md prescribes; profiles/r01_pmc_msm_accumulate.json): bytes per pair x pairs
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_msm_accumulate.json")))
+        if cv is ecc.BN254 and args.log_n == 17:
+            traffic = int(pmc["hbm_bytes_per_pair"] * pairs_per_launch)
+    except Exception:
+        traffic = None
     roofline = {
         "bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
         "avg_launch_ms": round(acc_avg_ms, 4), "pairs_per_launch": round(pairs_per_launch, 1),
         "algorithmic_bytes_per_pair": pair_bytes,
     }

@@ -313,6 +313,43 @@ typedef struct { int curve; const domain_t* d; fr_t** polys; int inverse; } fft_
 static void fft_task(void* arg, int i) { fft_job* J = (fft_job*)arg; if (J->inverse) ifft(J->curve, J->d, J->polys[i]); else fft(J->curve, J->d, J->polys[i]); }
 
 
+typedef struct {
+    int cv; size_t n4, chunk; fr_t** ev; fr_t* h; fr_t alpha, a2, beta, gamma, bu, bu2, u, w4; const fr_t* zhinv;
+} quot_job;
+static void quot_task(void* arg, int t) {
+    quot_job* Q = (quot_job*)arg;
+    const fr_field* F = &FR[Q->cv];
+    enum { EL, ER, EO, EZ, EQK, EQL, EQR, EQM, EQO, ES1, ES2, ES3, EL0 };
+    fr_t** ev = Q->ev; fr_t* h = Q->h;
+    const size_t n4 = Q->n4, lo = (size_t)t * Q->chunk, hi = lo + Q->chunk < n4 ? lo + Q->chunk : n4;
+    const fr_t alpha = Q->alpha, a2 = Q->a2, beta = Q->beta, gamma = Q->gamma, bu = Q->bu, bu2 = Q->bu2, w4 = Q->w4;
+    const fr_t* zhinv = Q->zhinv;
+    fr_t x; f4_pow_u64(F, &x, &w4, lo); f4_mul(F, &x, &x, &Q->u);
+    for (size_t i = lo; i < hi; i++) {
+        fr_t l = ev[EL][i], r = ev[ER][i], o = ev[EO][i], z = ev[EZ][i], zs = ev[EZ][(i + 4) % n4];
+        fr_t gate, t, lg, rg, og, pa, pb, a, b, c, loc, num;
+        f4_mul(F, &gate, &ev[EQL][i], &l);
+        f4_mul(F, &t, &ev[EQR][i], &r); f4_add(F, &gate, &gate, &t);
+        f4_mul(F, &t, &l, &r); f4_mul(F, &t, &t, &ev[EQM][i]); f4_add(F, &gate, &gate, &t);
+        f4_mul(F, &t, &ev[EQO][i], &o); f4_add(F, &gate, &gate, &t);
+        f4_add(F, &gate, &gate, &ev[EQK][i]);
+        f4_add(F, &lg, &l, &gamma); f4_add(F, &rg, &r, &gamma); f4_add(F, &og, &o, &gamma);
+        f4_mul(F, &t, &beta, &ev[ES1][i]); f4_add(F, &a, &lg, &t);
+        f4_mul(F, &t, &beta, &ev[ES2][i]); f4_add(F, &b, &rg, &t);
+        f4_mul(F, &t, &beta, &ev[ES3][i]); f4_add(F, &c, &og, &t);
+        f4_mul(F, &pa, &zs, &a); f4_mul(F, &pa, &pa, &b); f4_mul(F, &pa, &pa, &c);
+        f4_mul(F, &t, &beta, &x); f4_add(F, &a, &lg, &t);
+        f4_mul(F, &t, &bu, &x); f4_add(F, &b, &rg, &t);
+        f4_mul(F, &t, &bu2, &x); f4_add(F, &c, &og, &t);
+        f4_mul(F, &pb, &z, &a); f4_mul(F, &pb, &pb, &b); f4_mul(F, &pb, &pb, &c);
+        f4_sub(F, &t, &z, &F->one); f4_mul(F, &loc, &ev[EL0][i], &t);
+        f4_sub(F, &t, &pa, &pb); f4_mul(F, &t, &t, &alpha); f4_add(F, &num, &gate, &t);
+        f4_mul(F, &t, &a2, &loc); f4_add(F, &num, &num, &t);
+        f4_mul(F, &h[i], &num, &zhinv[i & 3]);
+        f4_mul(F, &x, &x, &w4);
+    }
+}
+
 /* plonk.Prove (algoplonk.go:89).  Inputs as in include/apk.h apk_prove; output = the proof blob of helper.go:13-88
  * (768 bytes BN254 / 1056 bytes BLS12-381, no BSB22 support in the C oracle) */
 int orc_prove(const orc_circuit* C, const void* Lp, const void* Rp, const void* Op, const void* pubp, const void* blindp,
@@ -431,29 +468,12 @@ int orc_prove(const orc_circuit* C, const void* Lp, const void* Rp, const void* 
         fr_t zhinv[4];
         { fr_t un, i4, cur; f4_pow_u64(F, &un, &u, n); f4_pow_u64(F, &i4, &w4, n); cur = un;
           for (int k = 0; k < 4; k++) { fr_t t; f4_sub(F, &t, &cur, &F->one); f4_inv(F, &zhinv[k], &t); f4_mul(F, &cur, &cur, &i4); } }
-        fr_t x = u;
-        for (size_t i = 0; i < n4; i++) {
-            fr_t l = ev[EL][i], r = ev[ER][i], o = ev[EO][i], z = ev[EZ][i], zs = ev[EZ][(i + 4) % n4];
-            fr_t gate, t, lg, rg, og, pa, pb, a, b, c, loc, num;
-            f4_mul(F, &gate, &ev[EQL][i], &l);
-            f4_mul(F, &t, &ev[EQR][i], &r); f4_add(F, &gate, &gate, &t);
-            f4_mul(F, &t, &l, &r); f4_mul(F, &t, &t, &ev[EQM][i]); f4_add(F, &gate, &gate, &t);
-            f4_mul(F, &t, &ev[EQO][i], &o); f4_add(F, &gate, &gate, &t);
-            f4_add(F, &gate, &gate, &ev[EQK][i]);
-            f4_add(F, &lg, &l, &gamma); f4_add(F, &rg, &r, &gamma); f4_add(F, &og, &o, &gamma);
-            f4_mul(F, &t, &beta, &ev[ES1][i]); f4_add(F, &a, &lg, &t);
-            f4_mul(F, &t, &beta, &ev[ES2][i]); f4_add(F, &b, &rg, &t);
-            f4_mul(F, &t, &beta, &ev[ES3][i]); f4_add(F, &c, &og, &t);
-            f4_mul(F, &pa, &zs, &a); f4_mul(F, &pa, &pa, &b); f4_mul(F, &pa, &pa, &c);
-            f4_mul(F, &t, &beta, &x); f4_add(F, &a, &lg, &t);
-            f4_mul(F, &t, &bu, &x); f4_add(F, &b, &rg, &t);
-            f4_mul(F, &t, &bu2, &x); f4_add(F, &c, &og, &t);
-            f4_mul(F, &pb, &z, &a); f4_mul(F, &pb, &pb, &b); f4_mul(F, &pb, &pb, &c);
-            f4_sub(F, &t, &z, &F->one); f4_mul(F, &loc, &ev[EL0][i], &t);
-            f4_sub(F, &t, &pa, &pb); f4_mul(F, &t, &t, &alpha); f4_add(F, &num, &gate, &t);
-            f4_mul(F, &t, &a2, &loc); f4_add(F, &num, &num, &t);
-            f4_mul(F, &h[i], &num, &zhinv[i & 3]);
-            f4_mul(F, &x, &x, &w4);
+        {
+            quot_job Q; Q.cv = cv; Q.n4 = n4; Q.ev = ev; Q.h = h; Q.alpha = alpha; Q.a2 = a2; Q.beta = beta; Q.gamma = gamma;
+            Q.bu = bu; Q.bu2 = bu2; Q.u = u; Q.w4 = w4; Q.zhinv = zhinv;
+            int tasks = threads > 1 ? threads * 2 : 1;
+            Q.chunk = (n4 + tasks - 1) / tasks;
+            parallel_for(quot_task, &Q, (int)((n4 + Q.chunk - 1) / Q.chunk), threads);
         }
         ifft(cv, &d1, h);
         fr_t ui, p = F->one; f4_inv(F, &ui, &u);

@@ -55,3 +55,58 @@ def random_chain(cv: Curve, log_n: int, seed: int, nb_public: int = 2) -> Tuple[
         cons.append((ql, qr, qm, r - 1, qk, xa, xb, nv))
         sol.append(c)
     return Circuit(cv, nb_public, len(sol), cons), sol
+
+
+def bsb22_square(cv: Curve, nb_commitments: int, x: int = 9, y: int = 3):
+    """bsb22_test.go:18-39: X == Y*Y, then `Commit(Y, X)` nb_commitments times, each followed by AssertIsDifferent(cmt, 0).
+    Constraint encoding of gnark's scs builder `Commit` [UPSTREAM frontend/cs/scs, restated; SURVEY.md §3.3 R1]:
+      committed wire v :  -v + qcp*pi2 = 0          (ql = -1, qcp row = 1)
+      commitment wire  :  -cmt + qk = 0             (ql = -1, qk injected by prover and verifier = hash_fr([pi2]))
+    Returns (circuit, partial solution with the commitment-dependent wires unset, plan) - see `solve_bsb22`."""
+    from .plonk import Commitment
+    r = cv.r
+    m1 = r - 1
+    # vars: 0 = X (public), 1 = Y, then per commitment: cmt_k, inv_k
+    cons = [(0, 0, 1, m1, 0, 1, 1, 0)]                      # Y*Y - X = 0
+    commitments = []
+    plan = []
+    nv = 2
+    for _ in range(nb_commitments):
+        committed_rows = []
+        for v in (1, 0):                                    # Commit(Y, X)
+            committed_rows.append(len(cons))
+            cons.append((m1, 0, 0, 0, 0, v, 0, 0))
+        cmt, inv = nv, nv + 1
+        nv += 2
+        cidx = len(cons)
+        cons.append((m1, 0, 0, 0, 0, cmt, 0, 0))            # -cmt + qk(injected) = 0
+        cons.append((0, 0, 1, 0, m1, cmt, inv, 0))          # cmt * inv - 1 = 0   (AssertIsDifferent(cmt, 0))
+        commitments.append(Commitment(committed_rows, cidx))
+        plan.append((cmt, inv))
+    return Circuit(cv, 1, nv, cons, commitments), [x % r, y % r] + [0] * (nv - 2), plan
+
+
+def solve_bsb22(c: Circuit, sol, plan, commit_lagrange, hiding):
+    """gnark's solver with the BSB22 hint: for each commitment build the committed column pi2
+    (wire values at the committed rows + two hiding entries), commit it over the Lagrange SRS, hash the point to Fr
+    (hash_fr) and assign that to the commitment wire.  `commit_lagrange(evals) -> point`; hiding = 2 scalars each."""
+    from .plonk import hash_fr
+    cv = c.curve
+    r = cv.r
+    n = c.domain_size()
+    off = c.nb_public
+    sol = list(sol)
+    pi2s = []
+    for k, cm in enumerate(c.commitments):
+        col = [0] * n
+        for row in cm.committed:
+            col[off + row] = sol[c.constraints[row][5]]
+        col[off + cm.commitment_index] = hiding[k][0]
+        col[off + len(c.constraints) - 1] = hiding[k][1]
+        P = commit_lagrange(col)
+        val = hash_fr(cv.raw_bytes(P), r)
+        cmt, inv = plan[k]
+        sol[cmt] = val
+        sol[inv] = pow(val, -1, r)
+        pi2s.append(col)
+    return sol, pi2s

@@ -123,25 +123,27 @@ static void CN(jac_to_aff)(const FPN(field) * F, CN(aff) * r, const CN(jac) * p)
     FPN(mul)(F, &r->y, &p->Y, &zi2);
 }
 
-/* ---- Pippenger, one window per task ----------------------------------------------------------------------- */
+/* ---- Pippenger: tasks = windows x point-chunks (so every host core has work) ------------------------------- */
 typedef struct {
     const FPN(field) * F;
     const CN(aff) * pts;
     const uint64_t* sc; /* n x 4 plain (non-Montgomery) scalar limbs */
     size_t n;
-    int c, nwin;
-    CN(jac) * win_sum;
+    int c, nwin, nchunk;
+    CN(jac) * part; /* [nwin][nchunk] */
 } CN(msm_job);
 
-static void CN(msm_window)(void* arg, int w) {
+static void CN(msm_task)(void* arg, int t) {
     CN(msm_job)* J = (CN(msm_job)*)arg;
     const FPN(field)* F = J->F;
-    const int c = J->c;
+    const int c = J->c, w = t / J->nchunk, ch = t % J->nchunk;
     const size_t nb = (size_t)1 << c; /* unsigned digits: buckets 1 .. 2^c - 1 */
+    const size_t per = (J->n + J->nchunk - 1) / J->nchunk;
+    const size_t lo = (size_t)ch * per < J->n ? (size_t)ch * per : J->n, hi = lo + per < J->n ? lo + per : J->n;
     CN(jac)* B = (CN(jac)*)malloc(nb * sizeof(CN(jac)));
     for (size_t k = 0; k < nb; k++) CN(jac_set_inf)(F, &B[k]);
     const int bit = w * c;
-    for (size_t i = 0; i < J->n; i++) {
+    for (size_t i = lo; i < hi; i++) {
         const uint64_t* s = J->sc + 4 * i;
         int word = bit >> 6, off = bit & 63;
         uint64_t v = word < 4 ? s[word] >> off : 0;
@@ -156,24 +158,30 @@ static void CN(msm_window)(void* arg, int w) {
         CN(jac_add)(F, &run, &run, &B[k]);
         CN(jac_add)(F, &sum, &sum, &run);
     }
-    J->win_sum[w] = sum;
+    J->part[t] = sum;
     free(B);
 }
 
 static void CN(msm)(const FPN(field) * F, const CN(aff) * pts, const uint64_t* plain_scalars, size_t n, int scalar_bits,
                     int threads, CN(aff) * out) {
-    int c = 4;
-    { size_t m = n; int lg = 0; while (m > 1) { m >>= 1; lg++; } c = lg > 8 ? lg - 4 : (lg > 3 ? lg - 1 : 2); if (c > 16) c = 16; if (c < 2) c = 2; }
+    int nchunk = 1;
+    if (threads > 32 && n >= 4096) { nchunk = threads / 24; if (nchunk < 1) nchunk = 1; }
+    size_t m = (n + nchunk - 1) / nchunk;
+    int lg = 0;
+    while (m > 1) { m >>= 1; lg++; }
+    int c = lg > 8 ? lg - 4 : (lg > 3 ? lg - 1 : 2);
+    if (c > 16) c = 16;
+    if (c < 2) c = 2;
     int nwin = (scalar_bits + c - 1) / c;
-    CN(msm_job) J = {F, pts, plain_scalars, n, c, nwin, NULL};
-    J.win_sum = (CN(jac)*)malloc((size_t)nwin * sizeof(CN(jac)));
-    parallel_for(CN(msm_window), &J, nwin, threads);
+    CN(msm_job) J = {F, pts, plain_scalars, n, c, nwin, nchunk, NULL};
+    J.part = (CN(jac)*)malloc((size_t)nwin * nchunk * sizeof(CN(jac)));
+    parallel_for(CN(msm_task), &J, nwin * nchunk, threads);
     CN(jac) acc;
     CN(jac_set_inf)(F, &acc);
     for (int w = nwin - 1; w >= 0; w--) {
         for (int k = 0; k < c; k++) CN(jac_dbl)(F, &acc, &acc);
-        CN(jac_add)(F, &acc, &acc, &J.win_sum[w]);
+        for (int ch = 0; ch < nchunk; ch++) CN(jac_add)(F, &acc, &acc, &J.part[w * nchunk + ch]);
     }
-    free(J.win_sum);
+    free(J.part);
     CN(jac_to_aff)(F, out, &acc);
 }

@@ -238,3 +238,63 @@ def test_msm_only_context_and_index_range_sharding(gpu, cname):
         assert lib.apk_ntt(sm._ctx, 0, 0, 0, sc_bytes) == _lib.APK_ERR_STATE
         sm.close()
     assert cv.g1_from_bytes(acc) == ov.mul(ov.g1, oplonk.poly_eval(scalars, tau, cv.r))
+
+
+class _Bsb22Circuit(frontend.Circuit):
+    """bsb22_test.go:18-39."""
+    X = frontend.Public()
+    Y = frontend.Secret()
+
+    def __init__(self, nb=1):
+        self.nb = nb
+
+    def define(self, api):
+        api.AssertIsEqual(self.X, api.Mul(self.Y, self.Y))
+        for _ in range(self.nb):
+            cmt = api.Commit(self.Y, self.X)
+            api.AssertIsDifferent(cmt, 0)
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12-381"])
+@pytest.mark.parametrize("nb", [1, 2])
+def test_bsb22_proof_marshalling_and_verification(gpu, cname, nb):
+    """bsb22_test.go:46-123 (TestBsb22ProofMarshalling) + the oracle prover on the same inputs, byte for byte."""
+    cv, ov = CURVES[cname]
+    ccs = frontend.Compile(cv.r, _Bsb22Circuit(nb))
+    assert len(ccs.commitments) == nb
+    n = ccs.domain_size()
+    tau = tau_from_seed(41, cv.r)
+    srs = ap_setup.unsafe_srs(cv, n, tau, device=gpu, lagrange=True)
+    pk, vk = ap_plonk.Setup(ccs, srs, device=gpu)
+    a = _Bsb22Circuit(nb); a.X, a.Y = 9, 3
+    w = frontend.NewWitness(a, cv.r)
+    g = SplitMix64(77)
+    hiding = [(g.fr(cv.r), g.fr(cv.r)) for _ in range(nb)]
+    bl = blinding(cv, 12)
+    proof = ap_plonk.Prove(ccs, pk, w, bl, hiding=hiding)
+    blob, pib = MarshalProof(proof), MarshalPublicInputs(w)
+    base_words, pt = (24, 64) if cv is ecc.BN254 else (33, 96)
+    assert len(blob) == base_words * 32 + nb * 32 + nb * pt                      # bsb22_test.go:97-101
+    for i in range(nb):                                                          # :103-120
+        assert blob[(base_words + i) * 32:(base_words + i + 1) * 32] == proof.ClaimedValues[6 + i].to_bytes(32, "big")
+        start = (base_words + nb) * 32 + i * pt
+        assert blob[start:start + pt] == ov.raw_bytes(proof.Bsb22Commitments[i])
+    # oracle prover on the same circuit / hiding / blinding
+    from oracle import circuits as ocircuits
+    oc_ = oplonk.Circuit(ov, ccs.GetNbPublicVariables(), ccs.nb_variables, list(ccs.constraints),
+                         [oplonk.Commitment(list(rows), cidx) for rows, cidx in ccs.commitments])
+    osrs = oplonk.synthetic_srs(ov, n, tau, materialize=False)
+    opk = oplonk.setup(oc_, osrs)
+    wn = ov.omega(n)
+    pi2 = []
+    sol = frontend.solve(ccs, w, lambda col: oplonk.hash_fr(ov.raw_bytes(osrs.commit(oplonk.intt(col, wn, cv.r))), cv.r), hiding, pi2)
+    L, R, O = oplonk.solve_lro(oc_, sol)
+    opr = oplonk.prove(opk, L, R, O, w.public, bl, pi2=pi2)
+    assert proof.Bsb22Commitments == opr.bsb22_commitments
+    assert blob == oplonk.marshal_proof(ov, opr)
+    assert vk.Qcp == opk.vk.qcp and vk.CommitmentConstraintIndexes == opk.vk.commitment_constraint_indexes
+    ovk = oracle_vk_from_product(ov, vk)
+    assert oplonk.verify(ovk, blob, pib)
+    bad = bytearray(blob); bad[-1] ^= 1
+    assert not oplonk.verify(ovk, bytes(bad), pib)
+    pk.close()

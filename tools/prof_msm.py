@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Small driver for profiler runs: one context at BN254 2^log_n, then a few single MSMs and proofs.
+usage: python tools/prof_msm.py [log_n] [msms] [proofs]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from algoplonk_amd import _lib, ecc, frontend, plonk, setup, workloads
+from algoplonk_amd._lib import lib, check
+
+log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 17
+n_msm = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+n_proofs = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+cv = ecc.BN254
+wl = workloads.random_circuit(cv, log_n, 0xA190)
+n = wl.ccs.domain_size()
+srs = setup.unsafe_srs(cv, n, wl.tau)
+pk, vk = plonk.Setup(wl.ccs, srs)
+L, R, O = frontend.wire_columns(wl.ccs, wl.solution)
+d = []
+for v in (L, R, O):
+    b = cv.fr_vector(v)
+    p = C.c_void_p()
+    check(lib.apk_device_alloc(pk.ctx, len(b), C.byref(p)))
+    check(lib.apk_device_upload(pk.ctx, p, b, len(b)))
+    d.append(p)
+out = C.create_string_buffer(64)
+for _ in range(n_msm):
+    check(lib.apk_msm_g1_device(pk.ctx, 0, d[0], n, out))
+pr = _lib.Proof()
+for _ in range(n_proofs):
+    check(lib.apk_prove_device(pk.ctx, d[0], d[1], d[2], cv.fr_vector(wl.witness.public), cv.fr_vector(wl.blinding), None, C.byref(pr)))
+print("done")
