@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <string>
+#include <type_traits>
 
 #include <hip/hip_runtime_api.h>
 
@@ -82,6 +83,9 @@ static void g1_raw(int curve, const uint8_t* slot, uint8_t* out) {
 
 // ---- host-side execution of the SAME arithmetic templates the kernels use (ff.h / ec.h are host+device):
 // lets the CPU-only test tier check the field and curve formulas against the oracle without a GPU.
+template <class P, class = void> struct HasUnsat : std::false_type {};
+template <class P> struct HasUnsat<P, std::void_t<decltype(P::UL)>> : std::true_type {};
+
 template <class P>
 static int fe_op_t(int op, const void* a, const void* b, void* out) {
     using F = Fe<P>;
@@ -94,6 +98,17 @@ static int fe_op_t(int op, const void* a, const void* b, void* out) {
         case 2: r = F::mul(x, y); break;
         case 3: r = F::inv(x); break;
         case 4: r = F::neg(x); break;
+        // 10..13: the same operation carried out in the unsaturated-limb MSM field (ffu.h), converted in and out
+        case 10: case 11: case 12: case 13:
+            if constexpr (HasUnsat<P>::value) {
+                using U = FeU<P>;
+                U ux = U::from_fe(x), uy = U::from_fe(y);
+                r = (op == 10 ? U::mul(ux, uy) : op == 11 ? U::add(ux, uy) : op == 12 ? U::sub(ux, uy) : U::neg(ux)).to_fe();
+                break;
+            } else {
+                set_error("field has no unsaturated-limb form");
+                return APK_ERR_ARG;
+            }
         default: set_error("unknown field op %d", op); return APK_ERR_ARG;
     }
     memcpy(out, &r, sizeof r);
@@ -136,6 +151,22 @@ static int g1_op_t(int op, const void* p, const void* q, void* out) {
                     if ((s.l[w] >> bit) & 1u) acc.madd(a);
                 }
             r = acc.to_affine();
+            break;
+        }
+        case 10: case 11: {  // mixed (10) / full (11) addition in the unsaturated-limb representation
+            using XU = XYZZ<FPP, FeU<FPP>>;
+            memcpy(&b, q, sizeof b);
+            Affine<FPP> ra = to_table_record<FPP>(a), rb = to_table_record<FPP>(b);
+            XU acc = op == 10 ? XU::from_affine(unpack_affine<FPP>(ra)) : XU::dbl_affine(unpack_affine<FPP>(ra));
+            if (op == 11) acc.madd(unpack_affine<FPP>(ra), true);
+            if (op == 10) {
+                acc.madd(unpack_affine<FPP>(rb));
+            } else {
+                XU other = XU::dbl_affine(unpack_affine<FPP>(rb));
+                other.madd(unpack_affine<FPP>(rb), true);
+                acc.add(other);
+            }
+            r = to_fe_point<FPP>(acc).to_affine();
             break;
         }
         default: set_error("unknown g1 op %d", op); return APK_ERR_ARG;

@@ -68,6 +68,7 @@ class CurveBackend : public Backend {
     using Fp = Fe<FPP>;
     using Aff = Affine<FPP>;
     using Pt = XYZZ<FPP>;
+    using PtU = XYZZ<FPP, FeU<FPP>>;  // MSM-internal points: unsaturated limbs (ffu.h)
     static constexpr int FPB = FPP::N * 4;  // bytes per Fp element
 
     // ---------------------------------------------------------------------------------------------- host Fr
@@ -177,9 +178,9 @@ class CurveBackend : public Backend {
     }
 
     // ---------------------------------------------------------------------------------------------- NTT runner
-    // natural in -> natural out; in != out.  which: 0 = size n, 1 = size 4n
-    int run_ntt(hipStream_t st, int which, bool inverse, const Fr* in, Fr* out, uint32_t in_len, uint32_t out_len,
-                const Fr* pre, const Fr* post, const Fr* scale) {
+    // natural in -> natural out; in != out.  which: 0 = size n, 1 = size 4n.  `count` same-size transforms per launch.
+    int run_ntt_batch(hipStream_t st, int which, bool inverse, int count, const Fr* const* ins, Fr* const* outs, const uint32_t* in_lens,
+                      uint32_t out_len, const Fr* pre, const Fr* post, const Fr* scale) {
         const int log_n = which ? (int)log_n_ + 2 : (int)log_n_;
         const Fr* tw = which ? (inverse ? ptr<Fr>(twi_4n_) : ptr<Fr>(tw_4n_)) : (inverse ? ptr<Fr>(twi_n_) : ptr<Fr>(tw_n_));
         // small transforms are latency-bound: 512-element tiles (16 KiB LDS) give >= 256 workgroups at 2^17;
@@ -189,6 +190,8 @@ class CurveBackend : public Backend {
         if (tile_log > log_n) tile_log = log_n;
         if (max_s > tile_log) max_s = tile_log;
         const int passes = (log_n + max_s - 1) / max_s;
+        NttBatch nb{};
+        for (int i = 0; i < count; i++) { nb.in[i] = ins[i]; nb.out[i] = outs[i]; nb.in_len[i] = in_lens[i]; }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         Slot* owner = nullptr;
         if (stats_on_) {
@@ -201,10 +204,10 @@ class CurveBackend : public Backend {
             NttPassArgs a;
             a.log_n = log_n; a.tile_log = tile_log; a.t0 = t0; a.t1 = t0 + s;
             a.first = (p == 0); a.last = (p == passes - 1);
-            a.in_len = in_len; a.out_len = out_len;
-            const uint32_t grid = 1u << (log_n - tile_log);
+            a.out_len = out_len;
+            const dim3 grid(1u << (log_n - tile_log), count);
             const size_t lds = ((size_t)1 << tile_log) * sizeof(Fr);
-            ntt_pass_kernel<FRP><<<grid, NTT_THREADS, lds, st>>>(p == 0 ? in : out, out, tw, pre, post, scale, a);
+            ntt_pass_kernel<FRP><<<grid, NTT_THREADS, lds, st>>>(nb, tw, pre, post, scale, a);
             KCHK();
             t0 += s;
         }
@@ -215,9 +218,13 @@ class CurveBackend : public Backend {
             HIPCHK(hipEventElapsedTime(&ms, e0, e1));
             std::lock_guard<std::mutex> g(stats_mu_);
             stats_.ntt_ms += ms;
-            stats_.ntt_elements += (uint64_t)1 << log_n;
+            stats_.ntt_elements += ((uint64_t)1 << log_n) * count;
         }
         return APK_OK;
+    }
+    int run_ntt(hipStream_t st, int which, bool inverse, const Fr* in, Fr* out, uint32_t in_len, uint32_t out_len,
+                const Fr* pre, const Fr* post, const Fr* scale) {
+        return run_ntt_batch(st, which, inverse, 1, &in, &out, &in_len, out_len, pre, post, scale);
     }
     int inv_ntt_n(hipStream_t st, const Fr* in, Fr* out) { return run_ntt(st, 0, true, in, out, n_, n_, nullptr, nullptr, ptr<Fr>(scales_)); }
     // evaluations of a canonical polynomial (len coefficients) on the 4n coset
@@ -266,19 +273,25 @@ class CurveBackend : public Backend {
         KCHK();
         if (stats_on_) HIPCHK(hipEventRecord(s.ev2, st));
         msm_accumulate_kernel<FPP><<<cdiv(max_units, 128), 128, 0, st>>>(ptr<Aff>(T.table), ptr<uint32_t>(s.sorted), ptr<uint32_t>(s.offsets),
-                                                                        ptr<uint32_t>(s.unit_off), total_buckets, max_units, ptr<Pt>(s.partial));
+                                                                        ptr<uint32_t>(s.unit_off), total_buckets, max_units, ptr<PtU>(s.partial));
         KCHK();
         if (stats_on_) HIPCHK(hipEventRecord(s.ev3, st));
-        msm_combine_kernel<FPP><<<cdiv((uint64_t)total_buckets * MSM_COMBINE_LANES, 256), 256, 0, st>>>(
-            ptr<Pt>(s.partial), ptr<uint32_t>(s.unit_off), total_buckets, ptr<Pt>(s.bucket_sum));
+        // lanes per bucket: ~5 unit partials per lane, so the sequential part and the shuffle tree are balanced
+        int lanes_log = 0;
+        {
+            const uint64_t upb = (entries / MSM_UNIT) / total_buckets + 1;  // unit partials per bucket (estimate)
+            while ((1u << lanes_log) < MSM_COMBINE_LANES && (upb >> lanes_log) > 5) lanes_log++;
+        }
+        msm_combine_kernel<FPP><<<cdiv((uint64_t)total_buckets << lanes_log, 256), 256, 0, st>>>(
+            ptr<PtU>(s.partial), ptr<uint32_t>(s.unit_off), total_buckets, lanes_log, ptr<PtU>(s.bucket_sum));
         KCHK();
         const uint32_t nchunk = NB_ > 2048 ? NB_ / 2048 : 1;
         const uint32_t nbits = (uint32_t)c_;
         dim3 gr(nchunk, nbits, a.batch);
-        msm_bitsum_kernel<FPP><<<gr, MSM_RED_THREADS, MSM_RED_THREADS * sizeof(Pt), st>>>(ptr<Pt>(s.bucket_sum), NB_, nchunk, nbits,
-                                                                                           ptr<Pt>(s.bit_partial));
+        msm_bitsum_kernel<FPP><<<gr, MSM_RED_THREADS, MSM_RED_THREADS * sizeof(PtU), st>>>(ptr<PtU>(s.bucket_sum), NB_, nchunk, nbits,
+                                                                                           ptr<PtU>(s.bit_partial));
         KCHK();
-        msm_final_kernel<FPP><<<a.batch, 256, 0, st>>>(ptr<Pt>(s.bit_partial), nchunk, nbits, ptr<Aff>(s.result), ptr<Pt>(s.result_xyzz));
+        msm_final_kernel<FPP><<<a.batch, 256, 0, st>>>(ptr<PtU>(s.bit_partial), nchunk, nbits, ptr<Aff>(s.result), ptr<Pt>(s.result_xyzz));
         KCHK();
         if (stats_on_) HIPCHK(hipEventRecord(s.ev1, st));
         HIPCHK(hipMemcpyAsync(h_out, s.result.p, a.batch * sizeof(Aff), hipMemcpyDeviceToHost, st));
@@ -333,10 +346,10 @@ class CurveBackend : public Backend {
         CHK(s.unit_off.alloc((size_t)(tb + 1) * 4));
         CHK(s.counts.alloc((size_t)tb * msm_G_max_ * 4));
         CHK(s.sorted.alloc(entries * 4));
-        CHK(s.partial.alloc((entries / MSM_UNIT + tb) * sizeof(Pt)));
-        CHK(s.bucket_sum.alloc((size_t)tb * sizeof(Pt)));
+        CHK(s.partial.alloc((entries / MSM_UNIT + tb) * sizeof(PtU)));
+        CHK(s.bucket_sum.alloc((size_t)tb * sizeof(PtU)));
         const uint32_t nchunk = NB_ > 2048 ? NB_ / 2048 : 1;
-        CHK(s.bit_partial.alloc((size_t)batch * c_ * nchunk * sizeof(Pt)));
+        CHK(s.bit_partial.alloc((size_t)batch * c_ * nchunk * sizeof(PtU)));
         CHK(s.result.alloc(MSM_MAX_BATCH * sizeof(Aff)));
         CHK(s.result_xyzz.alloc(MSM_MAX_BATCH * sizeof(Pt)));
         return APK_OK;
@@ -361,7 +374,16 @@ class CurveBackend : public Backend {
     };
 
     int powers(hipStream_t st, Fr* out, uint32_t count, const Fr& w, const Fr& scale) {
-        powers_kernel<FRP><<<cdiv(cdiv(count, 16), 256), 256, 0, st>>>(out, count, w, scale);
+        PowersBatch<FRP> pb{};
+        pb.out[0] = out; pb.w[0] = w; pb.scale[0] = scale;
+        powers_kernel<FRP><<<dim3(cdiv(cdiv(count, 8), 256), 1), 256, 0, st>>>(pb, count);
+        KCHK();
+        return APK_OK;
+    }
+    int powers_batch(hipStream_t st, int k, Fr* const* outs, const Fr* ws, uint32_t count) {
+        PowersBatch<FRP> pb{};
+        for (int i = 0; i < k; i++) { pb.out[i] = outs[i]; pb.w[i] = ws[i]; pb.scale[i] = Fr::one(); }
+        powers_kernel<FRP><<<dim3(cdiv(cdiv(count, 8), 256), k), 256, 0, st>>>(pb, count);
         KCHK();
         return APK_OK;
     }
@@ -788,9 +810,12 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     }
     Fr* canon[3] = {ptr<Fr>(s.cl), ptr<Fr>(s.cr), ptr<Fr>(s.co)};
     const Fr* wires[3] = {dL, dR, dO};
+    for (int j = 0; j < 3; j++) HIPCHK(hipMemsetAsync(canon[j] + n, 0, 4 * sizeof(Fr), st));
+    {
+        const uint32_t lens[3] = {n, n, n};
+        CHK(run_ntt_batch(st, 0, true, 3, wires, canon, lens, n, nullptr, nullptr, ptr<Fr>(scales_)));
+    }
     for (int j = 0; j < 3; j++) {
-        HIPCHK(hipMemsetAsync(canon[j] + n, 0, 4 * sizeof(Fr), st));
-        CHK(inv_ntt_n(st, wires[j], canon[j]));
         Fr4<FRP> b{};
         b.v[0] = bl[2 * j]; b.v[1] = bl[2 * j + 1];
         blind_kernel<FRP><<<1, 64, 0, st>>>(canon[j], n, b, 2); KCHK();
@@ -808,9 +833,10 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         HIPCHK(hipMemcpyAsync(ptr<Fr>(s.qk_lag) + nb_public_ + cci_[k], &cval[k], sizeof(Fr), hipMemcpyHostToDevice, st));
     CHK(inv_ntt_n(st, ptr<Fr>(s.qk_lag), ptr<Fr>(s.qk_can)));
     CHK(coset_ntt_4n(st, ptr<Fr>(s.qk_can), n, ptr<Fr>(s.eqk)));
-    for (int j = 0; j < 3; j++) {
+    {
         Fr* ev[3] = {ptr<Fr>(s.el), ptr<Fr>(s.er), ptr<Fr>(s.eo)};
-        CHK(coset_ntt_4n(st, canon[j], n + 2, ev[j]));
+        const uint32_t lens[3] = {n + 2, n + 2, n + 2};
+        CHK(run_ntt_batch(st, 1, false, 3, canon, ev, lens, n4_, ptr<Fr>(coset_pre_), nullptr, nullptr));
     }
     HIPCHK(hipStreamSynchronize(st));
     Aff lro[3] = {hp[0], hp[1], hp[2]};
@@ -904,11 +930,10 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     const Fr zw = zeta * omega_;
     const bool z0 = zeta.is_zero();
     const Fr zeta_inv = Fr::inv(zeta), zw_inv = Fr::inv(zw);
-    CHK(powers(st, ptr<Fr>(s.pw_z), n + 3, zeta, Fr::one()));
-    CHK(powers(st, ptr<Fr>(s.pw_zw), n + 3, zw, Fr::one()));
-    if (!z0) {
-        CHK(powers(st, ptr<Fr>(s.pw_zi), n + 3, zeta_inv, Fr::one()));
-        CHK(powers(st, ptr<Fr>(s.pw_zwi), n + 3, zw_inv, Fr::one()));
+    {
+        Fr* outs[4] = {ptr<Fr>(s.pw_z), ptr<Fr>(s.pw_zw), ptr<Fr>(s.pw_zi), ptr<Fr>(s.pw_zwi)};
+        const Fr ws[4] = {zeta, zw, zeta_inv, zw_inv};
+        CHK(powers_batch(st, z0 ? 2 : 4, outs, ws, n + 3));
     }
     Fr ev[EVAL_MAX];
     {

@@ -8,29 +8,47 @@
 // G1Affine.MultiExp runs on [UPSTREAM; reached from /root/reference/algoplonk.go:89 via kzg.Commit].
 #pragma once
 #include "ff.h"
+#include "ffu.h"
 
-template <class FP>
+// FT = field element class: Fe<FP> (saturated, gnark's Montgomery radix - what crosses the C-ABI) or FeU<FP>
+// (unsaturated limbs, radix R' - the MSM pipeline's internal form, ffu.h).
+template <class FP, class FT = Fe<FP>>
 struct Affine {
-    Fe<FP> x, y;
+    FT x, y;
     APK_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
-    APK_HD static Affine inf() { return Affine{Fe<FP>::zero(), Fe<FP>::zero()}; }
+    APK_HD static Affine inf() { return Affine{FT::zero(), FT::zero()}; }
 };
 
+// packed R'-domain words (a table record in HBM) -> limbs; no arithmetic
 template <class FP>
+APK_HD Affine<FP, FeU<FP>> unpack_affine(const Affine<FP>& rec) {
+    return Affine<FP, FeU<FP>>{FeU<FP>::unpack(rec.x.l), FeU<FP>::unpack(rec.y.l)};
+}
+// gnark-layout affine point -> packed R'-domain record (two domain-conversion products)
+template <class FP>
+APK_HD Affine<FP> to_table_record(const Affine<FP>& p) {
+    Affine<FP> rec;
+    FeU<FP>::from_fe(p.x).pack(rec.x.l);
+    FeU<FP>::from_fe(p.y).pack(rec.y.l);
+    return rec;
+}
+
+template <class FP, class FT = Fe<FP>>
 struct XYZZ {
-    using F = Fe<FP>;
+    using F = FT;
+    using Aff = Affine<FP, FT>;
     F X, Y, ZZ, ZZZ;
 
     APK_HD bool is_inf() const { return ZZ.is_zero(); }
     APK_HD static XYZZ inf() { return XYZZ{F::one(), F::one(), F::zero(), F::zero()}; }
-    APK_HD static XYZZ from_affine(const Affine<FP>& p) {
+    APK_HD static XYZZ from_affine(const Aff& p) {
         if (p.is_inf()) return inf();
         return XYZZ{p.x, p.y, F::one(), F::one()};
     }
     APK_HD void neg_inplace() { Y = F::neg(Y); }
 
     // 2 * (affine p)
-    APK_HD static XYZZ dbl_affine(const Affine<FP>& p) {
+    APK_HD static XYZZ dbl_affine(const Aff& p) {
         if (p.is_inf() || p.y.is_zero()) return inf();
         F U = F::dbl(p.y);
         F V = F::sqr(U);
@@ -63,9 +81,9 @@ struct XYZZ {
     }
 
     // this += q (affine).  `negate` flips q's sign (signed-digit buckets).
-    APK_HD void madd(const Affine<FP>& q_in, bool negate = false) {
+    APK_HD void madd(const Aff& q_in, bool negate = false) {
         if (q_in.is_inf()) return;
-        Affine<FP> q = q_in;
+        Aff q = q_in;
         if (negate) q.y = F::neg(q.y);
         if (is_inf()) {
             X = q.x; Y = q.y; ZZ = F::one(); ZZZ = F::one();
@@ -117,11 +135,18 @@ struct XYZZ {
         ZZZ = (ZZZ * q.ZZZ) * PPP;
     }
 
-    APK_HD Affine<FP> to_affine() const {
-        if (is_inf()) return Affine<FP>::inf();
+    // only for FT = Fe<FP> (needs a field inversion)
+    APK_HD Aff to_affine() const {
+        if (is_inf()) return Aff::inf();
         // 1/ZZZ gives both: 1/ZZ = ZZZ^-1 * ZZZ / ZZ ... simpler: two field ops from one inversion
         F zzz_inv = F::inv(ZZZ);
         F zz_inv = F::sqr(zzz_inv * ZZ);  // (ZZ/ZZZ)^2 = 1/Z^2 = 1/ZZ
-        return Affine<FP>{X * zz_inv, Y * zzz_inv};
+        return Aff{X * zz_inv, Y * zzz_inv};
     }
 };
+
+// MSM-internal point (unsaturated limbs, radix R') -> gnark-radix XYZZ: four domain-conversion products
+template <class FP>
+APK_HD XYZZ<FP> to_fe_point(const XYZZ<FP, FeU<FP>>& p) {
+    return XYZZ<FP>{p.X.to_fe(), p.Y.to_fe(), p.ZZ.to_fe(), p.ZZZ.to_fe()};
+}

@@ -22,7 +22,7 @@
 namespace apk {
 
 constexpr int MSM_MAX_BATCH = 4;
-constexpr int MSM_UNIT = 16;        // entries per accumulation work unit
+constexpr int MSM_UNIT = 16;        // entries per accumulation work unit (8 and 32 measured within 5 % on throughput)
 constexpr int MSM_COMBINE_LANES = 16;
 constexpr int MSM_RED_THREADS = 256;
 constexpr int MSM_RED_MAXCHUNK = 8;
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const Affine<FP>* _
                                                              const uint32_t* __restrict__ offsets,
                                                              const uint32_t* __restrict__ unit_off,
                                                              uint32_t total_buckets, uint32_t max_units,
-                                                             XYZZ<FP>* __restrict__ partial) {
+                                                             XYZZ<FP, FeU<FP>>* __restrict__ partial) {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= max_units) return;
     const uint32_t total_units = unit_off[total_buckets];
@@ -175,48 +175,48 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const Affine<FP>* _
     const uint32_t slice = u - unit_off[k];
     const uint32_t beg = offsets[k] + slice * MSM_UNIT;
     const uint32_t end = min(beg + MSM_UNIT, offsets[k + 1]);
-    XYZZ<FP> acc = XYZZ<FP>::inf();
+    // table records are packed R'-domain words: unpack to unsaturated limbs, accumulate carry-free (ffu.h)
+    XYZZ<FP, FeU<FP>> acc = XYZZ<FP, FeU<FP>>::inf();
     for (uint32_t e = beg; e < end; e++) {
         uint32_t v = sorted[e];
-        Affine<FP> p = table[v & 0x7fffffffu];
-        acc.madd(p, (v >> 31) != 0);
+        Affine<FP> rec = table[v & 0x7fffffffu];
+        acc.madd(unpack_affine<FP>(rec), (v >> 31) != 0);
     }
     partial[u] = acc;
 }
 
-template <class FP>
-__device__ __forceinline__ XYZZ<FP> shfl_down_point(const XYZZ<FP>& p, int delta, int width) {
-    XYZZ<FP> r;
-    constexpr int N = Fe<FP>::N;
+template <class PT>
+__device__ __forceinline__ PT shfl_down_point(const PT& p, int delta, int width) {
+    PT r;
+    constexpr int NW = sizeof(PT) / 4;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&p);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&r);
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-        r.X.l[i] = __shfl_down(p.X.l[i], delta, width);
-        r.Y.l[i] = __shfl_down(p.Y.l[i], delta, width);
-        r.ZZ.l[i] = __shfl_down(p.ZZ.l[i], delta, width);
-        r.ZZZ.l[i] = __shfl_down(p.ZZZ.l[i], delta, width);
-    }
+    for (int i = 0; i < NW; i++) dst[i] = __shfl_down(src[i], delta, width);
     return r;
 }
 
 // merge a bucket's unit partials: MSM_COMBINE_LANES lanes per bucket, strided sums + shuffle tree
 template <class FP>
-__global__ void __launch_bounds__(256) msm_combine_kernel(const XYZZ<FP>* __restrict__ partial,
+__global__ void __launch_bounds__(256) msm_combine_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ partial,
                                                           const uint32_t* __restrict__ unit_off, uint32_t total_buckets,
-                                                          XYZZ<FP>* __restrict__ bucket_sum) {
+                                                          int lanes_log,  // lanes per bucket = 2^lanes_log <= MSM_COMBINE_LANES
+                                                          XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum) {
+    using PT = XYZZ<FP, FeU<FP>>;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t k = gid / MSM_COMBINE_LANES;
-    const uint32_t lane = gid % MSM_COMBINE_LANES;
-    XYZZ<FP> acc = XYZZ<FP>::inf();
+    const uint32_t LANES = 1u << lanes_log;
+    const uint32_t k = gid >> lanes_log;
+    const uint32_t lane = gid & (LANES - 1);
+    PT acc = PT::inf();
     uint32_t beg = 0, end = 0;
     if (k < total_buckets) { beg = unit_off[k]; end = unit_off[k + 1]; }
-    for (uint32_t u = beg + lane; u < end; u += MSM_COMBINE_LANES) acc.add(partial[u]);
+    for (uint32_t u = beg + lane; u < end; u += LANES) acc.add(partial[u]);
     // all lanes of the wave take part in every shuffle; groups with nothing to add see infinities
     const uint32_t n_units = end - beg;
     uint64_t need = __ballot(n_units > 1);
     if (need) {
-#pragma unroll
-        for (int d = MSM_COMBINE_LANES / 2; d >= 1; d >>= 1) {
-            XYZZ<FP> o = shfl_down_point(acc, d, MSM_COMBINE_LANES);
+        for (int d = (int)LANES / 2; d >= 1; d >>= 1) {
+            PT o = shfl_down_point<PT>(acc, d, (int)LANES);
             if (lane < (uint32_t)d && n_units > (uint32_t)d) acc.add(o);
         }
     }
@@ -226,16 +226,17 @@ __global__ void __launch_bounds__(256) msm_combine_kernel(const XYZZ<FP>* __rest
 // ---- weighted bucket reduction, bit-wise --------------------------------------------------------------
 // grid (chunk, bit, msm): S[msm][bit][chunk] = sum of B_k (k = idx+1) with bit `bit` of k set, idx in chunk
 template <class FP>
-__global__ void __launch_bounds__(MSM_RED_THREADS) msm_bitsum_kernel(const XYZZ<FP>* __restrict__ bucket_sum, uint32_t nb,
+__global__ void __launch_bounds__(MSM_RED_THREADS) msm_bitsum_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum, uint32_t nb,
                                                                      uint32_t nchunk, uint32_t nbits,
-                                                                     XYZZ<FP>* __restrict__ bit_partial) {
+                                                                     XYZZ<FP, FeU<FP>>* __restrict__ bit_partial) {
+    using PT = XYZZ<FP, FeU<FP>>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    XYZZ<FP>* sm = reinterpret_cast<XYZZ<FP>*>(smem_raw);
+    PT* sm = reinterpret_cast<PT*>(smem_raw);
     const uint32_t chunk = blockIdx.x, bit = blockIdx.y, m = blockIdx.z;
     const uint32_t t = threadIdx.x;
     const uint32_t per = nb / nchunk;
     const uint32_t lo = chunk * per, hi = lo + per;
-    XYZZ<FP> acc = XYZZ<FP>::inf();
+    PT acc = PT::inf();
     for (uint32_t idx = lo + t; idx < hi; idx += MSM_RED_THREADS) {
         if (((idx + 1) >> bit) & 1u) acc.add(bucket_sum[m * nb + idx]);
     }
@@ -243,7 +244,7 @@ __global__ void __launch_bounds__(MSM_RED_THREADS) msm_bitsum_kernel(const XYZZ<
     __syncthreads();
     for (uint32_t d = MSM_RED_THREADS / 2; d >= 1; d >>= 1) {
         if (t < d) {
-            XYZZ<FP> o = sm[t + d];
+            PT o = sm[t + d];
             acc.add(o);
             sm[t] = acc;
         }
@@ -254,55 +255,57 @@ __global__ void __launch_bounds__(MSM_RED_THREADS) msm_bitsum_kernel(const XYZZ<
 
 // one workgroup per msm: sum chunks per bit, scale by 2^bit, sum over bits, convert to affine
 template <class FP>
-__global__ void __launch_bounds__(256) msm_final_kernel(const XYZZ<FP>* __restrict__ bit_partial, uint32_t nchunk,
+__global__ void __launch_bounds__(256) msm_final_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ bit_partial, uint32_t nchunk,
                                                         uint32_t nbits, Affine<FP>* __restrict__ result,
                                                         XYZZ<FP>* __restrict__ result_xyzz) {
-    __shared__ XYZZ<FP> sm[256];
+    using PT = XYZZ<FP, FeU<FP>>;
+    __shared__ PT sm[256];
     const uint32_t m = blockIdx.x;
     const uint32_t t = threadIdx.x;
     const uint32_t bit = t / MSM_RED_MAXCHUNK, chunk = t % MSM_RED_MAXCHUNK;
-    XYZZ<FP> acc = XYZZ<FP>::inf();
+    PT acc = PT::inf();
     if (bit < nbits)
         for (uint32_t ch = chunk; ch < nchunk; ch += MSM_RED_MAXCHUNK) acc.add(bit_partial[(m * nbits + bit) * nchunk + ch]);
     sm[t] = acc;
     __syncthreads();
     for (uint32_t d = MSM_RED_MAXCHUNK / 2; d >= 1; d >>= 1) {
-        if (chunk < d) { XYZZ<FP> o = sm[t + d]; acc.add(o); sm[t] = acc; }
+        if (chunk < d) { PT o = sm[t + d]; acc.add(o); sm[t] = acc; }
         __syncthreads();
     }
     if (chunk == 0) {
-        for (uint32_t i = 0; i < bit && i < nbits; i++) acc = XYZZ<FP>::dbl(acc);
+        for (uint32_t i = 0; i < bit && i < nbits; i++) acc = PT::dbl(acc);
         sm[t] = acc;
     }
     __syncthreads();
     // tree over bits: entries at t = bit*MAXCHUNK
     for (uint32_t d = 16; d >= 1; d >>= 1) {
         if (chunk == 0 && bit < d && bit + d < 32) {
-            XYZZ<FP> o = sm[(bit + d) * MSM_RED_MAXCHUNK];
+            PT o = sm[(bit + d) * MSM_RED_MAXCHUNK];
             acc.add(o);
             sm[t] = acc;
         }
         __syncthreads();
     }
     if (t == 0) {
-        if (result_xyzz) result_xyzz[m] = acc;
-        result[m] = acc.to_affine();
+        XYZZ<FP> g = to_fe_point<FP>(acc);  // back to gnark's Montgomery radix
+        if (result_xyzz) result_xyzz[m] = g;
+        result[m] = g.to_affine();
     }
 }
 
-// ---- table construction: table[j*n + i] = 2^(off[j]) * P_i (affine) ----------------------------------------
+// ---- table construction: table[j*n + i] = 2^(off[j]) * P_i (affine), stored as packed R'-domain records (ffu.h) ----------------------------------------
 template <class FP>
 __global__ void __launch_bounds__(256) msm_table_kernel(const Affine<FP>* __restrict__ bases, uint32_t n, MsmWindows win,
                                                         Affine<FP>* __restrict__ table) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Affine<FP> p = bases[i];
-    table[i] = p;
+    table[i] = to_table_record<FP>(p);
     for (int j = 1; j < win.W; j++) {
         XYZZ<FP> q = XYZZ<FP>::dbl_affine(p);
         for (int k = 1; k < win.width[j - 1]; k++) q = XYZZ<FP>::dbl(q);
         p = q.to_affine();
-        table[(size_t)j * n + i] = p;
+        table[(size_t)j * n + i] = to_table_record<FP>(p);
     }
 }
 

@@ -22,19 +22,26 @@ constexpr int NTT_THREADS = 256;
 
 __device__ __forceinline__ uint32_t bitrev32(uint32_t x, int bits) { return __brev(x) >> (32 - bits); }
 
+// up to NTT_MAX_BATCH same-size transforms per launch (blockIdx.y): the three wire polynomials share launches,
+// which triples the workgroup count of these latency-bound small transforms
+constexpr int NTT_MAX_BATCH = 4;
+struct NttBatch {
+    const void* in[NTT_MAX_BATCH];
+    void* out[NTT_MAX_BATCH];
+    uint32_t in_len[NTT_MAX_BATCH];  // elements >= in_len read as zero (first pass only)
+};
+
 struct NttPassArgs {
     int log_n;
     int tile_log;        // log2(elements per workgroup tile)
     int t0, t1;          // stages [t0, t1)
-    uint32_t in_len;     // elements >= in_len read as zero (first pass only)
     int first, last;     // first pass gathers bit-reversed + pre-multiplies; last pass post-multiplies
     uint32_t out_len;    // last pass: elements >= out_len are not written
 };
 
 // tw[j] = w^j for j < N/2 (w = omega or omega^-1), Montgomery form
 template <class FR>
-__global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fe<FR>* __restrict__ in, Fe<FR>* __restrict__ out,
-                                                               const Fe<FR>* __restrict__ tw,
+__global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, const Fe<FR>* __restrict__ tw,
                                                                const Fe<FR>* __restrict__ pre,   // or null
                                                                const Fe<FR>* __restrict__ post,  // or null
                                                                const Fe<FR>* __restrict__ scale, // or null: one element
@@ -42,6 +49,9 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fe<FR>* __r
     using Fr = Fe<FR>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Fr* sm = reinterpret_cast<Fr*>(smem_raw);
+    Fr* __restrict__ out = reinterpret_cast<Fr*>(nb.out[blockIdx.y]);
+    const Fr* __restrict__ in = a.first ? reinterpret_cast<const Fr*>(nb.in[blockIdx.y]) : out;
+    const uint32_t in_len = nb.in_len[blockIdx.y];
     const int s = a.t1 - a.t0;
     const int tile_log = a.tile_log;
     const int clog = tile_log - s;  // log2(groups per tile)
@@ -58,7 +68,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fe<FR>* __r
         Fr v;
         if (a.first) {
             uint32_t src = bitrev32(idx, a.log_n);
-            if (src < a.in_len) {
+            if (src < in_len) {
                 v = in[src];
                 if (pre) v = v * pre[src];
             } else {
@@ -107,14 +117,23 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(const Fe<FR>* __r
 }
 
 // tw[j] = w^j, j < count: each thread exponentiates its block start then walks
+constexpr int POWERS_MAX_BATCH = 4;
 template <class FR>
-__global__ void __launch_bounds__(256) powers_kernel(Fe<FR>* __restrict__ out, uint32_t count, Fe<FR> w, Fe<FR> scale) {
+struct PowersBatch {
+    Fe<FR>* out[POWERS_MAX_BATCH];
+    Fe<FR> w[POWERS_MAX_BATCH];
+    Fe<FR> scale[POWERS_MAX_BATCH];
+};
+template <class FR>
+__global__ void __launch_bounds__(256) powers_kernel(PowersBatch<FR> pb, uint32_t count) {
     using Fr = Fe<FR>;
-    constexpr uint32_t PER = 16;
+    constexpr uint32_t PER = 8;
+    Fr* __restrict__ out = pb.out[blockIdx.y];
+    const Fr w = pb.w[blockIdx.y];
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t start = t * PER;
     if (start >= count) return;
-    Fr cur = Fr::pow_u64(w, start) * scale;
+    Fr cur = Fr::pow_u64(w, start) * pb.scale[blockIdx.y];
     for (uint32_t k = 0; k < PER && start + k < count; k++) {
         out[start + k] = cur;
         cur = cur * w;
