@@ -23,7 +23,7 @@ NB_BLINDING = 9
 SYMBOLS = [
     "apk_last_error", "apk_abi_version", "apk_device_count", "apk_g1_bytes", "apk_fp_bytes",
     "apk_ctx_create", "apk_ctx_destroy", "apk_msm_ctx_create", "apk_ctx_get_vk", "apk_msm_g1", "apk_msm_g1_device", "apk_ntt",
-    "apk_prove", "apk_prove_device", "apk_g1_mul_batch", "apk_marshal_proof", "apk_marshal_public_inputs",
+    "apk_prove", "apk_prove_device", "apk_g1_mul_batch", "apk_g1_decompress", "apk_g1_to_lagrange", "apk_marshal_proof", "apk_marshal_public_inputs",
     "apk_fe_from_be", "apk_fe_to_be", "apk_hash_fr", "apk_host_fe_op", "apk_host_g1_op",
     "apk_device_alloc", "apk_device_free", "apk_device_upload", "apk_device_download",
     "apk_stats_enable", "apk_stats_read",
@@ -96,6 +96,8 @@ def _load() -> C.CDLL:
     lib.apk_prove.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(Proof)]
     lib.apk_prove_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(Proof)]
     lib.apk_g1_mul_batch.argtypes = [i32, i32, vp, vp, u64, vp]
+    lib.apk_g1_decompress.argtypes = [i32, i32, vp, u64, vp]
+    lib.apk_g1_to_lagrange.argtypes = [i32, i32, vp, u64, vp]
     lib.apk_marshal_proof.argtypes = [C.POINTER(Proof), vp, sz, C.POINTER(sz)]
     lib.apk_marshal_public_inputs.argtypes = [i32, vp, C.c_uint32, vp, sz]
     lib.apk_fe_from_be.argtypes = [i32, i32, vp, vp]

@@ -97,7 +97,7 @@ def Run(ccs: frontend.ConstraintSystem, setupConfig, device: int = 0, seed: Opti
             tau += 2
         srs = setup.unsafe_srs(info.Curve, n, tau, device=device, lagrange=bool(ccs.commitments))
     else:
-        srs = setup.trusted_srs(info, n)
+        srs = setup.trusted_srs(info, n, device=device, lagrange=bool(ccs.commitments))
     return plonk.Setup(ccs, srs, device=device, msm_window=msm_window, slots=slots)
 
 

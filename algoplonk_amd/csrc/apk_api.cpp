@@ -276,6 +276,24 @@ int apk_g1_mul_batch(int curve, int device, const void* base, const void* scalar
     return APK_ERR_ARG;
 }
 
+int apk_g1_decompress(int curve, int device, const uint8_t* compressed, uint64_t count, void* out) {
+    if (!compressed || !out) { set_error("null argument"); return APK_ERR_ARG; }
+    if (count == 0) return APK_OK;
+    if (count >= (1ull << 31)) { set_error("count too large"); return APK_ERR_ARG; }
+    if (curve == APK_BN254) return g1_decompress_bn254(device, compressed, count, out);
+    if (curve == APK_BLS12_381) return g1_decompress_bls12381(device, compressed, count, out);
+    set_error("unsupported curve: %d", curve);
+    return APK_ERR_ARG;
+}
+
+int apk_g1_to_lagrange(int curve, int device, const void* points, uint64_t n, void* out) {
+    if (!points || !out) { set_error("null argument"); return APK_ERR_ARG; }
+    if (curve == APK_BN254) return g1_to_lagrange_bn254(device, points, n, out);
+    if (curve == APK_BLS12_381) return g1_to_lagrange_bls12381(device, points, n, out);
+    set_error("unsupported curve: %d", curve);
+    return APK_ERR_ARG;
+}
+
 int apk_host_fe_op(int curve, int field, int op, const void* a, const void* b, void* out) {
     if (!a || !out) { set_error("null argument"); return APK_ERR_ARG; }
     if (curve == APK_BN254) return field ? fe_op_t<FpBN254>(op, a, b, out) : fe_op_t<FrBN254>(op, a, b, out);

@@ -30,6 +30,10 @@ struct Backend {
 
 int g1_mul_batch_bn254(int device, const void* base, const void* scalars, uint64_t count, void* out);
 int g1_mul_batch_bls12381(int device, const void* base, const void* scalars, uint64_t count, void* out);
+int g1_decompress_bn254(int device, const uint8_t* in, uint64_t count, void* out);
+int g1_decompress_bls12381(int device, const uint8_t* in, uint64_t count, void* out);
+int g1_to_lagrange_bn254(int device, const void* points, uint64_t n, void* out);
+int g1_to_lagrange_bls12381(int device, const void* points, uint64_t n, void* out);
 Backend* make_backend_bn254();
 Backend* make_backend_bls12381();
 

@@ -21,6 +21,7 @@
 #include "kernels_msm.h"
 #include "kernels_ntt.h"
 #include "kernels_poly.h"
+#include "kernels_setup.h"
 #include "sha256.h"
 
 namespace apk {
@@ -1055,6 +1056,76 @@ int g1_mul_batch_impl(int device, const void* base, const void* scalars, uint64_
     g1_mul_batch_kernel<FRP, FPP><<<cdiv(count, 256), 256>>>(b, ptr<Fr>(ds), (uint32_t)count, ptr<Aff>(dout));
     KCHK();
     HIPCHK(hipMemcpy(out, dout.p, count * sizeof(Aff), hipMemcpyDeviceToHost));
+    return APK_OK;
+}
+
+// ---- setup-time entry points (host buffers in / out) ----------------------------------------------------------------
+static inline int pick_device(int device) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) { set_error("no HIP device available; libapk has no CPU fallback"); return APK_ERR_HIP; }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range", device); return APK_ERR_ARG; }
+    HIPCHK(hipSetDevice(device));
+    return APK_OK;
+}
+
+template <class FPP, int CURVE_ID>
+int g1_decompress_impl(int device, const uint8_t* in, uint64_t count, void* out) {
+    using Aff = Affine<FPP>;
+    CHK(pick_device(device));
+    const size_t nb = (size_t)FPP::N * 4;
+    DevBuf din, dout, derr;
+    CHK(din.alloc(count * nb));
+    CHK(dout.alloc(count * sizeof(Aff)));
+    CHK(derr.alloc(4));
+    HIPCHK(hipMemcpy(din.p, in, count * nb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(derr.p, 0, 4));
+    g1_decompress_kernel<FPP, CURVE_ID><<<cdiv(count, 256), 256>>>(ptr<uint8_t>(din), (uint32_t)count, ptr<Aff>(dout), ptr<uint32_t>(derr));
+    KCHK();
+    uint32_t bad = 0;
+    HIPCHK(hipMemcpy(&bad, derr.p, 4, hipMemcpyDeviceToHost));
+    if (bad) { set_error("%u compressed point(s) are not valid G1 encodings", bad); return APK_ERR_ARG; }
+    HIPCHK(hipMemcpy(out, dout.p, count * sizeof(Aff), hipMemcpyDeviceToHost));
+    return APK_OK;
+}
+
+template <class FRP, class FPP>
+int g1_to_lagrange_impl(int device, const void* points, uint64_t n, void* out) {
+    using Fr = Fe<FRP>;
+    using Aff = Affine<FPP>;
+    using Pt = XYZZ<FPP>;
+    if (n < 2 || (n & (n - 1)) || n > (1ull << 24)) { set_error("ToLagrangeG1: size must be a power of two in [2, 2^24]"); return APK_ERR_ARG; }
+    CHK(pick_device(device));
+    int log_n = 0;
+    while ((1ull << log_n) < n) log_n++;
+    // omega^-1 of the size-n domain, 1/n
+    Fr root;
+    for (int i = 0; i < Fr::N; i++) root.l[i] = FRP::root(i);
+    Fr w = Fr::to_mont(root);
+    for (int i = 0; i < FRP::ADICITY - log_n; i++) w = Fr::sqr(w);
+    Fr winv = Fr::inv(w);
+    Fr nn = Fr::zero();
+    nn.l[0] = (uint32_t)n;
+    Fr ninv = Fr::inv(Fr::to_mont(nn));
+    DevBuf din, dout, work, twi;
+    CHK(din.alloc(n * sizeof(Aff)));
+    CHK(dout.alloc(n * sizeof(Aff)));
+    CHK(work.alloc(n * sizeof(Pt)));
+    CHK(twi.alloc((n / 2 + 1) * sizeof(Fr)));
+    HIPCHK(hipMemcpy(din.p, points, n * sizeof(Aff), hipMemcpyHostToDevice));
+    PowersBatch<FRP> pb{};
+    pb.out[0] = ptr<Fr>(twi); pb.w[0] = winv; pb.scale[0] = Fr::one();
+    powers_kernel<FRP><<<dim3(cdiv(cdiv(n / 2, 8), 256), 1), 256>>>(pb, (uint32_t)(n / 2));
+    KCHK();
+    lagrange_load_kernel<FPP><<<cdiv(n, 256), 256>>>(ptr<Aff>(din), (uint32_t)n, log_n, ptr<Pt>(work));
+    KCHK();
+    for (int t = 0; t < log_n; t++) {
+        lagrange_stage_kernel<FRP, FPP><<<cdiv(n / 2, 128), 128>>>(ptr<Pt>(work), ptr<Fr>(twi), (uint32_t)n, log_n, t);
+        KCHK();
+    }
+    lagrange_finish_kernel<FRP, FPP><<<cdiv(n, 128), 128>>>(ptr<Pt>(work), (uint32_t)n, ninv, ptr<Aff>(dout));
+    KCHK();
+    HIPCHK(hipMemcpy(out, dout.p, n * sizeof(Aff), hipMemcpyDeviceToHost));
     return APK_OK;
 }
 

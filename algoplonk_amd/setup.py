@@ -166,11 +166,29 @@ def load_trusted_setup_bytes(dirpath: str, g1_count: int, g1_compressed_size: in
     return g1_count.to_bytes(4, "big") + g1[4:needed], vk
 
 
-def trusted_srs(setup: Setup, n: int) -> SRS:
-    root = os.environ.get("APK_TRUSTED_SETUP_DIR")
+def decompress_g1_batch(curve: ecc.ID, compressed: bytes, device: int = 0) -> bytes:
+    """kzg SRS ReadFrom on the GPU (apk_g1_decompress): compressed points -> gnark in-memory affine bytes."""
+    count = len(compressed) // curve.fp_bytes
+    out = C.create_string_buffer(count * 2 * curve.fp_bytes)
+    check(lib.apk_g1_decompress(curve.abi, device, compressed, count, out))
+    return out.raw
+
+
+def to_lagrange_g1(curve: ecc.ID, points: bytes, device: int = 0) -> bytes:
+    """kzg.ToLagrangeG1 on the GPU (apk_g1_to_lagrange): [tau^j]G1, j < n  ->  [L_i(tau)]G1."""
+    n = len(points) // (2 * curve.fp_bytes)
+    out = C.create_string_buffer(len(points))
+    check(lib.apk_g1_to_lagrange(curve.abi, device, points, n, out))
+    return out.raw
+
+
+def trusted_srs(setup: Setup, n: int, device: int = 0, lagrange: bool = False, root: Optional[str] = None) -> SRS:
+    """trustedSetupBLS12381 / trustedSetupBN254 + the ToLagrangeG1 step of setup.Run (setup/setup.go:110-143)."""
+    root = root or os.environ.get("APK_TRUSTED_SETUP_DIR")
     if not root:
         raise FileNotFoundError("trusted setup files are not bundled: set APK_TRUSTED_SETUP_DIR")
     cv = setup.Curve
     g1b, _vk = load_trusted_setup_bytes(os.path.join(root, setup.NamePath), n + 3, cv.fp_bytes)
-    pts = [decompress_g1(cv, g1b[4 + i * cv.fp_bytes: 4 + (i + 1) * cv.fp_bytes]) for i in range(n + 3)]
-    return SRS(cv, n, cv.g1_vector(pts), None, None)
+    g1 = decompress_g1_batch(cv, g1b[4:], device)
+    lag = to_lagrange_g1(cv, g1[: n * 2 * cv.fp_bytes], device) if lagrange else None   # G1[:len-3] (setup.go:124,138)
+    return SRS(cv, n, g1, lag, None)

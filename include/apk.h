@@ -141,6 +141,15 @@ int apk_prove_device(apk_ctx* ctx, const void* d_L, const void* d_R, const void*
  * tau^i (canonical SRS) or L_i(tau) (Lagrange SRS) as the scalars. */
 int apk_g1_mul_batch(int curve, int device, const void* base, const void* scalars, uint64_t count, void* out);
 
+/* ---- trusted-setup loading on the GPU: what setup.Run's trusted branch does before plonk.Setup ----
+ * apk_g1_decompress : kzg SRS ReadFrom (setup/setup.go:173-174,189-190).  `compressed` = count x (32 | 48) bytes exactly as
+ *                     they sit in pk.bin after the 4-byte count (big-endian X with gnark's flag bits);
+ *                     out = count G1 affine in gnark's in-memory form.  APK_ERR_ARG if any encoding is not a curve point.
+ * apk_g1_to_lagrange: kzg.ToLagrangeG1 (setup/setup.go:124,138): out[i] = [L_i(tau)]G1 from points[j] = [tau^j]G1, n a
+ *                     power of two, without knowing tau (inverse FFT in the exponent).  Host buffers. */
+int apk_g1_decompress(int curve, int device, const uint8_t* compressed, uint64_t count, void* out);
+int apk_g1_to_lagrange(int curve, int device, const void* points, uint64_t n, void* out);
+
 /* ---- wire formats (host only, no GPU needed): replace MarshalProof / MarshalPublicInputs ----------------- */
 /* helper.go:13-24,27-88: 768 + 96k bytes (BN254) / 1056 + 128k bytes (BLS12-381).  Returns the length in *len. */
 int apk_marshal_proof(const apk_proof* proof, uint8_t* out, size_t cap, size_t* len);

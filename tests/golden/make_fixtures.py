@@ -73,4 +73,17 @@ def proof_vectors():
 
 if __name__ == "__main__":
     trusted_setup_fixtures()
+    ethereum_srs_prefix()
     proof_vectors()
+
+
+def ethereum_srs_prefix():
+    """First 2^14 + 3 points of the Ethereum KZG ceremony pk.bin (what setup.Run loads for a 2^14 circuit,
+    setup/setup.go:113-114,196-228) + its vk.bin, laid out like the reference's setup/<NamePath>/ directory."""
+    d = os.path.join(HERE, "setup", "EethereumKzgCeremonyBLS12_381")
+    os.makedirs(d, exist_ok=True)
+    src = os.path.join(REF, "setup", "EethereumKzgCeremonyBLS12_381")
+    with open(os.path.join(src, "pk.bin"), "rb") as f, open(os.path.join(d, "pk.bin"), "wb") as o:
+        o.write(f.read(4 + 16387 * 48))
+    with open(os.path.join(src, "vk.bin"), "rb") as f, open(os.path.join(d, "vk.bin"), "wb") as o:
+        o.write(f.read())

@@ -1,0 +1,119 @@
+"""-m gpu: the setup-time GPU work of SURVEY.md §8f.1 (row a12) - SRS decompression, ToLagrangeG1, and BASELINE.json
+configs[2]: a BLS12-381 2^14 circuit proved under the REAL Ethereum KZG ceremony SRS (no tau known to anyone)."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import pytest
+
+from algoplonk_amd import _lib, ecc, frontend, plonk as ap_plonk, setup as ap_setup, workloads
+from algoplonk_amd import MarshalProof, MarshalPublicInputs
+from algoplonk_amd._lib import lib, check
+from oracle import c_oracle, plonk as oplonk
+from oracle.prng import SplitMix64, tau_from_seed
+
+from helpers import CURVES
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+KAT = json.load(open(os.path.join(G, "trusted_setup_kat.json")))
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12-381"])
+def test_decompress_matches_oracle_and_rejects_bad_points(gpu, cname):
+    cv, ov = CURVES[cname]
+    g = SplitMix64(3)
+    pts = [ov.mul(ov.g1, g.fr(cv.r)) for _ in range(40)] + [None, ov.g1, ov.neg(ov.g1)]
+    comp = b"".join(ov.compress(P) for P in pts)
+    got = cv.g1_vector_decode(ap_setup.decompress_g1_batch(cv, comp, gpu))
+    assert got == pts
+    # an x that is not on the curve, and a missing compression flag
+    x = 5
+    while oplonk_sqrt(ov, x) is not None:
+        x += 1
+    bad = bytearray(x.to_bytes(cv.fp_bytes, "big")); bad[0] |= 0x80
+    with pytest.raises(_lib.ApkError, match="not valid G1"):
+        ap_setup.decompress_g1_batch(cv, bytes(bad), gpu)
+    with pytest.raises(_lib.ApkError):
+        ap_setup.decompress_g1_batch(cv, ov.g1[0].to_bytes(cv.fp_bytes, "big"), gpu)   # flags 00
+
+
+def oplonk_sqrt(ov, x):
+    from oracle.curves import sqrt_mod
+    return sqrt_mod((x * x * x + ov.b) % ov.p, ov.p)
+
+
+def test_decompress_reference_known_answers(gpu):
+    """setup/trusted_setup_test.go:172-288 through the GPU path."""
+    cv, ov = CURVES["bls12-381"]
+    head = open(os.path.join(G, "EethereumKzgCeremonyBLS12_381.pk.head.bin"), "rb").read()[4:]
+    pts = cv.g1_vector_decode(ap_setup.decompress_g1_batch(cv, head, gpu))
+    assert pts[0] == ov.g1
+    for P, h in zip(pts, KAT["ethereum_g1_first5"]):
+        assert ov.compress(P).hex() == h and P[0] == int(h, 16) & ((1 << 381) - 1)
+    dusk = b"".join(bytes.fromhex(h) for h in KAT["dusk_g1_first5"] + [KAT["dusk_g1_32767"]])
+    for P, h in zip(cv.g1_vector_decode(ap_setup.decompress_g1_batch(cv, dusk, gpu)), KAT["dusk_g1_first5"] + [KAT["dusk_g1_32767"]]):
+        assert ov.is_on_curve(P) and ov.compress(P).hex() == h
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12-381"])
+@pytest.mark.parametrize("log_n", [1, 3, 7])
+def test_to_lagrange_matches_known_tau(gpu, cname, log_n):
+    """kzg.ToLagrangeG1: out[i] = [L_i(tau)]G1.  With a synthetic SRS the right answer is computable from tau."""
+    cv, ov = CURVES[cname]
+    n = 1 << log_n
+    tau = tau_from_seed(9, cv.r)
+    srs = ap_setup.unsafe_srs(cv, max(n, 8), tau, device=gpu)
+    pts = srs.g1[: n * 2 * cv.fp_bytes]
+    lag = cv.g1_vector_decode(ap_setup.to_lagrange_g1(cv, pts, gpu))
+    w = ov.omega(n)
+    zn = (pow(tau, n, cv.r) - 1) * pow(n, -1, cv.r) % cv.r
+    for i in (0, 1, n // 2, n - 1):
+        wi = pow(w, i, cv.r)
+        assert lag[i] == ov.mul(ov.g1, wi * zn % cv.r * pow(tau - wi, -1, cv.r) % cv.r)
+
+
+def test_real_ethereum_srs_2p14_matches_c_oracle(gpu):
+    """BASELINE.json configs[2]: BLS12-381 random circuit, 2^14 constraints, Ethereum KZG ceremony SRS (the first
+    2^14+3 points of the reference's pk.bin, tests/golden/setup/).  Nobody knows tau, so the checks are:
+    (1) byte-identical proof to the C oracle run on the same decompressed SRS; (2) the Lagrange SRS produced by the
+    GPU ToLagrangeG1 commits an evaluation vector to the same point as the canonical SRS commits its coefficients."""
+    cv, ov = CURVES["bls12-381"]
+    info, ok = ap_setup.Get(ap_setup.Name.EthereumKzgCeremonyBLS12381)
+    assert ok and info.Trusted
+    wl = workloads.random_circuit(cv, 14, 0xA191)
+    n = wl.ccs.domain_size()
+    srs = ap_setup.trusted_srs(info, n, device=gpu, lagrange=True, root=os.path.join(G, "setup"))
+    assert srs.tau is None and len(srs.g1) == (n + 3) * 96 and len(srs.g1_lagrange) == n * 96
+    assert cv.g1_from_bytes(srs.g1[:96]) == ov.g1
+    pk, vk = ap_plonk.Setup(wl.ccs, srs, device=gpu)
+    proof = ap_plonk.Prove(wl.ccs, pk, wl.witness, wl.blinding)
+    blob = MarshalProof(proof)
+    # (1) C oracle on the same SRS
+    clib = c_oracle.load()
+    tr = frontend.build_trace(wl.ccs)
+    L, R, O = frontend.wire_columns(wl.ccs, wl.solution)
+    rc, cblob, _ = c_oracle.prove(clib, cv.abi, n, wl.ccs.GetNbPublicVariables(), srs.g1,
+                                  [cv.fr_vector(x) for x in (tr.ql, tr.qr, tr.qm, tr.qo, tr.qk)], tr.perm, cv.fr_vector(L),
+                                  cv.fr_vector(R), cv.fr_vector(O), cv.fr_vector(wl.witness.public), cv.fr_vector(wl.blinding),
+                                  threads=os.cpu_count() or 1)
+    assert rc == 0 and blob == cblob
+    # (2) Lagrange vs canonical commitment of the same polynomial, on a context that holds both SRS
+    g = SplitMix64(2)
+    coeffs = [g.fr(cv.r) for _ in range(n)]
+    evals = pk.ntt(coeffs)
+    pk.close()
+    d = _lib.CircuitDesc()
+    # a context with the Lagrange SRS needs a circuit with a commitment; reuse the MSM-only context instead
+    ctx = C.c_void_p()
+    check(lib.apk_msm_ctx_create(cv.abi, gpu, srs.g1_lagrange, n, 0, C.byref(ctx)))
+    out = C.create_string_buffer(96)
+    check(lib.apk_msm_g1(ctx, 0, cv.fr_vector(evals), n, out))
+    lib.apk_ctx_destroy(ctx)
+    ctx2 = C.c_void_p()
+    check(lib.apk_msm_ctx_create(cv.abi, gpu, srs.g1, n + 3, 0, C.byref(ctx2)))
+    out2 = C.create_string_buffer(96)
+    check(lib.apk_msm_g1(ctx2, 0, cv.fr_vector(coeffs), n, out2))
+    lib.apk_ctx_destroy(ctx2)
+    assert out.raw == out2.raw and any(out.raw)
