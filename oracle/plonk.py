@@ -264,6 +264,7 @@ class VerifyingKey:
     commitment_constraint_indexes: List[int]
     g1: Point
     tau: Optional[int] = None  # synthetic SRS only: replaces G2 = ([1]G2, [tau]G2)
+    g2: Optional[tuple] = None  # BLS12-381 only: (G2_SRS_0, G2_SRS_1) for the real pairing check (pairing_bls12381.py)
 
 
 @dataclass
@@ -742,8 +743,14 @@ def verify(vk: VerifyingKey, proof: bytes, public_inputs: bytes) -> bool:
         points_quotient = cv.add(points_quotient, cv.mul(P(OPENING_AT_Z_OMEGA), rv * zeta_omega % q))
         digest = cv.add(digest, points_quotient)
         # :346-355  e(digest, G2_0) * e(-quotient, G2_1) == 1   <=>   digest == tau * quotient
+        if vk.g2 is not None:
+            # the reference's own final line: ec.pairing_check(EC.BLS12_381g1, digest + invert(quotient), g2)
+            # (templateLogicSigBLS12_381.go:364-371)
+            assert cv.name == "bls12-381", "the plain-Python pairing exists for BLS12-381 only"
+            from .pairing_bls12381 import pairing_check
+            return pairing_check([digest, cv.neg(quotient)], [vk.g2[0], vk.g2[1]])
         if vk.tau is None:
-            raise NotImplementedError("real-SRS pairing check is a 'next' row (SURVEY.md §8f.3)")
+            raise NotImplementedError("no tau and no G2 points: cannot finish the verification")
         return digest == cv.mul(quotient, vk.tau)
     except ValueError:
         return False

@@ -99,6 +99,18 @@ def test_real_ethereum_srs_2p14_matches_c_oracle(gpu):
                                   cv.fr_vector(R), cv.fr_vector(O), cv.fr_vector(wl.witness.public), cv.fr_vector(wl.blinding),
                                   threads=os.cpu_count() or 1)
     assert rc == 0 and blob == cblob
+    # (1b) the transcribed verifier accepts it with the REAL pairing check against the G2 points of the ceremony's
+    # vk.bin (templateLogicSigBLS12_381.go:366-371) - nobody knows tau here
+    from oracle import pairing_bls12381 as pr
+    from helpers import oracle_vk_from_product
+    import dataclasses
+    vkb = open(os.path.join(G, "setup", "EethereumKzgCeremonyBLS12_381", "vk.bin"), "rb").read()
+    ovk = dataclasses.replace(oracle_vk_from_product(ov, vk), tau=None, g2=(pr.g2_decompress(vkb[:96]), pr.g2_decompress(vkb[96:192])))
+    assert ov.decompress(vkb[192:]) == vk.KzgG1                      # Vk.G1 == G1[0] (setup/trusted_setup_test.go:127-129)
+    pib = MarshalPublicInputs(wl.witness)
+    assert oplonk.verify(ovk, blob, pib)
+    bad = bytearray(pib); bad[-1] ^= 1
+    assert not oplonk.verify(ovk, blob, bytes(bad))
     # (2) Lagrange vs canonical commitment of the same polynomial, on a context that holds both SRS
     g = SplitMix64(2)
     coeffs = [g.fr(cv.r) for _ in range(n)]

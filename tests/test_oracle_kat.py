@@ -101,3 +101,34 @@ def test_hash_fr_matches_expand_msg_xmd_shape():
     """templateLogicSigBN254.go:386-397: 48 bytes of expand_msg_xmd reduced mod r."""
     v = oplonk.hash_fr(oc.BN254.raw_bytes(oc.BN254.g1), oc.BN254.r)
     assert 0 <= v < oc.BN254.r and v != oplonk.hash_fr(oc.BN254.raw_bytes(oc.BN254.mul(oc.BN254.g1, 2)), oc.BN254.r)
+
+
+def test_pairing_and_g2_decoding_against_reference_expectations():
+    """setup/trusted_setup_test.go:194-253: vk.bin's first G2 point is the BLS12-381 G2 generator; plus the defining
+    relation of any KZG SRS, e([tau]G1, G2) == e(G1, [tau]G2), on the REAL Ethereum ceremony data."""
+    from oracle import pairing_bls12381 as pr
+    cv = oc.BLS12_381
+    vk = open(os.path.join(G, "EethereumKzgCeremonyBLS12_381.vk.bin"), "rb").read()
+    g20, g21 = pr.g2_decompress(vk[:96]), pr.g2_decompress(vk[96:192])
+    assert g20 == pr.G2_GEN and pr.g2_on_curve(g21)
+    head = open(os.path.join(G, "EethereumKzgCeremonyBLS12_381.pk.head.bin"), "rb").read()
+    tau_g1 = cv.decompress(head[4 + 48: 4 + 96])
+    assert pr.pairing_check([tau_g1, cv.neg(cv.g1)], [g20, g21])
+    assert not pr.pairing_check([tau_g1, cv.neg(cv.mul(cv.g1, 2))], [g20, g21])
+
+
+def test_verifier_with_real_pairing_agrees_with_known_tau_shortcut():
+    """The transcription's last line, ec.pairing_check (templateLogicSigBLS12_381.go:366-371), run for real."""
+    from oracle import pairing_bls12381 as pr
+    import dataclasses
+    cv = oc.BLS12_381
+    c, sol = ocircuits.pythagorean(cv)
+    tau = tau_from_seed(77, cv.r)
+    pk = oplonk.setup(c, oplonk.synthetic_srs(cv, c.domain_size(), tau, materialize=False))
+    L, R, O = oplonk.solve_lro(c, sol)
+    pr_ = oplonk.prove(pk, L, R, O, sol[:2], list(range(11, 20)))
+    blob, pib = oplonk.marshal_proof(cv, pr_), oplonk.marshal_public_inputs(sol[:2])
+    vk_pairing = dataclasses.replace(pk.vk, tau=None, g2=(pr.G2_GEN, pr.g2_mul(pr.G2_GEN, tau)))
+    assert oplonk.verify(pk.vk, blob, pib) and oplonk.verify(vk_pairing, blob, pib)
+    bad = bytearray(blob); bad[700] ^= 1
+    assert not oplonk.verify(vk_pairing, bytes(bad), pib)
