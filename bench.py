@@ -27,8 +27,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # one hardware queue per in-flight proof stream (the ROCm default of 4 serialises 16 streams onto 4 queues:
-# 172 -> 205 proofs/s measured); must be set before the HIP runtime initialises
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# 172 -> 205 proofs/s measured with 16; 24 queues / 24 proofs in flight is the plateau); set before HIP initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -40,10 +40,12 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=17)
     ap.add_argument("--curve", default="bn254", choices=["bn254", "bls12_381"])
-    ap.add_argument("--inflight", type=int, default=16, help="independent proofs per step (context slots)")
+    ap.add_argument("--inflight", type=int, default=24, help="independent proofs per step (context slots)")
     ap.add_argument("--msm-window", type=int, default=0)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="prove", choices=["prove", "msm-sharded"],
+                    help="prove (default, BASELINE configs[1]) | msm-sharded (configs[3]: ONE MSM split by index range over the ranks)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -65,6 +67,8 @@ def main() -> None:
 
     cv = ecc.BN254 if args.curve == "bn254" else ecc.BLS12_381
     seed = 0xA190 if cv is ecc.BN254 else 0xA191
+    if args.mode == "msm-sharded":
+        return bench_sharded_msm(args, cv, rank, local_rank, world, torch, dist)
     t0 = time.time()
     wl = workloads.random_circuit(cv, args.log_n, seed)
     n = wl.ccs.domain_size()
@@ -196,6 +200,58 @@ def main() -> None:
             "proof_sha256_prefix": gpu_proof_sha, "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_sharded_msm(args, cv, rank, local_rank, world, torch, dist):
+    """BASELINE.json configs[3]: one 2^log_n MSM (seed 0xA192, uniform scalars, SRS-shaped points) sharded by index range:
+    every rank keeps the windowed tables of its slice resident, computes a full partial sum, then ONE all-gather of a
+    64/96-byte point per rank + world-1 host point additions (algoplonk_amd/parallel.py).  Strong scaling."""
+    from algoplonk_amd import parallel, setup, workloads
+    from algoplonk_amd._lib import lib, check
+
+    n = 1 << args.log_n
+    g = workloads.SplitMix64(0xA192)
+    tau = workloads.tau_from_seed(0xA192, cv.r)
+    srs = setup.unsafe_srs(cv, n, tau, device=local_rank)
+    scalars = cv.fr_vector([g.fr(cv.r) for _ in range(n)])
+    sm = parallel.ShardedMsm(cv, srs.g1[: n * 2 * cv.fp_bytes], device=local_rank, rank=rank, world=world, msm_window=args.msm_window)
+    mine = scalars[sm.lo * 32: sm.hi * 32]
+    d = C.c_void_p()
+    check(lib.apk_device_alloc(sm._ctx, len(mine), C.byref(d)))
+    check(lib.apk_device_upload(sm._ctx, d, mine, len(mine)))
+    out = C.create_string_buffer(2 * cv.fp_bytes)
+
+    def step():
+        check(lib.apk_msm_g1_device(sm._ctx, 0, d, sm.hi - sm.lo, out))
+        return parallel.gather_and_add(cv, out.raw) if world > 1 else out.raw
+
+    for _ in range(args.warmup):
+        res = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        import hashlib
+        print(json.dumps({
+            "metric": "MSM Mscalar/s", "value": round(n * args.steps / elapsed / 1e6, 3), "unit": "Mscalar/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u29x9 Fp (BN254) / u28x14 Fp (BLS12-381) unsaturated Montgomery",
+            "data": "synthetic", "config": {"workload": "%s single MSM 2^%d sharded by index range" % (cv.name, args.log_n),
+                                            "parallelism": "index-range x%d + all-gather of %d-byte points" % (world, 2 * cv.fp_bytes)},
+            "result_sha256_prefix": hashlib.sha256(res).hexdigest()[:16]}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
