@@ -131,7 +131,7 @@ class CurveBackend : public Backend {
         DevBuf pi2_lag[APK_MAX_COMMITMENTS], pi2_can[APK_MAX_COMMITMENTS], epi2[APK_MAX_COMMITMENTS];
         DevBuf scratch_in;  // upload staging for primitives
         // MSM workspace
-        DevBuf counts, hist, offsets, cursor, unit_off, sorted, partial, bucket_sum, bit_partial, result, result_xyzz;
+        DevBuf counts, hist, offsets, unit_off, sorted, partial, bucket_sum, bit_partial, result, result_xyzz;
         void* h_pinned = nullptr;  // small pinned staging for results
     };
 
@@ -266,7 +266,7 @@ class CurveBackend : public Backend {
         KCHK();
         msm_colscan_kernel<0><<<cdiv(total_buckets, 256), 256, 0, st>>>(ptr<uint32_t>(s.counts), NB_, G, total_buckets, ptr<uint32_t>(s.hist));
         KCHK();
-        msm_scan_kernel<MSM_UNIT><<<1, 1024, 0, st>>>(ptr<uint32_t>(s.hist), total_buckets, ptr<uint32_t>(s.offsets), ptr<uint32_t>(s.cursor),
+        msm_scan_kernel<MSM_UNIT><<<1, 1024, 0, st>>>(ptr<uint32_t>(s.hist), total_buckets, ptr<uint32_t>(s.offsets),
                                                        ptr<uint32_t>(s.unit_off));
         KCHK();
         msm_digits_kernel<FRP, true><<<gd, 256, lds, st>>>(a, win_, NB_, T.n_bases, G, ptr<uint32_t>(s.counts), ptr<uint32_t>(s.offsets),
@@ -343,7 +343,7 @@ class CurveBackend : public Backend {
     int alloc_msm_workspace(Slot& s, uint32_t batch) {
         const uint64_t entries = (uint64_t)batch * msm_bases_ * W_;
         const uint32_t tb = batch * NB_;
-        CHK(s.hist.alloc((size_t)(tb + 1) * 4)); CHK(s.offsets.alloc((size_t)(tb + 1) * 4)); CHK(s.cursor.alloc((size_t)(tb + 1) * 4));
+        CHK(s.hist.alloc((size_t)(tb + 1) * 4)); CHK(s.offsets.alloc((size_t)(tb + 1) * 4));
         CHK(s.unit_off.alloc((size_t)(tb + 1) * 4));
         CHK(s.counts.alloc((size_t)tb * msm_G_max_ * 4));
         CHK(s.sorted.alloc(entries * 4));

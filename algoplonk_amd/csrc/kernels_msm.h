@@ -8,11 +8,11 @@
 //   * the SRS is fixed per circuit and HBM is 288 GB, so every window's multiple 2^(c*j) * P_i is
 //     precomputed once ("windowed point tables").  All W windows then feed ONE set of 2^(c-1) buckets:
 //     no per-window reduction, no final double-and-add over windows.
-//   * scalars are recoded into signed c-bit digits; (digit, point) pairs are counting-sorted by bucket with
-//     L2 atomics (histogram -> single-block scan -> scatter);
-//   * bucket accumulation is cut into fixed-size work units (<= K entries of one bucket per lane) so a
-//     skewed bucket cannot serialise a wave; unit partials are merged by 16-lane groups with
-//     wavefront shuffles;
+//   * scalars are recoded into signed digits (window widths c or c-1 bits, balanced); (digit, point) pairs are
+//     counting-sorted by bucket with LDS-private histograms (slice histogram -> column scan -> bucket scan -> scatter);
+//   * bucket accumulation is cut into fixed-size work units (<= MSM_UNIT entries of one bucket per lane) so a
+//     skewed bucket cannot serialise a wave; point arithmetic runs on unsaturated limbs (ffu.h: carry-free
+//     v_mad_u64_u32 chains); unit partials are merged by 2..16-lane groups with wavefront shuffles;
 //   * the weighted bucket sum  sum_k k*B_k  is evaluated bit-wise (sum_b 2^b * sum_{k: bit b} B_k):
 //     LDS tree reductions, critical path ~2*log2(#buckets) point operations instead of 2*#buckets.
 // Several MSMs over the same bases (e.g. [L],[R],[O]) run as one batch: bucket id = msm*NB + bucket.
@@ -123,10 +123,10 @@ __global__ void __launch_bounds__(256) msm_colscan_kernel(uint32_t* __restrict__
 }
 
 // ---- single-block exclusive scans: bucket offsets and work-unit offsets --------------------------------
-// offsets[k] = sum_{i<k} hist[i]; cursor = copy of offsets; unit_off[k] = sum_{i<k} ceil(hist[i]/UNIT)
+// offsets[k] = sum_{i<k} hist[i]; unit_off[k] = sum_{i<k} ceil(hist[i]/UNIT)
 template <int UNIT>
 __global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t* __restrict__ hist, uint32_t total,
-                                                        uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
+                                                        uint32_t* __restrict__ offsets,
                                                         uint32_t* __restrict__ unit_off) {
     __shared__ uint32_t s_cnt[1024];
     __shared__ uint32_t s_unit[1024];
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t* __restri
     uint32_t bc = s_cnt[t] - sc, bu = s_unit[t] - su;  // exclusive prefix of this thread's chunk
     for (uint32_t i = lo; i < hi; i++) {
         uint32_t h = hist[i];
-        offsets[i] = bc; cursor[i] = bc; unit_off[i] = bu;
+        offsets[i] = bc; unit_off[i] = bu;
         bc += h; bu += (h + UNIT - 1) / UNIT;
     }
     if (t == 1023) { offsets[total] = s_cnt[1023]; unit_off[total] = s_unit[1023]; }

@@ -8,9 +8,9 @@
 * trusted setups                       setup/setup.go:110-149,196-228: pk.bin = BE u32 count || compressed G1.
                                         The ceremony files are not shipped with this repo; point
                                         APK_TRUSTED_SETUP_DIR at a directory laid out like the reference's
-                                        `setup/<NamePath>/{pk,vk}.bin`.  Decompression runs on the host here;
-                                        `ToLagrangeG1` is only needed for BSB22 circuits (our wire commitments use
-                                        the canonical SRS) and is a "next" row.
+                                        `setup/<NamePath>/{pk,vk}.bin`.  Point decompression and `ToLagrangeG1` run on
+                                        the GPU (apk_g1_decompress / apk_g1_to_lagrange); the Lagrange
+                                        SRS is only built for BSB22 circuits (wire commitments use the canonical SRS).
 """
 from __future__ import annotations
 
