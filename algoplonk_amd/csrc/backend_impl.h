@@ -131,7 +131,7 @@ class CurveBackend : public Backend {
         DevBuf pi2_lag[APK_MAX_COMMITMENTS], pi2_can[APK_MAX_COMMITMENTS], epi2[APK_MAX_COMMITMENTS];
         DevBuf scratch_in;  // upload staging for primitives
         // MSM workspace
-        DevBuf counts, hist, offsets, unit_off, sorted, partial, bucket_sum, bit_partial, result, result_xyzz;
+        DevBuf counts, hist, offsets, unit_off, sorted, partial, bucket_sum, rowcol, bit_partial, result, result_xyzz;
         void* h_pinned = nullptr;  // small pinned staging for results
     };
 
@@ -286,13 +286,15 @@ class CurveBackend : public Backend {
         msm_combine_kernel<FPP><<<cdiv((uint64_t)total_buckets << lanes_log, 256), 256, 0, st>>>(
             ptr<PtU>(s.partial), ptr<uint32_t>(s.unit_off), total_buckets, lanes_log, ptr<PtU>(s.bucket_sum));
         KCHK();
-        const uint32_t nchunk = NB_ > 2048 ? NB_ / 2048 : 1;
-        const uint32_t nbits = (uint32_t)c_;
-        dim3 gr(nchunk, nbits, a.batch);
-        msm_bitsum_kernel<FPP><<<gr, MSM_RED_THREADS, MSM_RED_THREADS * sizeof(PtU), st>>>(ptr<PtU>(s.bucket_sum), NB_, nchunk, nbits,
-                                                                                           ptr<PtU>(s.bit_partial));
+        // sum_k k*B_k: row/column sums of the bucket array, bit-wise weighted sums of those, final scaling + affine
+        const int m_bits = c_ - 1, cols_log = m_bits - m_bits / 2;
+        const uint32_t rows = 1u << (m_bits / 2), cols = 1u << cols_log;
+        msm_rowcol_kernel<FPP><<<dim3(rows + cols, a.batch), 256, 0, st>>>(ptr<PtU>(s.bucket_sum), NB_, rows, cols, ptr<PtU>(s.rowcol));
         KCHK();
-        msm_final_kernel<FPP><<<a.batch, 256, 0, st>>>(ptr<PtU>(s.bit_partial), nchunk, nbits, ptr<Aff>(s.result), ptr<Pt>(s.result_xyzz));
+        const uint32_t nbits = (uint32_t)cols_log + 1;  // weights <= cols
+        msm_bitsum_kernel<FPP><<<dim3(nbits, 2, a.batch), 256, 0, st>>>(ptr<PtU>(s.rowcol), rows, cols, ptr<PtU>(s.bit_partial));
+        KCHK();
+        msm_final_kernel<FPP><<<a.batch, 64, 0, st>>>(ptr<PtU>(s.bit_partial), nbits, cols_log, ptr<Aff>(s.result), ptr<Pt>(s.result_xyzz));
         KCHK();
         if (stats_on_) HIPCHK(hipEventRecord(s.ev1, st));
         HIPCHK(hipMemcpyAsync(h_out, s.result.p, a.batch * sizeof(Aff), hipMemcpyDeviceToHost, st));
@@ -349,8 +351,12 @@ class CurveBackend : public Backend {
         CHK(s.sorted.alloc(entries * 4));
         CHK(s.partial.alloc((entries / MSM_UNIT + tb) * sizeof(PtU)));
         CHK(s.bucket_sum.alloc((size_t)tb * sizeof(PtU)));
-        const uint32_t nchunk = NB_ > 2048 ? NB_ / 2048 : 1;
-        CHK(s.bit_partial.alloc((size_t)batch * c_ * nchunk * sizeof(PtU)));
+        {
+            const int m_bits = c_ - 1;
+            const uint32_t rows = 1u << (m_bits / 2), cols = 1u << (m_bits - m_bits / 2);
+            CHK(s.rowcol.alloc((size_t)batch * (rows + cols) * sizeof(PtU)));
+        }
+        CHK(s.bit_partial.alloc((size_t)batch * 2 * 32 * sizeof(PtU)));
         CHK(s.result.alloc(MSM_MAX_BATCH * sizeof(Aff)));
         CHK(s.result_xyzz.alloc(MSM_MAX_BATCH * sizeof(Pt)));
         return APK_OK;
@@ -395,7 +401,8 @@ class CurveBackend : public Backend {
             const char* env = getenv("APK_MSM_WINDOW");
             if (env) c_ = atoi(env);
         }
-        if (c_ == 0) { c_ = log_size - 4; if (c_ < 8) c_ = 8; if (c_ > 16) c_ = 16; }
+        // measured flat between log2(n)-4 and log2(n)-2 (tools/sweep.sh); 16 only pays from 2^21 up (128 KiB LDS histograms)
+        if (c_ == 0) { c_ = log_size - 2; if (c_ < 8) c_ = 8; if (c_ > 15) c_ = 15; if (log_size >= 21) c_ = 16; }
         if (c_ < 7 || c_ > 16) { set_error("msm_window %d out of [7,16]", c_); return APK_ERR_ARG; }
         W_ = (FRP::BITS + 1 + c_ - 1) / c_;
         NB_ = 1u << (c_ - 1);

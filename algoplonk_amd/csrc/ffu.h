@@ -7,8 +7,10 @@
 // ~35 % fewer issue cycles per product, and plain C++ (the same code runs on the host for the CPU-only tests).
 //
 // Values are CANONICAL (0 <= x < p, every limb < 2^UB) after every operation, so the point formulas and their
-// special-case tests are unchanged.  The Montgomery radix is R' = 2^(UB*UL), not gnark's R = 2^(32N): FeU values never
-// leave the MSM pipeline (windowed tables are internal data; results are converted back with to_fe()).
+// special-case tests are unchanged.  (A weakly reduced variant - skip the conditional subtraction after products - was
+// tried: subtraction then needs a second conditional correction because an operand may exceed p, which eats the gain.)
+// The Montgomery radix is R' = 2^(UB*UL), not gnark's R = 2^(32N): FeU values never leave the MSM pipeline (windowed
+// tables are internal data; results are converted back with to_fe()).
 //
 // Replaces (device side) gnark-crypto v0.20.1 ecc/<curve>/fp element arithmetic inside G1Affine.MultiExp
 // [UPSTREAM, not vendored; reached from /root/reference/algoplonk.go:89 via kzg.Commit].
@@ -143,7 +145,38 @@ struct FeU {
         r.l[L - 1] = (uint32_t)acc;
         return reduce_once(r);
     }
-    APK_HD static FeU sqr(const FeU& a) { return mul(a, a); }
+
+    // a*a/R': the off-diagonal partial products are taken once against 2a (L*(L+1)/2 mads instead of L*L)
+    APK_HD static FeU sqr(const FeU& a) {
+        uint32_t m[L], d[L];
+        FeU r;
+#pragma unroll
+        for (int i = 0; i < L; i++) d[i] = a.l[i] << 1;   // < 2^(B+1): products stay below 2^(2B+1), column sums below 2^63
+        uint64_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < L; k++) {
+#pragma unroll
+            for (int i = 0; 2 * i < k; i++) acc += (uint64_t)d[i] * a.l[k - i];
+            if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+            for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::umod(k - i);
+            m[k] = ((uint32_t)acc * P::UINV) & MASK;
+            acc += (uint64_t)m[k] * P::umod(0);
+            acc >>= B;
+        }
+#pragma unroll
+        for (int k = L; k < 2 * L - 1; k++) {
+#pragma unroll
+            for (int i = k - L + 1; 2 * i < k; i++) acc += (uint64_t)d[i] * a.l[k - i];
+            if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+            for (int i = k - L + 1; i < L; i++) acc += (uint64_t)m[i] * P::umod(k - i);
+            r.l[k - L] = (uint32_t)acc & MASK;
+            acc >>= B;
+        }
+        r.l[L - 1] = (uint32_t)acc;
+        return reduce_once(r);
+    }
 
     // ---- packed (saturated, N x 32-bit) <-> limbs.  The packed form is what sits in HBM (tables, results). ----
     APK_HD static FeU unpack(const uint32_t* w) {

@@ -13,8 +13,9 @@
 //   * bucket accumulation is cut into fixed-size work units (<= MSM_UNIT entries of one bucket per lane) so a
 //     skewed bucket cannot serialise a wave; point arithmetic runs on unsaturated limbs (ffu.h: carry-free
 //     v_mad_u64_u32 chains); unit partials are merged by 2..16-lane groups with wavefront shuffles;
-//   * the weighted bucket sum  sum_k k*B_k  is evaluated bit-wise (sum_b 2^b * sum_{k: bit b} B_k):
-//     LDS tree reductions, critical path ~2*log2(#buckets) point operations instead of 2*#buckets.
+//   * the weighted bucket sum  sum_k k*B_k  is reduced in two levels (row / column sums of the bucket array, then
+//     bit-wise weighted sums of <= 256 elements): 2 additions per bucket, critical path ~log2(#buckets) + c point
+//     operations instead of the 2*#buckets of a running sum.
 // Several MSMs over the same bases (e.g. [L],[R],[O]) run as one batch: bucket id = msm*NB + bucket.
 #pragma once
 #include "ec.h"
@@ -24,8 +25,6 @@ namespace apk {
 constexpr int MSM_MAX_BATCH = 4;
 constexpr int MSM_UNIT = 16;        // entries per accumulation work unit (8 and 32 measured within 5 % on throughput)
 constexpr int MSM_COMBINE_LANES = 16;
-constexpr int MSM_RED_THREADS = 256;
-constexpr int MSM_RED_MAXCHUNK = 8;
 
 // Signed-digit windows.  Widths differ by at most one bit (c or c-1) so the BITS+1 scalar bits are spread evenly:
 // with equal widths the top window can be left with 1-3 significant bits, and every scalar then lands in the same
@@ -223,67 +222,80 @@ __global__ void __launch_bounds__(256) msm_combine_kernel(const XYZZ<FP, FeU<FP>
     if (k < total_buckets && lane == 0) bucket_sum[k] = acc;
 }
 
-// ---- weighted bucket reduction, bit-wise --------------------------------------------------------------
-// grid (chunk, bit, msm): S[msm][bit][chunk] = sum of B_k (k = idx+1) with bit `bit` of k set, idx in chunk
-template <class FP>
-__global__ void __launch_bounds__(MSM_RED_THREADS) msm_bitsum_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum, uint32_t nb,
-                                                                     uint32_t nchunk, uint32_t nbits,
-                                                                     XYZZ<FP, FeU<FP>>* __restrict__ bit_partial) {
-    using PT = XYZZ<FP, FeU<FP>>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    PT* sm = reinterpret_cast<PT*>(smem_raw);
-    const uint32_t chunk = blockIdx.x, bit = blockIdx.y, m = blockIdx.z;
-    const uint32_t t = threadIdx.x;
-    const uint32_t per = nb / nchunk;
-    const uint32_t lo = chunk * per, hi = lo + per;
-    PT acc = PT::inf();
-    for (uint32_t idx = lo + t; idx < hi; idx += MSM_RED_THREADS) {
-        if (((idx + 1) >> bit) & 1u) acc.add(bucket_sum[m * nb + idx]);
-    }
-    sm[t] = acc;
-    __syncthreads();
-    for (uint32_t d = MSM_RED_THREADS / 2; d >= 1; d >>= 1) {
-        if (t < d) {
-            PT o = sm[t + d];
-            acc.add(o);
-            sm[t] = acc;
-        }
-        __syncthreads();
-    }
-    if (t == 0) bit_partial[(m * nbits + bit) * nchunk + chunk] = acc;
-}
+// ---- weighted bucket reduction  S = sum_k k * B_k,  k = idx + 1 -----------------------------------------------------
+// Work-efficient two-level form.  Write idx = hi * COLS + lo; then
+//     S = COLS * sum_hi hi * R_hi  +  sum_lo (lo + 1) * C_lo,      R_hi = row sums, C_lo = column sums
+// (2 additions per bucket instead of (c-1)/2 for a bit-wise reduction over all buckets), and the two small weighted
+// sums over <= 256 elements are evaluated bit-wise: sum_b 2^b * (sum of the elements whose weight has bit b set).
+// Critical path ~ log2(#buckets) + c point operations; every level is an LDS tree.
 
-// one workgroup per msm: sum chunks per bit, scale by 2^bit, sum over bits, convert to affine
+// grid (rows + cols, batch): block x < rows sums row x (contiguous), else column x - rows (stride COLS)
 template <class FP>
-__global__ void __launch_bounds__(256) msm_final_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ bit_partial, uint32_t nchunk,
-                                                        uint32_t nbits, Affine<FP>* __restrict__ result,
-                                                        XYZZ<FP>* __restrict__ result_xyzz) {
+__global__ void __launch_bounds__(256) msm_rowcol_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum, uint32_t nb, uint32_t rows,
+                                                         uint32_t cols, XYZZ<FP, FeU<FP>>* __restrict__ rc) {
     using PT = XYZZ<FP, FeU<FP>>;
     __shared__ PT sm[256];
-    const uint32_t m = blockIdx.x;
-    const uint32_t t = threadIdx.x;
-    const uint32_t bit = t / MSM_RED_MAXCHUNK, chunk = t % MSM_RED_MAXCHUNK;
+    const uint32_t m = blockIdx.y, x = blockIdx.x, t = threadIdx.x;
+    const PT* src = bucket_sum + (size_t)m * nb;
     PT acc = PT::inf();
-    if (bit < nbits)
-        for (uint32_t ch = chunk; ch < nchunk; ch += MSM_RED_MAXCHUNK) acc.add(bit_partial[(m * nbits + bit) * nchunk + ch]);
+    if (x < rows) {
+        for (uint32_t lo = t; lo < cols; lo += 256) acc.add(src[x * cols + lo]);
+    } else {
+        const uint32_t col = x - rows;
+        for (uint32_t hi = t; hi < rows; hi += 256) acc.add(src[hi * cols + col]);
+    }
     sm[t] = acc;
     __syncthreads();
-    for (uint32_t d = MSM_RED_MAXCHUNK / 2; d >= 1; d >>= 1) {
-        if (chunk < d) { PT o = sm[t + d]; acc.add(o); sm[t] = acc; }
+    for (uint32_t d = 128; d >= 1; d >>= 1) {
+        if (t < d) { PT o = sm[t + d]; acc.add(o); sm[t] = acc; }
         __syncthreads();
     }
-    if (chunk == 0) {
-        for (uint32_t i = 0; i < bit && i < nbits; i++) acc = PT::dbl(acc);
-        sm[t] = acc;
+    if (t == 0) rc[(size_t)m * (rows + cols) + x] = acc;
+}
+
+// grid (nbits, 2, batch): which = 0 -> rows part (elements R_1..R_{rows-1}, weight = index), which = 1 -> column part
+// (elements C_0..C_{cols-1}, weight = index + 1).  out[(m*2 + which)*32 + bit] = sum of the elements whose weight has `bit`.
+template <class FP>
+__global__ void __launch_bounds__(256) msm_bitsum_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ rc, uint32_t rows, uint32_t cols,
+                                                         XYZZ<FP, FeU<FP>>* __restrict__ bit_partial) {
+    using PT = XYZZ<FP, FeU<FP>>;
+    __shared__ PT sm[256];
+    const uint32_t bit = blockIdx.x, which = blockIdx.y, m = blockIdx.z, t = threadIdx.x;
+    const PT* src = rc + (size_t)m * (rows + cols) + (which ? rows : 0);
+    const uint32_t count = which ? cols : rows;
+    PT acc = PT::inf();
+    for (uint32_t i = t; i < count; i += 256) {
+        const uint32_t weight = which ? i + 1 : i;
+        if ((weight >> bit) & 1u) acc.add(src[i]);
     }
+    sm[t] = acc;
     __syncthreads();
-    // tree over bits: entries at t = bit*MAXCHUNK
-    for (uint32_t d = 16; d >= 1; d >>= 1) {
-        if (chunk == 0 && bit < d && bit + d < 32) {
-            PT o = sm[(bit + d) * MSM_RED_MAXCHUNK];
-            acc.add(o);
-            sm[t] = acc;
-        }
+    for (uint32_t d = 128; d >= 1; d >>= 1) {
+        if (t < d) { PT o = sm[t + d]; acc.add(o); sm[t] = acc; }
+        __syncthreads();
+    }
+    if (t == 0) bit_partial[((size_t)m * 2 + which) * 32 + bit] = acc;
+}
+
+// one workgroup of 64 lanes per msm: lane (which, bit) scales its bit-sum by 2^bit (and the row part by COLS = 2^cols_log),
+// LDS tree over the 64 lanes, conversion back to gnark's radix and to affine form
+template <class FP>
+__global__ void __launch_bounds__(64) msm_final_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ bit_partial, uint32_t nbits, int cols_log,
+                                                       Affine<FP>* __restrict__ result, XYZZ<FP>* __restrict__ result_xyzz) {
+    using PT = XYZZ<FP, FeU<FP>>;
+    __shared__ PT sm[64];
+    const uint32_t m = blockIdx.x, t = threadIdx.x;
+    const uint32_t which = t >> 5, bit = t & 31;
+    PT acc = PT::inf();
+    if (bit < nbits) {
+        acc = bit_partial[((size_t)m * 2 + which) * 32 + bit];
+        const int dbl = (int)bit + (which == 0 ? cols_log : 0);
+        for (int i = 0; i < dbl; i++) acc = PT::dbl(acc);
+    }
+    sm[t] = acc;
+    __syncthreads();
+    for (uint32_t d = 32; d >= 1; d >>= 1) {
+        if (t < d) { PT o = sm[t + d]; acc.add(o); sm[t] = acc; }
         __syncthreads();
     }
     if (t == 0) {

@@ -60,6 +60,10 @@ def test_host_field_and_curve_templates_match_oracle(cname):
                 assert dec(out.raw) == exp, (cname, field, op)
             check(lib.apk_host_fe_op(cv.abi, field, 3, enc(a), None, out))
             assert dec(out.raw) == (pow(a, -1, mod) if a else 0)
+            if field == 1:   # the MSM's unsaturated-limb field (ffu.h), converted in and out of gnark's radix
+                for op, exp in ((10, a * b % mod), (11, (a + b) % mod), (12, (a - b) % mod), (13, (-a) % mod), (10, a * a % mod)):
+                    check(lib.apk_host_fe_op(cv.abi, 1, op, enc(a), enc(a) if exp == a * a % mod and op == 10 and a != b else enc(b), out))
+                    assert dec(out.raw) == exp, (cname, "unsat", op)
         # canonical big-endian codecs
         be = C.create_string_buffer(nb)
         check(lib.apk_fe_to_be(cv.abi, field, enc(12345), be))
@@ -74,7 +78,11 @@ def test_host_field_and_curve_templates_match_oracle(cname):
         for op, q, exp in ((0, cv.g1_to_bytes(Q), ov.add(P, Q)), (1, cv.g1_to_bytes(Q), ov.add(P, Q)), (2, None, ov.add(P, P)),
                            (3, cv.fr_to_mont_bytes(k2), ov.mul(P, k2)), (0, cv.g1_to_bytes(P), ov.add(P, P)),
                            (0, cv.g1_to_bytes(ov.neg(P)), None), (1, cv.g1_to_bytes(P), ov.add(P, P)),
-                           (1, cv.g1_to_bytes(ov.neg(P)), None), (0, cv.g1_to_bytes(None), P)):
+                           (1, cv.g1_to_bytes(ov.neg(P)), None), (0, cv.g1_to_bytes(None), P),
+                           # 10 / 11: the same additions on unsaturated limbs (dedicated squaring, table-record packing)
+                           (10, cv.g1_to_bytes(Q), ov.add(P, Q)), (11, cv.g1_to_bytes(Q), ov.add(P, Q)), (10, cv.g1_to_bytes(P), ov.add(P, P)),
+                           (10, cv.g1_to_bytes(ov.neg(P)), None), (11, cv.g1_to_bytes(P), ov.add(P, P)), (11, cv.g1_to_bytes(ov.neg(P)), None),
+                           (10, cv.g1_to_bytes(None), P)):
             check(lib.apk_host_g1_op(cv.abi, op, cv.g1_to_bytes(P), q, out))
             assert cv.g1_from_bytes(out.raw) == exp, (cname, op)
 
