@@ -298,3 +298,57 @@ def test_bsb22_proof_marshalling_and_verification(gpu, cname, nb):
     bad = bytearray(blob); bad[-1] ^= 1
     assert not oplonk.verify(ovk, bytes(bad), pib)
     pk.close()
+
+
+class _RandomWithCommit(frontend.Circuit):
+    """A 2^log_n random-gate circuit (BASELINE.md §2 generator) whose first secret and a mid-circuit wire are BSB22
+    committed and whose commitment feeds later gates - the shape of BASELINE.json configs[4] at test size."""
+    P0 = frontend.Public()
+    P1 = frontend.Public()
+    S0 = frontend.Secret()
+    S1 = frontend.Secret()
+
+    def __init__(self, gates=0, seed=1, r=0):
+        self.gates, self.seed, self.r = gates, seed, r
+
+    def define(self, api):
+        g = SplitMix64(self.seed)
+        wires = [self.P0, self.P1, self.S0, self.S1]
+        for i in range(self.gates):
+            a, b = wires[g.below(len(wires))], wires[g.below(len(wires))]
+            wires.append(api.Gate(g.fr(self.r), g.fr(self.r), g.fr(self.r), g.fr(self.r), a, b))
+            if i == self.gates // 2:
+                cmt = api.Commit(self.S0, wires[-1])
+                api.AssertIsDifferent(cmt, 0)
+                wires.append(cmt)
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12-381"])
+def test_bsb22_inside_a_random_circuit_2p10(gpu, cname):
+    cv, ov = CURVES[cname]
+    circuit = _RandomWithCommit(gates=1000, seed=0xA193, r=cv.r)
+    ccs = frontend.Compile(cv.r, circuit)
+    n = ccs.domain_size()
+    assert n == 1024 and len(ccs.commitments) == 1
+    tau = tau_from_seed(0xA193, cv.r)
+    srs = ap_setup.unsafe_srs(cv, n, tau, device=gpu, lagrange=True)
+    pk, vk = ap_plonk.Setup(ccs, srs, device=gpu)
+    a = _RandomWithCommit(gates=1000, seed=0xA193, r=cv.r)
+    a.P0, a.P1, a.S0, a.S1 = 11, 22, 33, 44
+    w = frontend.NewWitness(a, cv.r)
+    g = SplitMix64(5)
+    hiding = [(g.fr(cv.r), g.fr(cv.r))]
+    bl = blinding(cv, 3)
+    proof = ap_plonk.Prove(ccs, pk, w, bl, hiding=hiding)
+    blob, pib = MarshalProof(proof), MarshalPublicInputs(w)
+    oc_ = oplonk.Circuit(ov, 2, ccs.nb_variables, list(ccs.constraints), [oplonk.Commitment(list(rows), cidx) for rows, cidx in ccs.commitments])
+    osrs = oplonk.synthetic_srs(ov, n, tau, materialize=False)
+    opk = oplonk.setup(oc_, osrs)
+    wn = ov.omega(n)
+    pi2 = []
+    sol = frontend.solve(ccs, w, lambda col: oplonk.hash_fr(ov.raw_bytes(osrs.commit(oplonk.intt(col, wn, cv.r))), cv.r), hiding, pi2)
+    L, R, O = oplonk.solve_lro(oc_, sol)
+    opr = oplonk.prove(opk, L, R, O, w.public, bl, pi2=pi2)
+    assert blob == oplonk.marshal_proof(ov, opr)
+    assert oplonk.verify(oracle_vk_from_product(ov, vk), blob, pib)
+    pk.close()
