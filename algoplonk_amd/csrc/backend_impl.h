@@ -131,7 +131,7 @@ class CurveBackend : public Backend {
         DevBuf pi2_lag[APK_MAX_COMMITMENTS], pi2_can[APK_MAX_COMMITMENTS], epi2[APK_MAX_COMMITMENTS];
         DevBuf scratch_in;  // upload staging for primitives
         // MSM workspace
-        DevBuf counts, hist, offsets, unit_off, sorted, partial, bucket_sum, rowcol, bit_partial, result, result_xyzz;
+        DevBuf counts, hist, offsets, unit_off, scan_blk, sorted, partial, bucket_sum, rowcol, bit_partial, result, result_xyzz;
         void* h_pinned = nullptr;  // small pinned staging for results
     };
 
@@ -266,9 +266,18 @@ class CurveBackend : public Backend {
         KCHK();
         msm_colscan_kernel<0><<<cdiv(total_buckets, 256), 256, 0, st>>>(ptr<uint32_t>(s.counts), NB_, G, total_buckets, ptr<uint32_t>(s.hist));
         KCHK();
-        msm_scan_kernel<MSM_UNIT><<<1, 1024, 0, st>>>(ptr<uint32_t>(s.hist), total_buckets, ptr<uint32_t>(s.offsets),
-                                                       ptr<uint32_t>(s.unit_off));
-        KCHK();
+        {
+            const uint32_t nblk = cdiv(total_buckets, MSM_SCAN_BLOCK);   // <= 1024: total_buckets <= 4 * 2^15... checked at init
+            msm_scan_local_kernel<MSM_UNIT><<<nblk, MSM_SCAN_BLOCK, 0, st>>>(ptr<uint32_t>(s.hist), total_buckets, ptr<uint32_t>(s.offsets),
+                                                                             ptr<uint32_t>(s.unit_off), ptr<uint32_t>(s.scan_blk), nblk);
+            KCHK();
+            msm_scan_totals_kernel<0><<<1, MSM_SCAN_BLOCK, 0, st>>>(ptr<uint32_t>(s.scan_blk), nblk, total_buckets, ptr<uint32_t>(s.offsets),
+                                                                     ptr<uint32_t>(s.unit_off));
+            KCHK();
+            msm_scan_apply_kernel<0><<<nblk, MSM_SCAN_BLOCK, 0, st>>>(ptr<uint32_t>(s.scan_blk), nblk, total_buckets, ptr<uint32_t>(s.offsets),
+                                                                      ptr<uint32_t>(s.unit_off));
+            KCHK();
+        }
         msm_digits_kernel<FRP, true><<<gd, 256, lds, st>>>(a, win_, NB_, T.n_bases, G, ptr<uint32_t>(s.counts), ptr<uint32_t>(s.offsets),
                                                             ptr<uint32_t>(s.sorted));
         KCHK();
@@ -347,6 +356,7 @@ class CurveBackend : public Backend {
         const uint32_t tb = batch * NB_;
         CHK(s.hist.alloc((size_t)(tb + 1) * 4)); CHK(s.offsets.alloc((size_t)(tb + 1) * 4));
         CHK(s.unit_off.alloc((size_t)(tb + 1) * 4));
+        CHK(s.scan_blk.alloc((size_t)2 * (cdiv(tb, MSM_SCAN_BLOCK) + 1) * 4));
         CHK(s.counts.alloc((size_t)tb * msm_G_max_ * 4));
         CHK(s.sorted.alloc(entries * 4));
         CHK(s.partial.alloc((entries / MSM_UNIT + tb) * sizeof(PtU)));
