@@ -295,6 +295,8 @@ class CurveBackend : public Backend {
         msm_combine_kernel<FPP><<<cdiv((uint64_t)total_buckets << lanes_log, 256), 256, 0, st>>>(
             ptr<PtU>(s.partial), ptr<uint32_t>(s.unit_off), total_buckets, lanes_log, ptr<PtU>(s.bucket_sum));
         KCHK();
+        msm_combine_heavy_kernel<FPP><<<256, 256, 0, st>>>(ptr<PtU>(s.partial), ptr<uint32_t>(s.unit_off), total_buckets, ptr<PtU>(s.bucket_sum));
+        KCHK();
         // sum_k k*B_k: row/column sums of the bucket array, bit-wise weighted sums of those, final scaling + affine
         const int m_bits = c_ - 1, cols_log = m_bits - m_bits / 2;
         const uint32_t rows = 1u << (m_bits / 2), cols = 1u << cols_log;

@@ -25,6 +25,7 @@ namespace apk {
 constexpr int MSM_MAX_BATCH = 4;
 constexpr int MSM_UNIT = 16;        // entries per accumulation work unit (8 and 32 measured within 5 % on throughput)
 constexpr int MSM_COMBINE_LANES = 16;
+constexpr uint32_t MSM_HEAVY_UNITS = 512;  // unit partials above which a bucket is merged by a whole workgroup
 
 // Signed-digit windows.  Widths differ by at most one bit (c or c-1) so the BITS+1 scalar bits are spread evenly:
 // with equal widths the top window can be left with 1-3 significant bits, and every scalar then lands in the same
@@ -234,6 +235,7 @@ __global__ void __launch_bounds__(256) msm_combine_kernel(const XYZZ<FP, FeU<FP>
     PT acc = PT::inf();
     uint32_t beg = 0, end = 0;
     if (k < total_buckets) { beg = unit_off[k]; end = unit_off[k + 1]; }
+    if (end - beg > MSM_HEAVY_UNITS) end = beg;   // skewed bucket: left to msm_combine_heavy_kernel
     for (uint32_t u = beg + lane; u < end; u += LANES) acc.add(partial[u]);
     // all lanes of the wave take part in every shuffle; groups with nothing to add see infinities
     const uint32_t n_units = end - beg;
@@ -244,7 +246,36 @@ __global__ void __launch_bounds__(256) msm_combine_kernel(const XYZZ<FP, FeU<FP>
             if (lane < (uint32_t)d && n_units > (uint32_t)d) acc.add(o);
         }
     }
-    if (k < total_buckets && lane == 0) bucket_sum[k] = acc;
+    if (k < total_buckets && lane == 0 && unit_off[k + 1] - unit_off[k] <= MSM_HEAVY_UNITS) bucket_sum[k] = acc;
+}
+
+// Skewed inputs (e.g. a Lagrange-basis commitment of a witness full of ones): a bucket with more than MSM_HEAVY_UNITS unit
+// partials gets a whole workgroup - strided sums over 256 lanes, then an LDS tree - instead of a few lanes walking thousands
+// of partials.  Each of the (few) blocks scans a slice of the bucket list and only does work for heavy buckets, so the launch
+// costs microseconds when there are none (uniform scalars never produce one).
+template <class FP>
+__global__ void __launch_bounds__(256) msm_combine_heavy_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ partial,
+                                                                const uint32_t* __restrict__ unit_off, uint32_t total_buckets,
+                                                                XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum) {
+    using PT = XYZZ<FP, FeU<FP>>;
+    __shared__ PT sm[256];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (total_buckets + gridDim.x - 1) / gridDim.x;
+    const uint32_t k0 = blockIdx.x * per, k1 = min(k0 + per, total_buckets);
+    for (uint32_t k = k0; k < k1; k++) {
+        const uint32_t beg = unit_off[k], end = unit_off[k + 1];
+        if (end - beg <= MSM_HEAVY_UNITS) continue;   // uniform across the block
+        PT acc = PT::inf();
+        for (uint32_t u = beg + t; u < end; u += 256) acc.add(partial[u]);
+        sm[t] = acc;
+        __syncthreads();
+        for (uint32_t d = 128; d >= 1; d >>= 1) {
+            if (t < d) { PT o = sm[t + d]; acc.add(o); sm[t] = acc; }
+            __syncthreads();
+        }
+        if (t == 0) bucket_sum[k] = acc;
+        __syncthreads();
+    }
 }
 
 // ---- weighted bucket reduction  S = sum_k k * B_k,  k = idx + 1 -----------------------------------------------------

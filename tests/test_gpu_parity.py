@@ -352,3 +352,30 @@ def test_bsb22_inside_a_random_circuit_2p10(gpu, cname):
     assert blob == oplonk.marshal_proof(ov, opr)
     assert oplonk.verify(oracle_vk_from_product(ov, vk), blob, pib)
     pk.close()
+
+
+def test_skewed_scalars_at_full_size_are_correct_and_not_pathological(gpu):
+    """A Lagrange-basis commitment of a real witness is full of 0 / 1 / small values: one bucket then holds ~n entries.
+    The work-unit split + the heavy-bucket merge keep such an MSM within a small factor of the uniform case."""
+    import time
+    cv, ov = CURVES["bn254"]
+    n = 1 << 17
+    tau = tau_from_seed(3, cv.r)
+    srs = ap_setup.unsafe_srs(cv, n, tau, device=gpu)
+    ctx = C.c_void_p()
+    check(lib.apk_msm_ctx_create(cv.abi, gpu, srs.g1, n + 3, 0, C.byref(ctx)))
+    out = C.create_string_buffer(64)
+    g = SplitMix64(1)
+    uniform = [g.fr(cv.r) for _ in range(n)]
+    cases = {"uniform": uniform, "ones": [1] * n, "bits": [i & 1 for i in range(n)], "small": [g.below(1 << 10) for _ in range(n)],
+             "minus_one": [cv.r - 1] * n}
+    times = {}
+    for name, sc in cases.items():
+        buf = cv.fr_vector(sc)
+        check(lib.apk_msm_g1(ctx, 0, buf, n, out))          # warm
+        t0 = time.perf_counter()
+        check(lib.apk_msm_g1(ctx, 0, buf, n, out))
+        times[name] = time.perf_counter() - t0
+        assert cv.g1_from_bytes(out.raw) == ov.mul(ov.g1, oplonk.poly_eval(sc, tau, cv.r)), name
+    lib.apk_ctx_destroy(ctx)
+    assert max(times.values()) < 20 * times["uniform"] + 0.05, times
