@@ -213,6 +213,12 @@ def solve(ccs: ConstraintSystem, w: Witness, commit_hint=None, hiding=None, pi2_
             s[wire] = commit_hint(col)
             if pi2_out is not None:
                 pi2_out.append(col)
+        elif isinstance(fn, tuple) and fn[0] == "gate":
+            # closure-free encoding used by the large synthetic workloads: c = ql*a + qr*b + qm*a*b + qk
+            _, ql, qr, qm, qk, xa, xb = fn
+            s[wire] = (ql * s[xa] + qr * s[xb] + qm * s[xa] % ccs.field * s[xb] + qk) % ccs.field
+        elif isinstance(fn, tuple) and fn[0] == "inv":
+            s[wire] = pow(s[fn[1]], -1, ccs.field)
         else:
             s[wire] = fn(s)
     return s

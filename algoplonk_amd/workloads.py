@@ -59,6 +59,49 @@ class Workload:
     tau: int
 
 
+def random_circuit_bsb22(curve: ecc.ID, log_n: int, seed: int, nb_commitments: int = 1, committed: int = 16,
+                         nb_public: int = 2):
+    """BASELINE.json configs[4] shape: the random-gate circuit with `nb_commitments` BSB22 commitments, each over
+    `committed` wires (the committed column is all zero except those entries + 2 hiding values), each commitment feeding
+    later gates.  Returns (ccs, witness, blinding, tau); solving needs the commitment hint (plonk.Prove supplies it)."""
+    r = curve.r
+    n = 1 << log_n
+    g = SplitMix64(seed)
+    inputs = [g.fr(r) for _ in range(nb_public + 2)]
+    cons, solver, commitments = [], [], []
+    nv = nb_public + 2
+    budget = n - nb_public
+    per_commit = committed + 2                      # committed rows + the commitment row + the != 0 row
+    plain = budget - nb_commitments * per_commit
+    assert plain > 4 * nb_commitments
+    next_commit_at = plain // (nb_commitments + 1)
+    done_commits = 0
+    for i in range(plain):
+        xa, xb = g.below(nv), g.below(nv)
+        ql, qr, qm, qk = g.fr(r), g.fr(r), g.fr(r), g.fr(r)
+        cons.append((ql, qr, qm, r - 1, qk, xa, xb, nv))
+        solver.append((nv, ("gate", ql, qr, qm, qk, xa, xb)))
+        nv += 1
+        if done_commits < nb_commitments and i + 1 == next_commit_at * (done_commits + 1):
+            rows = []
+            for _ in range(committed):
+                rows.append(len(cons))
+                cons.append((r - 1, 0, 0, 0, 0, g.below(nv), 0, 0))       # -v + qcp*pi2 = 0
+            cmt = nv
+            solver.append((cmt, ("commit", done_commits)))
+            commitments.append((rows, len(cons)))
+            cons.append((r - 1, 0, 0, 0, 0, cmt, 0, 0))                   # -cmt + qk(injected) = 0
+            inv = nv + 1
+            solver.append((inv, ("inv", cmt)))
+            cons.append((0, 0, 1, 0, r - 1, cmt, inv, 0))                 # cmt * inv - 1 = 0
+            nv += 2
+            done_commits += 1
+    ccs = frontend.ConstraintSystem(r, ["p%d" % i for i in range(nb_public)], ["s0", "s1"], cons, solver, nv, commitments)
+    w = frontend.Witness(r, inputs[:nb_public], inputs[nb_public:])
+    gb = SplitMix64(seed ^ 0xB11D)
+    return ccs, w, [gb.fr(r) for _ in range(9)], tau_from_seed(seed, r)
+
+
 def random_circuit(curve: ecc.ID, log_n: int, seed: int, nb_public: int = 2) -> Workload:
     """BASELINE.json configs[1]/[2]: n - nb_public random gates c = ql*a + qr*b + qm*a*b + qk over earlier wires."""
     r = curve.r

@@ -379,3 +379,28 @@ def test_skewed_scalars_at_full_size_are_correct_and_not_pathological(gpu):
         assert cv.g1_from_bytes(out.raw) == ov.mul(ov.g1, oplonk.poly_eval(sc, tau, cv.r)), name
     lib.apk_ctx_destroy(ctx)
     assert max(times.values()) < 20 * times["uniform"] + 0.05, times
+
+
+@pytest.mark.parametrize("cname,log_n", [("bls12-381", 17), ("bn254", 16)])
+def test_bsb22_at_scale_is_accepted_by_the_transcribed_verifier(gpu, cname, log_n):
+    """SURVEY.md §8f.2 / BASELINE.json configs[4] shape on one GPU: a large random circuit with one BSB22 commitment over
+    16 wires (sparse committed column, Lagrange-SRS MSM in the hint).  Verified by the template transcription, including
+    the hash_fr / L_{nbPublic+cci}(zeta) public-input term (templateLogicSigBN254.go:187-193)."""
+    from algoplonk_amd import workloads
+    cv, ov = CURVES[cname]
+    ccs, w, bl, tau = workloads.random_circuit_bsb22(cv, log_n, 0xA193)
+    n = ccs.domain_size()
+    assert n == 1 << log_n and len(ccs.commitments) == 1
+    srs = ap_setup.unsafe_srs(cv, n, tau, device=gpu, lagrange=True)
+    pk, vk = ap_plonk.Setup(ccs, srs, device=gpu)
+    proof = ap_plonk.Prove(ccs, pk, w, bl, hiding=[(12345, 67890)])
+    blob, pib = MarshalProof(proof), MarshalPublicInputs(w)
+    base_words, pt = (24, 64) if cv is ecc.BN254 else (33, 96)
+    assert len(blob) == base_words * 32 + 32 + pt
+    ovk = oracle_vk_from_product(ov, vk)
+    assert oplonk.verify(ovk, blob, pib)
+    bad = bytearray(blob); bad[-1] ^= 1           # tamper with the BSB22 commitment point
+    assert not oplonk.verify(ovk, bytes(bad), pib)
+    bad = bytearray(blob); bad[base_words * 32 + 5] ^= 1   # tamper with qcp(zeta)
+    assert not oplonk.verify(ovk, bytes(bad), pib)
+    pk.close()
