@@ -404,3 +404,21 @@ def test_bsb22_at_scale_is_accepted_by_the_transcribed_verifier(gpu, cname, log_
     bad = bytearray(blob); bad[base_words * 32 + 5] ^= 1   # tamper with qcp(zeta)
     assert not oplonk.verify(ovk, bytes(bad), pib)
     pk.close()
+
+
+def test_largest_size_bls12_381_2p21_proof_verifies(gpu):
+    """BASELINE.json configs[4] size on one GPU (BLS12-381, n = 2^21, 64 MiB per polynomial, 3.2 GB of windowed tables):
+    the proof is checked by the transcribed verifier, whose cost does not depend on n."""
+    from algoplonk_amd import workloads
+    cv, ov = CURVES["bls12-381"]
+    wl = workloads.random_circuit(cv, 21, 0xA193)
+    n = wl.ccs.domain_size()
+    srs = ap_setup.unsafe_srs(cv, n, wl.tau, device=gpu)
+    pk, vk = ap_plonk.Setup(wl.ccs, srs, device=gpu)
+    proof = ap_plonk.Prove(wl.ccs, pk, wl.witness, wl.blinding)
+    blob, pib = MarshalProof(proof), MarshalPublicInputs(wl.witness)
+    ovk = oracle_vk_from_product(ov, vk)
+    assert len(blob) == 1056 and oplonk.verify(ovk, blob, pib)
+    bad = bytearray(blob); bad[900] ^= 1
+    assert not oplonk.verify(ovk, bytes(bad), pib)
+    pk.close()
