@@ -257,7 +257,8 @@ class CurveBackend : public Backend {
         const uint32_t max_units = (uint32_t)(entries / MSM_UNIT) + total_buckets;
         if (stats_on_) HIPCHK(hipEventRecord(s.ev0, st));
         // counting sort by bucket: LDS-private histograms per scalar slice, column scan, bucket scan, scatter
-        uint32_t G = cdiv(maxlen, 2048);
+        static const uint32_t slice = getenv("APK_MSM_SLICE") ? (uint32_t)atoi(getenv("APK_MSM_SLICE")) : 2048u;  // scalars per sort workgroup
+        uint32_t G = cdiv(maxlen, slice ? slice : 2048u);
         if (G < 1) G = 1;
         if (G > msm_G_max_) G = msm_G_max_;
         dim3 gd(G, a.batch);
