@@ -264,7 +264,7 @@ class VerifyingKey:
     commitment_constraint_indexes: List[int]
     g1: Point
     tau: Optional[int] = None  # synthetic SRS only: replaces G2 = ([1]G2, [tau]G2)
-    g2: Optional[tuple] = None  # BLS12-381 only: (G2_SRS_0, G2_SRS_1) for the real pairing check (pairing_bls12381.py)
+    g2: Optional[tuple] = None  # (G2_SRS_0, G2_SRS_1): finish with the real pairing check (pairing_bls12381.py / pairing_bn254.py)
 
 
 @dataclass
@@ -746,8 +746,10 @@ def verify(vk: VerifyingKey, proof: bytes, public_inputs: bytes) -> bool:
         if vk.g2 is not None:
             # the reference's own final line: ec.pairing_check(EC.BLS12_381g1, digest + invert(quotient), g2)
             # (templateLogicSigBLS12_381.go:364-371)
-            assert cv.name == "bls12-381", "the plain-Python pairing exists for BLS12-381 only"
-            from .pairing_bls12381 import pairing_check
+            if cv.name == "bls12-381":
+                from .pairing_bls12381 import pairing_check
+            else:
+                from .pairing_bn254 import pairing_check   # templateLogicSigBN254.go:350-355
             return pairing_check([digest, cv.neg(quotient)], [vk.g2[0], vk.g2[1]])
         if vk.tau is None:
             raise NotImplementedError("no tau and no G2 points: cannot finish the verification")

@@ -209,6 +209,15 @@ def test_full_size_proof_is_accepted_by_the_transcribed_verifier(gpu, cname, log
     assert oplonk.verify(ovk, blob, pib)
     bad = bytearray(blob); bad[400] ^= 1
     assert not oplonk.verify(ovk, bytes(bad), pib)
+    # and with the template's real last line: ec.pairing_check against G2 = ([1]G2, [tau]G2)
+    import dataclasses
+    if cname == "bn254":
+        from oracle import pairing_bn254 as pr
+    else:
+        from oracle import pairing_bls12381 as pr
+    ovk_pairing = dataclasses.replace(ovk, tau=None, g2=(pr.G2_GEN, pr.g2_mul(pr.G2_GEN, wl.tau)))
+    assert oplonk.verify(ovk_pairing, blob, pib)
+    assert not oplonk.verify(ovk_pairing, bytes(bad), pib)
     # MSM linearity at full size: msm(a) + msm(b) == msm(a + b)
     a = wl.solution[: n]; b = wl.solution[1: n + 1]
     assert ov.add(pk.msm(a), pk.msm(b)) == pk.msm([(x + y) % cv.r for x, y in zip(a, b)])

@@ -117,11 +117,26 @@ def test_pairing_and_g2_decoding_against_reference_expectations():
     assert not pr.pairing_check([tau_g1, cv.neg(cv.mul(cv.g1, 2))], [g20, g21])
 
 
-def test_verifier_with_real_pairing_agrees_with_known_tau_shortcut():
-    """The transcription's last line, ec.pairing_check (templateLogicSigBLS12_381.go:366-371), run for real."""
-    from oracle import pairing_bls12381 as pr
+def test_bn254_g2_decoding_and_pairing():
+    """setup/trusted_setup_test.go:22-40: the PPoT vk.bin starts with the BN254 G2 generator; bilinearity of the pairing."""
+    from oracle import pairing_bn254 as pr
+    cv = oc.BN254
+    vk = open(os.path.join(G, "PerpetualPowersOfTauBN254.vk.bin"), "rb").read()
+    g20, g21 = pr.g2_decompress(vk[:64]), pr.g2_decompress(vk[64:128])
+    assert g20 == pr.G2_GEN and pr.g2_on_curve(g21) and g21 != g20
+    assert pr.pairing_check([cv.mul(cv.g1, 7), cv.neg(cv.mul(cv.g1, 77))], [pr.g2_mul(pr.G2_GEN, 11), pr.G2_GEN])
+    assert not pr.pairing_check([cv.mul(cv.g1, 7), cv.neg(cv.mul(cv.g1, 78))], [pr.g2_mul(pr.G2_GEN, 11), pr.G2_GEN])
+
+
+@pytest.mark.parametrize("cv", [oc.BN254, oc.BLS12_381])
+def test_verifier_with_real_pairing_agrees_with_known_tau_shortcut(cv):
+    """The transcription's last line, ec.pairing_check (templateLogicSigBN254.go:350-355,
+    templateLogicSigBLS12_381.go:366-371), run for real."""
+    if cv is oc.BN254:
+        from oracle import pairing_bn254 as pr
+    else:
+        from oracle import pairing_bls12381 as pr
     import dataclasses
-    cv = oc.BLS12_381
     c, sol = ocircuits.pythagorean(cv)
     tau = tau_from_seed(77, cv.r)
     pk = oplonk.setup(c, oplonk.synthetic_srs(cv, c.domain_size(), tau, materialize=False))
