@@ -93,10 +93,12 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, cons
             // twiddle exponent: (index mod 2^t) * N / 2^(t+1)
             uint32_t imod = (low << a.t0) | (g & lomask);
             uint32_t tidx = imod << (a.log_n - 1 - t);
-            Fr w = tw[tidx];
             uint32_t e0 = (mid0 << clog) | c, e1 = (mid1 << clog) | c;
             Fr u = sm[e0];
-            Fr v = sm[e1] * w;
+            Fr v = sm[e1];
+            // skip the product for the unit twiddle (all of stage 0) and for zero operands (the first two stages of
+            // the zero-padded 4n transforms: their upper three quarters are zero) - both are wave-uniform in practice
+            if (tidx != 0 && !v.is_zero()) v = v * tw[tidx];
             sm[e0] = u + v;
             sm[e1] = u - v;
         }
