@@ -191,3 +191,34 @@ def test_frontend_trace_matches_oracle_trace():
         assert (tr.ql, tr.qr, tr.qm, tr.qo, tr.qk, tr.perm) == (otr2.ql, otr2.qr, otr2.qm, otr2.qo, otr2.qk, otr2.S)
         assert (L, R, O) == oplonk.solve_lro(o2, sol)
         assert oplonk.check_gates(o2, otr2, L, R, O, sol[:2])
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12-381"])
+def test_frontend_commit_path_against_the_oracle(cname):
+    """Host logic only: the product's frontend (Commit / AssertIsDifferent, closure-free workload solver, qcp columns,
+    commitment indexes) produces a constraint system + witness that the oracle proves and the transcribed verifier accepts."""
+    from algoplonk_amd import workloads
+    from oracle.prng import tau_from_seed
+    cv, ov = CURVES[cname]
+    ccs, w, bl, tau = workloads.random_circuit_bsb22(cv, 6, 0xA193, nb_commitments=2, committed=3)
+    n = ccs.domain_size()
+    assert n == 64 and len(ccs.commitments) == 2
+    tr = frontend.build_trace(ccs)
+    assert len(tr.qcp) == 2 and all(sum(q) == 3 for q in tr.qcp)
+    oc_ = oplonk.Circuit(ov, ccs.GetNbPublicVariables(), ccs.nb_variables, list(ccs.constraints),
+                         [oplonk.Commitment(list(rows), cidx) for rows, cidx in ccs.commitments])
+    osrs = oplonk.synthetic_srs(ov, n, tau, materialize=False)
+    opk = oplonk.setup(oc_, osrs)
+    otr = opk.trace
+    assert (tr.ql, tr.qr, tr.qm, tr.qo, tr.qk, tr.perm, tr.qcp) == (otr.ql, otr.qr, otr.qm, otr.qo, otr.qk, otr.S, otr.qcp)
+    wn = ov.omega(n)
+    pi2 = []
+    hiding = [(5, 6), (7, 8)]
+    sol = frontend.solve(ccs, w, lambda col: oplonk.hash_fr(ov.raw_bytes(osrs.commit(oplonk.intt(col, wn, cv.r))), cv.r), hiding, pi2)
+    L, R, O = frontend.wire_columns(ccs, sol)
+    assert (L, R, O) == oplonk.solve_lro(oc_, sol)
+    pr = oplonk.prove(opk, L, R, O, w.public, bl, pi2=pi2)
+    blob, pib = oplonk.marshal_proof(ov, pr), oplonk.marshal_public_inputs(w.public)
+    assert oplonk.verify(opk.vk, blob, pib)
+    with pytest.raises(ValueError, match="commitment hint"):
+        frontend.solve(ccs, w)
