@@ -153,6 +153,24 @@ static int g1_op_t(int op, const void* p, const void* q, void* out) {
             r = acc.to_affine();
             break;
         }
+        case 12: case 13: {  // a fixed chain of signed mixed additions through every special case: lazy (12) / plain (13)
+            using XU = XYZZ<FPP, FeU<FPP>>;
+            memcpy(&b, q, sizeof b);
+            const Affine<FPP, FeU<FPP>> pa = unpack_affine<FPP>(to_table_record<FPP>(a)), pb = unpack_affine<FPP>(to_table_record<FPP>(b)),
+                                        pinf = Affine<FPP, FeU<FPP>>::inf();
+            // a, 2a (doubling), a, inf (cancellation), b, 2b, 2b+a, 3b+a, 3b, 2b, b, skip, a+b, a+2b, a+3b, 3b, a+3b
+            static const int script[17][2] = {{0, 0}, {0, 0}, {0, 1}, {0, 1}, {1, 0}, {1, 0}, {0, 0}, {1, 0}, {0, 1}, {1, 1}, {1, 1},
+                                              {2, 0}, {0, 0}, {1, 0}, {1, 0}, {0, 1}, {0, 0}};
+            XU acc = XU::inf();
+            bool flipped = false;
+            for (const auto& st : script) {
+                const auto& pt = st[0] == 0 ? pa : st[0] == 1 ? pb : pinf;
+                if (op == 12) acc.madd_lazy(pt, st[1] != 0, flipped); else acc.madd(pt, st[1] != 0);
+            }
+            if (op == 12) acc.finish_lazy(flipped);
+            r = to_fe_point<FPP>(acc).to_affine();
+            break;
+        }
         case 10: case 11: {  // mixed (10) / full (11) addition in the unsaturated-limb representation
             using XU = XYZZ<FPP, FeU<FPP>>;
             memcpy(&b, q, sizeof b);

@@ -109,6 +109,57 @@ struct XYZZ {
         ZZZ = ZZZ * PPP;
     }
 
+    // ---- the bucket-accumulation loop's form of madd (FT = FeU only; ffu.h "lazy forms") ------------------------------
+    // Same formulas, but no conditional subtraction anywhere: differences add a multiple of p, products skip the final
+    // reduction, and Y3 = R*(Q - X3) - Y*PPP is taken as -(R*(X3 - Q) + Y*PPP) with ONE Montgomery reduction for both
+    // products - so every call flips the sign of the point the state stands for (`flipped`), and the next call adds -q
+    // instead of q: -(A) + -(q) = -(A + q).  Bounds kept between calls, in units of p (R'/p >= 160, so a product of
+    // operands below a*p and b*p is below (1 + a*b/160)*p):  X < 5.1, Y < 1.2, ZZ, ZZZ < 1.1; inside: P < 7.1, R < 3.1,
+    // PP < 1.4, PPP, Q < 1.1, X3 < R^2 + 4 < 5.1, T < 7.1, Y3 < 1 + (3.1*7.1 + 1.2*1.1)/160.  finish_lazy() brings the
+    // state back to canonical limbs and the true sign, so the result is limb-for-limb what madd() gives.
+    APK_HD void madd_lazy(const Aff& q, bool negate, bool& flipped) {
+        if (q.is_inf()) return;
+        const bool ng = negate != flipped;
+        if (is_inf()) {
+            X = q.x; Y = negate ? F::neg(q.y) : q.y; ZZ = F::one(); ZZZ = F::one();
+            flipped = false;
+            return;
+        }
+        const F qy = ng ? F::template neg_k<1>(q.y) : q.y;
+        const F U2 = F::mul_nr(q.x, ZZ);
+        const F S2 = F::mul_nr(qy, ZZZ);
+        const F Pd = F::template sub_k<6>(U2, X);
+        const F R = F::template sub_k<2>(S2, Y);
+        const F PP = F::sqr_nr(Pd);
+        if (PP.l[0] == 0u || PP.l[0] == FP::umod(0)) {   // cheap filter; P = 0 mod p <=> PP in {0, p}
+            if (PP.is_zero_mod_p()) {
+                if (F::template canon<2>(R).is_zero()) {
+                    *this = dbl_affine(Aff{q.x, ng ? F::neg(q.y) : q.y});   // state == q: 2q in the same sign frame
+                } else {
+                    *this = inf();
+                    flipped = false;
+                }
+                return;
+            }
+        }
+        const F PPP = F::mul_nr(Pd, PP);
+        const F Q = F::mul_nr(X, PP);
+        const F X3 = F::template sub2_k<4>(F::sqr_nr(R), PPP, Q);
+        const F T = F::template sub_k<2>(X3, Q);
+        Y = F::mul2_nr(R, T, Y, PPP);
+        X = X3;
+        ZZ = F::mul_nr(ZZ, PP);
+        ZZZ = F::mul_nr(ZZZ, PPP);
+        flipped = !flipped;
+    }
+    APK_HD void finish_lazy(bool flipped) {
+        X = F::template canon<4>(X);
+        Y = F::template canon<1>(Y);
+        ZZ = F::template canon<1>(ZZ);
+        ZZZ = F::template canon<1>(ZZZ);
+        if (flipped) Y = F::neg(Y);
+    }
+
     // this += q
     APK_HD void add(const XYZZ& q) {
         if (q.is_inf()) return;

@@ -118,8 +118,9 @@ struct FeU {
 
     // Montgomery product a*b/R' mod p, product scanning.  Column k collects a_i*b_(k-i) and m_i*p_(k-i): at most 2L
     // products below 2^(2B) plus a carry below 2^(64-B) - no overflow, no carry flag.  Inputs canonical; the result
-    // is below p + p*p/R' < 2p and is brought to [0, p) by one conditional subtraction.
-    APK_HD static FeU mul(const FeU& a, const FeU& b) {
+    // is below p + p*p/R' < 2p and is brought to [0, p) by one conditional subtraction (left out by mul_nr, see the
+    // lazy forms below).
+    APK_HD static FeU mul_nr(const FeU& a, const FeU& b) {
         uint32_t m[L];
         FeU r;
         uint64_t acc = 0;
@@ -143,11 +144,12 @@ struct FeU {
             acc >>= B;
         }
         r.l[L - 1] = (uint32_t)acc;
-        return reduce_once(r);
+        return r;
     }
+    APK_HD static FeU mul(const FeU& a, const FeU& b) { return reduce_once(mul_nr(a, b)); }
 
     // a*a/R': the off-diagonal partial products are taken once against 2a (L*(L+1)/2 mads instead of L*L)
-    APK_HD static FeU sqr(const FeU& a) {
+    APK_HD static FeU sqr_nr(const FeU& a) {
         uint32_t m[L], d[L];
         FeU r;
 #pragma unroll
@@ -175,7 +177,131 @@ struct FeU {
             acc >>= B;
         }
         r.l[L - 1] = (uint32_t)acc;
-        return reduce_once(r);
+        return r;
+    }
+    APK_HD static FeU sqr(const FeU& a) { return reduce_once(sqr_nr(a)); }
+
+    // ---- lazy forms: the bucket-accumulation inner loop (ec.h XYZZ::madd_lazy) --------------------------------------
+    // R'/p is large (BN254: 169, BLS12-381: 2520), so a Montgomery product of operands below A*p and C*p comes out
+    // below p*(1 + A*C*p/R') < 2p without the conditional subtraction as long as A*C <= HEADROOM, and a difference can
+    // be kept positive by adding a multiple of p instead of testing for a borrow.  Values are then only congruent mod p
+    // (still with every limb but the top one below 2^B); canon<K>() brings them back.  Column sums stay below 2^64:
+    // 2L products of limbs below 2^B plus L of m*p, or L products with one operand's limbs below 2^(B+1).
+    static constexpr uint32_t HEADROOM = 160;
+    static_assert(((uint64_t)P::umod(L - 1) + 1) * HEADROOM <= (1ull << B), "R'/p too small for the lazy forms");
+    static_assert((uint64_t)(3 * L + 1) <= (1ull << (64 - 2 * B)), "column sums of mul2_nr must fit 64 bits");
+
+    // limb i of K*p, normalised (the top limb keeps the excess)
+    template <uint32_t K>
+    APK_HD static constexpr uint32_t kp(int i) {
+        uint64_t carry = 0;
+        uint32_t limb = 0;
+        for (int j = 0; j <= i; j++) {
+            uint64_t t = (uint64_t)K * P::umod(j) + carry;
+            limb = j == L - 1 ? (uint32_t)t : (uint32_t)(t & MASK);
+            carry = t >> B;
+        }
+        return limb;
+    }
+
+    // a - b + K*p through a signed carry sweep: no comparison, limbs come out normalised.  Needs b <= K*p as values and
+    // limbs below 2^30; the result is below a + K*p.
+    template <uint32_t K>
+    APK_HD static FeU sub_k(const FeU& a, const FeU& b) {
+        FeU r;
+        int32_t carry = 0;
+#pragma unroll
+        for (int i = 0; i < L; i++) {
+            int32_t t = (int32_t)(a.l[i] - b.l[i] + kp<K>(i)) + carry;
+            carry = t >> B;   // arithmetic shift: a negative limb borrows from the next one
+            r.l[i] = i == L - 1 ? (uint32_t)t : ((uint32_t)t & MASK);
+        }
+        return r;
+    }
+    // K*p - a
+    template <uint32_t K>
+    APK_HD static FeU neg_k(const FeU& a) {
+        FeU r;
+        int32_t carry = 0;
+#pragma unroll
+        for (int i = 0; i < L; i++) {
+            int32_t t = (int32_t)(kp<K>(i) - a.l[i]) + carry;
+            carry = t >> B;
+            r.l[i] = i == L - 1 ? (uint32_t)t : ((uint32_t)t & MASK);
+        }
+        return r;
+    }
+    // a - b - 2c + K*p, same conventions (needs b + 2c <= K*p)
+    template <uint32_t K>
+    APK_HD static FeU sub2_k(const FeU& a, const FeU& b, const FeU& c) {
+        FeU r;
+        int32_t carry = 0;
+#pragma unroll
+        for (int i = 0; i < L; i++) {
+            int32_t t = (int32_t)(a.l[i] - ((c.l[i] << 1) + b.l[i]) + kp<K>(i)) + carry;
+            carry = t >> B;
+            r.l[i] = i == L - 1 ? (uint32_t)t : ((uint32_t)t & MASK);
+        }
+        return r;
+    }
+
+    // (a*b + c*d)/R' with ONE Montgomery reduction; below p + (a*b + c*d)/R'
+    APK_HD static FeU mul2_nr(const FeU& a, const FeU& b, const FeU& c, const FeU& d) {
+        uint32_t m[L];
+        FeU r;
+        uint64_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < L; k++) {
+#pragma unroll
+            for (int i = 0; i <= k; i++) {
+                acc += (uint64_t)a.l[i] * b.l[k - i];
+                acc += (uint64_t)c.l[i] * d.l[k - i];
+            }
+#pragma unroll
+            for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::umod(k - i);
+            m[k] = ((uint32_t)acc * P::UINV) & MASK;
+            acc += (uint64_t)m[k] * P::umod(0);
+            acc >>= B;
+        }
+#pragma unroll
+        for (int k = L; k < 2 * L - 1; k++) {
+#pragma unroll
+            for (int i = k - L + 1; i < L; i++) {
+                acc += (uint64_t)a.l[i] * b.l[k - i];
+                acc += (uint64_t)c.l[i] * d.l[k - i];
+            }
+#pragma unroll
+            for (int i = k - L + 1; i < L; i++) acc += (uint64_t)m[i] * P::umod(k - i);
+            r.l[k - L] = (uint32_t)acc & MASK;
+            acc >>= B;
+        }
+        r.l[L - 1] = (uint32_t)acc;
+        return r;
+    }
+
+    // value below 2K*p (K a power of two), limbs normalised -> [0, p)
+    template <uint32_t K>
+    APK_HD static FeU canon(const FeU& a) {
+        FeU d;
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < L; i++) {
+            uint32_t t = a.l[i] - kp<K>(i) - borrow;
+            borrow = t >> 31;
+            d.l[i] = i == L - 1 ? t : (t & MASK);
+        }
+        FeU r;
+#pragma unroll
+        for (int i = 0; i < L; i++) r.l[i] = borrow ? a.l[i] : d.l[i];
+        if constexpr (K > 1) return canon<K / 2>(r);
+        else return r;
+    }
+    // for a value below 2p with normalised limbs: is it 0 mod p?
+    APK_HD bool is_zero_mod_p() const {
+        uint32_t z = 0, e = 0;
+#pragma unroll
+        for (int i = 0; i < L; i++) { z |= l[i]; e |= l[i] ^ P::umod(i); }
+        return z == 0 || e == 0;
     }
 
     // ---- packed (saturated, N x 32-bit) <-> limbs.  The packed form is what sits in HBM (tables, results). ----

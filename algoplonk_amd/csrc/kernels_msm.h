@@ -201,12 +201,15 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const Affine<FP>* _
     const uint32_t beg = offsets[k] + slice * MSM_UNIT;
     const uint32_t end = min(beg + MSM_UNIT, offsets[k + 1]);
     // table records are packed R'-domain words: unpack to unsaturated limbs, accumulate carry-free (ffu.h)
+    // (madd_lazy: no conditional subtractions inside the loop, canonical limbs again after finish_lazy - ec.h)
     XYZZ<FP, FeU<FP>> acc = XYZZ<FP, FeU<FP>>::inf();
+    bool flipped = false;
     for (uint32_t e = beg; e < end; e++) {
         uint32_t v = sorted[e];
         Affine<FP> rec = table[v & 0x7fffffffu];
-        acc.madd(unpack_affine<FP>(rec), (v >> 31) != 0);
+        acc.madd_lazy(unpack_affine<FP>(rec), (v >> 31) != 0, flipped);
     }
+    acc.finish_lazy(flipped);
     partial[u] = acc;
 }
 

@@ -164,7 +164,9 @@ int apk_hash_fr(int curve, const void* g1_affine, void* out_fr);
 /* ---- diagnostics: run the library's own field / curve templates on the HOST (no GPU).  The kernels are built
  * from the same templates, so the CPU-only test tier can pin the formulas against the oracle.
  * field ops: 0 add, 1 sub, 2 mul (Montgomery), 3 inverse, 4 neg.  field: 0 = Fr, 1 = Fp.
- * g1 ops: 0 mixed add p+q, 1 full XYZZ add p+q, 2 double p, 3 scalar mul q*p (q = Fr Montgomery). */
+ * g1 ops: 0 mixed add p+q, 1 full XYZZ add p+q, 2 double p, 3 scalar mul q*p (q = Fr Montgomery); 10/11 = 0/1 on the
+ * MSM's unsaturated limbs; 12/13 = a fixed 17-step signed chain ending at p+3q through the accumulate loop's lazy
+ * mixed addition / the plain one. */
 int apk_host_fe_op(int curve, int field, int op, const void* a, const void* b, void* out);
 int apk_host_g1_op(int curve, int op, const void* p, const void* q, void* out);
 
