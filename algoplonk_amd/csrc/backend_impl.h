@@ -341,7 +341,7 @@ class CurveBackend : public Backend {
         CHK(s.cl.alloc(fn3)); CHK(s.cr.alloc(fn3)); CHK(s.co.alloc(fn3)); CHK(s.cz.alloc(fn3));
         CHK(s.qk_lag.alloc(fn)); CHK(s.qk_can.alloc(fn));
         CHK(s.ratio.alloc(fn)); CHK(s.zlag.alloc(fn));
-        CHK(s.scan_tot.alloc((size_t)(cdiv(n_ + 4, SCAN_BLOCK) + 1) * sizeof(Fr)));
+        CHK(s.scan_tot.alloc((size_t)(2 * (cdiv(n_ + 4, SCAN_BLOCK) + 1) + 2) * sizeof(Fr)));
         CHK(s.el.alloc(f4)); CHK(s.er.alloc(f4)); CHK(s.eo.alloc(f4)); CHK(s.ez.alloc(f4)); CHK(s.eqk.alloc(f4));
         CHK(s.quot.alloc(f4)); CHK(s.hcan.alloc(f4));
         CHK(s.pw_z.alloc(fn3)); CHK(s.pw_zi.alloc(fn3)); CHK(s.pw_zw.alloc(fn3)); CHK(s.pw_zwi.alloc(fn3));
@@ -885,10 +885,19 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     const Fr beta_u = beta * shift_, beta_u2 = beta_u * shift_;
 
     // ---------------- round 2: grand product Z -------------------------------------------
-    gp_ratio_kernel<FRP><<<cdiv(cdiv(n, GP_CHUNK), POLY_THREADS), POLY_THREADS, 0, st>>>(
-        dL, dR, dO, ptr<Fr>(s_lag_[0]), ptr<Fr>(s_lag_[1]), ptr<Fr>(s_lag_[2]), ptr<Fr>(tw_n_), n, beta, gamma, beta_u, beta_u2, ptr<Fr>(s.ratio));
-    KCHK();
-    CHK(scan_inplace(st, ptr<Fr>(s.ratio), n, false, true, ptr<Fr>(s.scan_tot), ptr<Fr>(s.zlag), 1));
+    {
+        const uint32_t nb = cdiv(n, SCAN_BLOCK);
+        GpScan<FRP> g{};
+        g.data[0] = ptr<Fr>(s.ratio); g.data[1] = ptr<Fr>(s.tmp);
+        g.tot[0] = ptr<Fr>(s.scan_tot); g.tot[1] = ptr<Fr>(s.scan_tot) + nb + 1;
+        gp_terms_kernel<FRP><<<cdiv(n, POLY_THREADS), POLY_THREADS, 0, st>>>(
+            dL, dR, dO, ptr<Fr>(s_lag_[0]), ptr<Fr>(s_lag_[1]), ptr<Fr>(s_lag_[2]), ptr<Fr>(tw_n_), n, beta, gamma, beta_u, beta_u2,
+            g.data[0], g.data[1]);
+        KCHK();
+        gp_scan_block_kernel<FRP><<<dim3(nb, 2), POLY_THREADS, 0, st>>>(g, n); KCHK();
+        gp_scan_totals_kernel<FRP><<<2, POLY_THREADS, 0, st>>>(g, nb); KCHK();
+        gp_finish_kernel<FRP><<<cdiv(n, POLY_THREADS), POLY_THREADS, 0, st>>>(g, n, nb, ptr<Fr>(s.zlag)); KCHK();
+    }
     HIPCHK(hipMemsetAsync(ptr<Fr>(s.cz) + n, 0, 4 * sizeof(Fr), st));
     CHK(inv_ntt_n(st, ptr<Fr>(s.zlag), ptr<Fr>(s.cz)));
     {

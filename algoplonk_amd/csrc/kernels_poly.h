@@ -43,46 +43,25 @@ __global__ void mul_kernel(Fe<FR>* out, const Fe<FR>* a, const Fe<FR>* b, uint32
 }
 
 // ---- grand product ------------------------------------------------------------------------------------------
-// ratio[i] = prod_j (w_j[i] + beta*u^j*omega^i + gamma) / prod_j (w_j[i] + beta*S_j[i] + gamma)
-// omega^i comes from the size-n twiddle table (tw[i] for i < n/2, -tw[i-n/2] above).
-// One lane inverts GP_CHUNK denominators with one Kaliski inversion (Montgomery's batching trick).
-constexpr int GP_CHUNK = 2;  // 2: 1024 waves at 2^17 and a short dependent chain around the inversion (8 measured 356 us)
+// Z[0] = 1, Z[k] = prod_{i<k} num_i / den_i with
+//   num_i = prod_j (w_j[i] + beta*u^j*omega^i + gamma),  den_i = prod_j (w_j[i] + beta*S_j[i] + gamma)
+// (omega^i comes from the size-n twiddle table: tw[i] for i < n/2, -tw[i-n/2] above).  No per-row inversion:
+// a forward product scan of num, a reverse product scan of den and ONE field inversion of the total give
+//   Z[k] = (prod_{i<k} num_i) * (prod_{i>=k} den_i) * (prod_i den_i)^-1.
 template <class FR>
-__global__ void __launch_bounds__(POLY_THREADS) gp_ratio_kernel(const Fe<FR>* __restrict__ L, const Fe<FR>* __restrict__ R,
+__global__ void __launch_bounds__(POLY_THREADS) gp_terms_kernel(const Fe<FR>* __restrict__ L, const Fe<FR>* __restrict__ R,
                                                                 const Fe<FR>* __restrict__ O, const Fe<FR>* __restrict__ S1,
                                                                 const Fe<FR>* __restrict__ S2, const Fe<FR>* __restrict__ S3,
                                                                 const Fe<FR>* __restrict__ tw, uint32_t n, Fe<FR> beta,
                                                                 Fe<FR> gamma, Fe<FR> beta_u, Fe<FR> beta_u2,
-                                                                Fe<FR>* __restrict__ ratio) {
+                                                                Fe<FR>* __restrict__ num, Fe<FR>* __restrict__ den) {
     using Fr = Fe<FR>;
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t base = t * GP_CHUNK;
-    if (base >= n) return;
-    Fr num[GP_CHUNK], pre[GP_CHUNK], den[GP_CHUNK];
-    Fr run = Fr::one();
-#pragma unroll
-    for (int k = 0; k < GP_CHUNK; k++) {
-        uint32_t i = base + k;
-        if (i < n) {
-            Fr w = i < n / 2 ? tw[i] : Fr::neg(tw[i - n / 2]);
-            Fr l = L[i] + gamma, r = R[i] + gamma, o = O[i] + gamma;
-            num[k] = (l + beta * w) * (r + beta_u * w) * (o + beta_u2 * w);
-            den[k] = (l + beta * S1[i]) * (r + beta * S2[i]) * (o + beta * S3[i]);
-        } else {
-            num[k] = Fr::one();
-            den[k] = Fr::one();
-        }
-        pre[k] = run;
-        run = run * den[k];
-    }
-    Fr inv = Fr::inv(run);
-#pragma unroll
-    for (int k = GP_CHUNK - 1; k >= 0; k--) {
-        uint32_t i = base + k;
-        Fr dinv = inv * pre[k];
-        inv = inv * den[k];
-        if (i < n) ratio[i] = num[k] * dinv;
-    }
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr w = i < n / 2 ? tw[i] : Fr::neg(tw[i - n / 2]);
+    Fr l = L[i] + gamma, r = R[i] + gamma, o = O[i] + gamma;
+    num[i] = (l + beta * w) * (r + beta_u * w) * (o + beta_u2 * w);
+    den[i] = (l + beta * S1[i]) * (r + beta * S2[i]) * (o + beta * S3[i]);
 }
 
 // ---- generic scans over Fr: op = multiply (grand product) or add (suffix sums for the KZG quotient) ------
@@ -96,8 +75,7 @@ __device__ __forceinline__ uint32_t scan_idx(uint32_t i, uint32_t count, bool re
 
 // phase 1: per-block inclusive scan in place; block totals out
 template <class FR, class OP>
-__global__ void __launch_bounds__(POLY_THREADS) scan_block_kernel(Fe<FR>* __restrict__ data, uint32_t count, bool rev,
-                                                                  Fe<FR>* __restrict__ block_tot) {
+__device__ __forceinline__ void scan_block_body(Fe<FR>* __restrict__ data, uint32_t count, bool rev, Fe<FR>* __restrict__ block_tot) {
     using Fr = Fe<FR>;
     __shared__ Fr sm[POLY_THREADS];
     const uint32_t t = threadIdx.x;
@@ -130,10 +108,16 @@ __global__ void __launch_bounds__(POLY_THREADS) scan_block_kernel(Fe<FR>* __rest
     }
     if (t == POLY_THREADS - 1) block_tot[blockIdx.x] = mine;
 }
+template <class FR, class OP>
+__global__ void __launch_bounds__(POLY_THREADS) scan_block_kernel(Fe<FR>* __restrict__ data, uint32_t count, bool rev,
+                                                                  Fe<FR>* __restrict__ block_tot) {
+    scan_block_body<FR, OP>(data, count, rev, block_tot);
+}
 
 // phase 2: single block, exclusive scan of block totals in place (nblocks <= POLY_THREADS * 64)
+// Returns (in the last thread) the total over all blocks.
 template <class FR, class OP>
-__global__ void __launch_bounds__(POLY_THREADS) scan_totals_kernel(Fe<FR>* __restrict__ tot, uint32_t nblocks) {
+__device__ __forceinline__ Fe<FR> scan_totals_body(Fe<FR>* __restrict__ tot, uint32_t nblocks) {
     using Fr = Fe<FR>;
     __shared__ Fr sm[POLY_THREADS];
     const uint32_t t = threadIdx.x;
@@ -158,6 +142,38 @@ __global__ void __launch_bounds__(POLY_THREADS) scan_totals_kernel(Fe<FR>* __res
         tot[i] = acc;  // exclusive
         acc = OP::apply(acc, x);
     }
+    return acc;
+}
+template <class FR, class OP>
+__global__ void __launch_bounds__(POLY_THREADS) scan_totals_kernel(Fe<FR>* __restrict__ tot, uint32_t nblocks) {
+    scan_totals_body<FR, OP>(tot, nblocks);
+}
+
+// ---- the grand product's pair of scans: blockIdx.y = 0 forward over num, 1 reverse over den ------------------
+template <class FR>
+struct GpScan {
+    Fe<FR>* data[2];
+    Fe<FR>* tot[2];   // tot[1] has one extra slot: the inverse of the product of all denominators
+};
+template <class FR>
+__global__ void __launch_bounds__(POLY_THREADS) gp_scan_block_kernel(GpScan<FR> g, uint32_t count) {
+    scan_block_body<FR, OpMul>(g.data[blockIdx.y], count, blockIdx.y != 0, g.tot[blockIdx.y]);
+}
+template <class FR>
+__global__ void __launch_bounds__(POLY_THREADS) gp_scan_totals_kernel(GpScan<FR> g, uint32_t nblocks) {
+    Fe<FR> total = scan_totals_body<FR, OpMul>(g.tot[blockIdx.x], nblocks);
+    if (blockIdx.x == 1 && threadIdx.x == POLY_THREADS - 1) g.tot[1][nblocks] = Fe<FR>::inv(total);
+}
+// Z[0] = 1; Z[k] = num_prefix_incl[k-1] * den_suffix_incl[k] / den_total
+template <class FR>
+__global__ void __launch_bounds__(POLY_THREADS) gp_finish_kernel(GpScan<FR> g, uint32_t n, uint32_t nblocks, Fe<FR>* __restrict__ z) {
+    using Fr = Fe<FR>;
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    if (k == 0) { z[0] = Fr::one(); return; }
+    Fr np = g.tot[0][(k - 1) / SCAN_BLOCK] * g.data[0][k - 1];
+    Fr ds = g.tot[1][(n - 1 - k) / SCAN_BLOCK] * g.data[1][k];
+    z[k] = np * (ds * g.tot[1][nblocks]);
 }
 
 // phase 3: fold the block prefix in.  `shift` turns the inclusive scan into the exclusive one the grand
