@@ -167,8 +167,28 @@ static int g1_op_t(int op, const void* p, const void* q, void* out) {
                 const auto& pt = st[0] == 0 ? pa : st[0] == 1 ? pb : pinf;
                 if (op == 12) acc.madd_lazy(pt, st[1] != 0, flipped); else acc.madd(pt, st[1] != 0);
             }
-            if (op == 12) acc.finish_lazy(flipped);
+            if (op == 12) { acc.lazy_fix_sign(flipped); acc.canonicalize(); }
             r = to_fe_point<FPP>(acc).to_affine();
+            break;
+        }
+        case 14: {  // lazy full addition / doubling through the special cases: ends at 4p + 6q
+            using XU = XYZZ<FPP, FeU<FPP>>;
+            memcpy(&b, q, sizeof b);
+            const Affine<FPP, FeU<FPP>> pa = unpack_affine<FPP>(to_table_record<FPP>(a)), pb = unpack_affine<FPP>(to_table_record<FPP>(b));
+            XU x1 = XU::dbl_lazy(XU::from_affine(pa));          // 2a
+            x1.add_lazy(XU::from_affine(pb));                    // 2a + b
+            XU x2 = XU::dbl_lazy(XU::dbl_lazy(XU::from_affine(pb)));   // 4b
+            x2.add_lazy(x1);                                     // 2a + 5b
+            XU x3 = x2;
+            x3.add_lazy(x2);                                     // equal operands: 4a + 10b
+            XU x4 = x2; x4.lazy_neg();
+            x3.add_lazy(x4);                                     // 2a + 5b
+            XU x5 = x3; x5.lazy_neg();
+            x3.add_lazy(x5);                                     // cancellation: infinity
+            x3.add_lazy(XU::inf());
+            x3.add_lazy(x1);                                     // 2a + b
+            x3.add_lazy(x2);                                     // 4a + 6b
+            r = to_fe_point<FPP>(x3).to_affine();
             break;
         }
         case 10: case 11: {  // mixed (10) / full (11) addition in the unsaturated-limb representation

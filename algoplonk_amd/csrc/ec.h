@@ -109,14 +109,18 @@ struct XYZZ {
         ZZZ = ZZZ * PPP;
     }
 
-    // ---- the bucket-accumulation loop's form of madd (FT = FeU only; ffu.h "lazy forms") ------------------------------
-    // Same formulas, but no conditional subtraction anywhere: differences add a multiple of p, products skip the final
-    // reduction, and Y3 = R*(Q - X3) - Y*PPP is taken as -(R*(X3 - Q) + Y*PPP) with ONE Montgomery reduction for both
-    // products - so every call flips the sign of the point the state stands for (`flipped`), and the next call adds -q
-    // instead of q: -(A) + -(q) = -(A + q).  Bounds kept between calls, in units of p (R'/p >= 160, so a product of
-    // operands below a*p and b*p is below (1 + a*b/160)*p):  X < 5.1, Y < 1.2, ZZ, ZZZ < 1.1; inside: P < 7.1, R < 3.1,
-    // PP < 1.4, PPP, Q < 1.1, X3 < R^2 + 4 < 5.1, T < 7.1, Y3 < 1 + (3.1*7.1 + 1.2*1.1)/160.  finish_lazy() brings the
-    // state back to canonical limbs and the true sign, so the result is limb-for-limb what madd() gives.
+    // ---- lazy forms used by the MSM kernels (FT = FeU only; ffu.h "lazy forms") -------------------------------------
+    // Same formulas as madd / add / dbl, but no conditional subtraction anywhere: differences add a multiple of p,
+    // products skip the final reduction, and Y3 = A*(B - X3) - C*D is taken as -(A*(X3 - B) + C*D) with ONE Montgomery
+    // reduction for both products.  Points are then held in the LAZY CLASS - limbs normalised, values only congruent:
+    //     X < 5.1p,  Y <= 2p,  ZZ, ZZZ < 1.1p,  infinity <=> ZZ is exactly zero
+    // which every lazy operation maps into itself (R'/p >= 160: a product of operands below a*p and b*p is below
+    // (1 + a*b/160)*p; the bounds of the intermediates are noted per line).  to_fe_point() accepts the class as it is, so
+    // the affine result is bit for bit the one the canonical formulas give.
+
+    // this += +-q for a canonical affine q.  Inside the accumulation loop the negation of Y3 is not paid for: each call
+    // flips the sign of the point the state stands for (`flipped`) and the next call adds -q instead: -(A) + -(q) = -(A+q).
+    // lazy_fix_sign() ends the loop.
     APK_HD void madd_lazy(const Aff& q, bool negate, bool& flipped) {
         if (q.is_inf()) return;
         const bool ng = negate != flipped;
@@ -126,12 +130,12 @@ struct XYZZ {
             return;
         }
         const F qy = ng ? F::template neg_k<1>(q.y) : q.y;
-        const F U2 = F::mul_nr(q.x, ZZ);
-        const F S2 = F::mul_nr(qy, ZZZ);
-        const F Pd = F::template sub_k<6>(U2, X);
-        const F R = F::template sub_k<2>(S2, Y);
-        const F PP = F::sqr_nr(Pd);
-        if (PP.l[0] == 0u || PP.l[0] == FP::umod(0)) {   // cheap filter; P = 0 mod p <=> PP in {0, p}
+        const F U2 = F::mul_nr(q.x, ZZ);                       // < 1.01
+        const F S2 = F::mul_nr(qy, ZZZ);                       // < 1.01
+        const F Pd = F::template sub_k<6>(U2, X);              // < 7.1
+        const F R = F::template sub_k<2>(S2, Y);               // < 3.1
+        const F PP = F::sqr_nr(Pd);                            // < 1.4
+        if (PP.l[0] == 0u || PP.l[0] == FP::umod(0)) {         // cheap filter; P = 0 mod p <=> PP in {0, p}
             if (PP.is_zero_mod_p()) {
                 if (F::template canon<2>(R).is_zero()) {
                     *this = dbl_affine(Aff{q.x, ng ? F::neg(q.y) : q.y});   // state == q: 2q in the same sign frame
@@ -142,22 +146,74 @@ struct XYZZ {
                 return;
             }
         }
-        const F PPP = F::mul_nr(Pd, PP);
-        const F Q = F::mul_nr(X, PP);
-        const F X3 = F::template sub2_k<4>(F::sqr_nr(R), PPP, Q);
-        const F T = F::template sub_k<2>(X3, Q);
-        Y = F::mul2_nr(R, T, Y, PPP);
+        const F PPP = F::mul_nr(Pd, PP);                       // < 1.1
+        const F Q = F::mul_nr(X, PP);                          // < 1.1
+        const F X3 = F::template sub2_k<4>(F::sqr_nr(R), PPP, Q);   // < 1.1 + 4
+        const F T = F::template sub_k<2>(X3, Q);               // < 7.1
+        Y = F::mul2_nr(R, T, Y, PPP);                          // = -Y3, < 1.2
         X = X3;
         ZZ = F::mul_nr(ZZ, PP);
         ZZZ = F::mul_nr(ZZZ, PPP);
         flipped = !flipped;
     }
-    APK_HD void finish_lazy(bool flipped) {
+    APK_HD void lazy_fix_sign(bool flipped) {
+        if (flipped) Y = F::template neg_k<2>(Y);
+    }
+    APK_HD void lazy_neg() { Y = F::template neg_k<2>(Y); }
+    // lazy class -> canonical limbs (tests; to_fe_point does not need it)
+    APK_HD void canonicalize() {
         X = F::template canon<4>(X);
-        Y = F::template canon<1>(Y);
+        Y = F::template canon<2>(Y);
         ZZ = F::template canon<1>(ZZ);
         ZZZ = F::template canon<1>(ZZZ);
-        if (flipped) Y = F::neg(Y);
+    }
+
+    // 2p for p in the lazy class
+    APK_HD static XYZZ dbl_lazy(const XYZZ& p) {
+        if (p.is_inf()) return inf();
+        if (p.Y.l[0] == 0u || p.Y.l[0] == FP::umod(0) || p.Y.l[0] == F::template kp<2>(0)) {   // Y = 0 mod p: a 2-torsion point
+            if (F::template canon<2>(p.Y).is_zero()) return inf();
+        }
+        const F U = F::add_n(p.Y, p.Y);                        // <= 4
+        const F V = F::sqr_nr(U);                              // < 1.1
+        const F W = F::mul_nr(U, V);                           // < 1.1
+        const F S = F::mul_nr(p.X, V);                         // < 1.1
+        const F M = F::triple_n(F::sqr_nr(p.X));               // < 3 * 1.17
+        XYZZ r;
+        r.X = F::template sub2_k<4>(F::sqr_nr(M), F::zero(), S);   // < 1.1 + 4
+        const F T = F::template sub_k<2>(r.X, S);              // < 7.1
+        r.Y = F::template neg_k<2>(F::mul2_nr(M, T, W, p.Y));  // M*(S - X3) - W*Y
+        r.ZZ = F::mul_nr(V, p.ZZ);
+        r.ZZZ = F::mul_nr(W, p.ZZZ);
+        return r;
+    }
+
+    // this += q, both in the lazy class
+    APK_HD void add_lazy(const XYZZ& q) {
+        if (q.is_inf()) return;
+        if (is_inf()) { *this = q; return; }
+        const F U1 = F::mul_nr(X, q.ZZ);                       // < 1.1
+        const F U2 = F::mul_nr(q.X, ZZ);
+        const F S1 = F::mul_nr(Y, q.ZZZ);                      // < 1.1
+        const F S2 = F::mul_nr(q.Y, ZZZ);
+        const F Pd = F::template sub_k<2>(U2, U1);             // < 3.1
+        const F R = F::template sub_k<2>(S2, S1);              // < 3.1
+        const F PP = F::sqr_nr(Pd);                            // < 1.1
+        if (PP.l[0] == 0u || PP.l[0] == FP::umod(0)) {
+            if (PP.is_zero_mod_p()) {
+                if (F::template canon<2>(R).is_zero()) *this = dbl_lazy(q);
+                else *this = inf();
+                return;
+            }
+        }
+        const F PPP = F::mul_nr(Pd, PP);                       // < 1.1
+        const F Q = F::mul_nr(U1, PP);                         // < 1.1
+        const F X3 = F::template sub2_k<4>(F::sqr_nr(R), PPP, Q);   // < 1.1 + 4
+        const F T = F::template sub_k<2>(X3, Q);               // < 7.1
+        Y = F::template neg_k<2>(F::mul2_nr(R, T, S1, PPP));   // R*(Q - X3) - S1*PPP
+        X = X3;
+        ZZ = F::mul_nr(F::mul_nr(ZZ, q.ZZ), PP);
+        ZZZ = F::mul_nr(F::mul_nr(ZZZ, q.ZZZ), PPP);
     }
 
     // this += q

@@ -231,6 +231,29 @@ struct FeU {
         }
         return r;
     }
+    // a + b and 3a with an unsigned carry sweep (limbs normalised again; values just add up)
+    APK_HD static FeU add_n(const FeU& a, const FeU& b) {
+        FeU r;
+        uint32_t carry = 0;
+#pragma unroll
+        for (int i = 0; i < L; i++) {
+            uint32_t t = a.l[i] + b.l[i] + carry;
+            carry = t >> B;
+            r.l[i] = i == L - 1 ? t : (t & MASK);
+        }
+        return r;
+    }
+    APK_HD static FeU triple_n(const FeU& a) {
+        FeU r;
+        uint32_t carry = 0;
+#pragma unroll
+        for (int i = 0; i < L; i++) {
+            uint32_t t = (a.l[i] << 1) + a.l[i] + carry;
+            carry = t >> B;
+            r.l[i] = i == L - 1 ? t : (t & MASK);
+        }
+        return r;
+    }
     // a - b - 2c + K*p, same conventions (needs b + 2c <= K*p)
     template <uint32_t K>
     APK_HD static FeU sub2_k(const FeU& a, const FeU& b, const FeU& c) {

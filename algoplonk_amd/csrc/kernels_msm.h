@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const Affine<FP>* _
     const uint32_t beg = offsets[k] + slice * MSM_UNIT;
     const uint32_t end = min(beg + MSM_UNIT, offsets[k + 1]);
     // table records are packed R'-domain words: unpack to unsaturated limbs, accumulate carry-free (ffu.h)
-    // (madd_lazy: no conditional subtractions inside the loop, canonical limbs again after finish_lazy - ec.h)
+    // (madd_lazy: no conditional subtractions; every XYZZ buffer of the MSM holds points of ec.h's lazy class)
     XYZZ<FP, FeU<FP>> acc = XYZZ<FP, FeU<FP>>::inf();
     bool flipped = false;
     for (uint32_t e = beg; e < end; e++) {
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const Affine<FP>* _
         Affine<FP> rec = table[v & 0x7fffffffu];
         acc.madd_lazy(unpack_affine<FP>(rec), (v >> 31) != 0, flipped);
     }
-    acc.finish_lazy(flipped);
+    acc.lazy_fix_sign(flipped);
     partial[u] = acc;
 }
 
@@ -239,14 +239,14 @@ __global__ void __launch_bounds__(256) msm_combine_kernel(const XYZZ<FP, FeU<FP>
     uint32_t beg = 0, end = 0;
     if (k < total_buckets) { beg = unit_off[k]; end = unit_off[k + 1]; }
     if (end - beg > MSM_HEAVY_UNITS) end = beg;   // skewed bucket: left to msm_combine_heavy_kernel
-    for (uint32_t u = beg + lane; u < end; u += LANES) acc.add(partial[u]);
+    for (uint32_t u = beg + lane; u < end; u += LANES) acc.add_lazy(partial[u]);
     // all lanes of the wave take part in every shuffle; groups with nothing to add see infinities
     const uint32_t n_units = end - beg;
     uint64_t need = __ballot(n_units > 1);
     if (need) {
         for (int d = (int)LANES / 2; d >= 1; d >>= 1) {
             PT o = shfl_down_point<PT>(acc, d, (int)LANES);
-            if (lane < (uint32_t)d && n_units > (uint32_t)d) acc.add(o);
+            if (lane < (uint32_t)d && n_units > (uint32_t)d) acc.add_lazy(o);
         }
     }
     if (k < total_buckets && lane == 0 && unit_off[k + 1] - unit_off[k] <= MSM_HEAVY_UNITS) bucket_sum[k] = acc;
@@ -269,11 +269,11 @@ __global__ void __launch_bounds__(256) msm_combine_heavy_kernel(const XYZZ<FP, F
         const uint32_t beg = unit_off[k], end = unit_off[k + 1];
         if (end - beg <= MSM_HEAVY_UNITS) continue;   // uniform across the block
         PT acc = PT::inf();
-        for (uint32_t u = beg + t; u < end; u += 256) acc.add(partial[u]);
+        for (uint32_t u = beg + t; u < end; u += 256) acc.add_lazy(partial[u]);
         sm[t] = acc;
         __syncthreads();
         for (uint32_t d = 128; d >= 1; d >>= 1) {
-            if (t < d) { PT o = sm[t + d]; acc.add(o); sm[t] = acc; }
+            if (t < d) { PT o = sm[t + d]; acc.add_lazy(o); sm[t] = acc; }
             __syncthreads();
         }
         if (t == 0) bucket_sum[k] = acc;
@@ -298,15 +298,15 @@ __global__ void __launch_bounds__(256) msm_rowcol_kernel(const XYZZ<FP, FeU<FP>>
     const PT* src = bucket_sum + (size_t)m * nb;
     PT acc = PT::inf();
     if (x < rows) {
-        for (uint32_t lo = t; lo < cols; lo += 256) acc.add(src[x * cols + lo]);
+        for (uint32_t lo = t; lo < cols; lo += 256) acc.add_lazy(src[x * cols + lo]);
     } else {
         const uint32_t col = x - rows;
-        for (uint32_t hi = t; hi < rows; hi += 256) acc.add(src[hi * cols + col]);
+        for (uint32_t hi = t; hi < rows; hi += 256) acc.add_lazy(src[hi * cols + col]);
     }
     sm[t] = acc;
     __syncthreads();
     for (uint32_t d = 128; d >= 1; d >>= 1) {
-        if (t < d) { PT o = sm[t + d]; acc.add(o); sm[t] = acc; }
+        if (t < d) { PT o = sm[t + d]; acc.add_lazy(o); sm[t] = acc; }
         __syncthreads();
     }
     if (t == 0) rc[(size_t)m * (rows + cols) + x] = acc;
@@ -325,12 +325,12 @@ __global__ void __launch_bounds__(256) msm_bitsum_kernel(const XYZZ<FP, FeU<FP>>
     PT acc = PT::inf();
     for (uint32_t i = t; i < count; i += 256) {
         const uint32_t weight = which ? i + 1 : i;
-        if ((weight >> bit) & 1u) acc.add(src[i]);
+        if ((weight >> bit) & 1u) acc.add_lazy(src[i]);
     }
     sm[t] = acc;
     __syncthreads();
     for (uint32_t d = 128; d >= 1; d >>= 1) {
-        if (t < d) { PT o = sm[t + d]; acc.add(o); sm[t] = acc; }
+        if (t < d) { PT o = sm[t + d]; acc.add_lazy(o); sm[t] = acc; }
         __syncthreads();
     }
     if (t == 0) bit_partial[((size_t)m * 2 + which) * 32 + bit] = acc;
@@ -349,12 +349,12 @@ __global__ void __launch_bounds__(64) msm_final_kernel(const XYZZ<FP, FeU<FP>>* 
     if (bit < nbits) {
         acc = bit_partial[((size_t)m * 2 + which) * 32 + bit];
         const int dbl = (int)bit + (which == 0 ? cols_log : 0);
-        for (int i = 0; i < dbl; i++) acc = PT::dbl(acc);
+        for (int i = 0; i < dbl; i++) acc = PT::dbl_lazy(acc);
     }
     sm[t] = acc;
     __syncthreads();
     for (uint32_t d = 32; d >= 1; d >>= 1) {
-        if (t < d) { PT o = sm[t + d]; acc.add(o); sm[t] = acc; }
+        if (t < d) { PT o = sm[t + d]; acc.add_lazy(o); sm[t] = acc; }
         __syncthreads();
     }
     if (t == 0) {

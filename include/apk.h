@@ -166,7 +166,7 @@ int apk_hash_fr(int curve, const void* g1_affine, void* out_fr);
  * field ops: 0 add, 1 sub, 2 mul (Montgomery), 3 inverse, 4 neg.  field: 0 = Fr, 1 = Fp.
  * g1 ops: 0 mixed add p+q, 1 full XYZZ add p+q, 2 double p, 3 scalar mul q*p (q = Fr Montgomery); 10/11 = 0/1 on the
  * MSM's unsaturated limbs; 12/13 = a fixed 17-step signed chain ending at p+3q through the accumulate loop's lazy
- * mixed addition / the plain one. */
+ * mixed addition / the plain one; 14 = lazy full additions and doublings ending at 4p+6q. */
 int apk_host_fe_op(int curve, int field, int op, const void* a, const void* b, void* out);
 int apk_host_g1_op(int curve, int op, const void* p, const void* q, void* out);
 

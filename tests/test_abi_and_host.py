@@ -86,7 +86,10 @@ def test_host_field_and_curve_templates_match_oracle(cname):
                            # 12 / 13: the accumulate loop's lazy mixed addition (no conditional subtractions) vs the plain one over
                            # a 17-step signed chain through doubling, cancellation and an infinity input: a + 3b
                            (12, cv.g1_to_bytes(Q), ov.add(P, ov.mul(Q, 3))), (13, cv.g1_to_bytes(Q), ov.add(P, ov.mul(Q, 3))),
-                           (12, cv.g1_to_bytes(P), ov.mul(P, 4)), (12, cv.g1_to_bytes(ov.neg(P)), ov.neg(ov.add(P, P)))):
+                           (12, cv.g1_to_bytes(P), ov.mul(P, 4)), (12, cv.g1_to_bytes(ov.neg(P)), ov.neg(ov.add(P, P))),
+                           # 14: lazy full addition / doubling (equal operands, cancellation, infinity): 4p + 6q
+                           (14, cv.g1_to_bytes(Q), ov.add(ov.mul(P, 4), ov.mul(Q, 6))), (14, cv.g1_to_bytes(P), ov.mul(P, 10)),
+                           (14, cv.g1_to_bytes(ov.neg(P)), ov.neg(ov.add(P, P)))):
             check(lib.apk_host_g1_op(cv.abi, op, cv.g1_to_bytes(P), q, out))
             assert cv.g1_from_bytes(out.raw) == exp, (cname, op)
 
