@@ -132,7 +132,8 @@ class CurveBackend : public Backend {
         DevBuf scratch_in;  // upload staging for primitives
         // MSM workspace
         DevBuf counts, hist, offsets, unit_off, scan_blk, sorted, partial, bucket_sum, rowcol, bit_partial, result, result_xyzz;
-        void* h_pinned = nullptr;  // small pinned staging for results
+        void* h_pinned = nullptr;  // small pinned staging for results: [0,1024) affine, [1024,2048) XYZZ, [2048,4096) scalars
+        uint32_t pending_pts = 0;  // MSM sums waiting in h_pinned for their affine conversion (sync_results)
     };
 
     int curve_ = CURVE_ID;
@@ -153,6 +154,12 @@ class CurveBackend : public Backend {
     DevBuf x4_, l0_4_;
     DevBuf s_lag_[3], ql_c_, qr_c_, qm_c_, qo_c_, qk_c_, s_c_[3], qcp_c_[APK_MAX_COMMITMENTS];
     DevBuf qk_lag_trace_;
+    // Qk completion in the quotient kernel (kernels_poly.h QuotientArgs::nb_inject): trace Qk on the coset, the Lagrange
+    // polynomials of the written rows on the coset, the trace's own values in those rows
+    bool qk_direct_ = false;
+    DevBuf eqk_trace_, inj_tab_[QK_INJECT_MAX];
+    std::vector<uint32_t> inj_row_;
+    std::vector<Fr> inj_trace_val_;
     DevBuf eql_, eqr_, eqm_, eqo_, es_[3], eqcp_[APK_MAX_COMMITMENTS];
     MsmTables tab_can_, tab_lag_;
     Aff vk_pts_[8 + APK_MAX_COMMITMENTS];
@@ -306,10 +313,14 @@ class CurveBackend : public Backend {
         const uint32_t nbits = (uint32_t)cols_log + 1;  // weights <= cols
         msm_bitsum_kernel<FPP><<<dim3(nbits, 2, a.batch), 256, 0, st>>>(ptr<PtU>(s.rowcol), rows, cols, ptr<PtU>(s.bit_partial));
         KCHK();
-        msm_final_kernel<FPP><<<a.batch, 64, 0, st>>>(ptr<PtU>(s.bit_partial), nbits, cols_log, ptr<Aff>(s.result), ptr<Pt>(s.result_xyzz));
+        // the sums leave the device in XYZZ form: the one field inversion of the affine conversion takes a lone GPU lane
+        // ~45 us and the host a few; sync_results() finishes them into h_out (= the slot's pinned buffer)
+        msm_final_kernel<FPP><<<a.batch, 64, 0, st>>>(ptr<PtU>(s.bit_partial), nbits, cols_log, nullptr, ptr<Pt>(s.result_xyzz));
         KCHK();
         if (stats_on_) HIPCHK(hipEventRecord(s.ev1, st));
-        HIPCHK(hipMemcpyAsync(h_out, s.result.p, a.batch * sizeof(Aff), hipMemcpyDeviceToHost, st));
+        (void)h_out;
+        HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(s.h_pinned) + 1024, s.result_xyzz.p, a.batch * sizeof(Pt), hipMemcpyDeviceToHost, st));
+        s.pending_pts = a.batch;
         if (stats_on_) {
             HIPCHK(hipEventSynchronize(s.ev1));
             float tot = 0, acc = 0;
@@ -322,6 +333,16 @@ class CurveBackend : public Backend {
             stats_.msm_accumulate_launches += 1;
             for (uint32_t b = 0; b < a.batch; b++) stats_.msm_pairs += a.len[b];
         }
+        return APK_OK;
+    }
+
+    // stream sync + affine conversion of the MSM sums run_msm left in the pinned buffer (results land at h_pinned[0..])
+    int sync_results(Slot& s) {
+        HIPCHK(hipStreamSynchronize(s.stream));
+        const Pt* g = reinterpret_cast<const Pt*>(reinterpret_cast<const uint8_t*>(s.h_pinned) + 1024);
+        Aff* o = reinterpret_cast<Aff*>(s.h_pinned);
+        for (uint32_t i = 0; i < s.pending_pts; i++) o[i] = g[i].to_affine();
+        s.pending_pts = 0;
         return APK_OK;
     }
 
@@ -591,7 +612,7 @@ class CurveBackend : public Backend {
         MsmBatchArgs a{};
         a.batch = 1; a.scalars[0] = dsc; a.len[0] = (uint32_t)len; a.offset[0] = 0;
         CHK(run_msm(s, T, a, reinterpret_cast<Aff*>(s.h_pinned)));
-        HIPCHK(hipStreamSynchronize(s.stream));
+        CHK(sync_results(s));
         memcpy(out, s.h_pinned, sizeof(Aff));
         return APK_OK;
     }
@@ -736,6 +757,27 @@ int CurveBackend<FRP, FPP, CURVE_ID>::setup_trace(const apk_circuit_desc* d) {
         if (i < 4) { CHK(cos[i]->alloc(f4)); CHK(coset_ntt_4n(st, ptr<Fr>(*can[i]), n_, ptr<Fr>(*cos[i]))); }
         HIPCHK(hipStreamSynchronize(st));
     }
+    // rows of Qk the prover writes per proof: public inputs 0..nb_public-1 and the commitment rows.  With few of them the
+    // completed column never goes through iNTT + coset NTT again: the quotient kernel adds delta_j * L_row_j(x) instead.
+    inj_row_.clear(); inj_trace_val_.clear();
+    for (uint32_t i = 0; i < nb_public_; i++) inj_row_.push_back(i);
+    for (uint32_t k = 0; k < nb_commit_; k++) inj_row_.push_back(nb_public_ + cci_[k]);
+    qk_direct_ = inj_row_.size() <= (size_t)QK_INJECT_MAX && !getenv("APK_QK_NTT");
+    if (qk_direct_) {
+        CHK(eqk_trace_.alloc(f4));
+        CHK(coset_ntt_4n(st, ptr<Fr>(qk_c_), n_, ptr<Fr>(eqk_trace_)));
+        for (size_t j = 0; j < inj_row_.size(); j++) {
+            const uint32_t row = inj_row_[j];
+            if (row >= n_) { set_error("Qk row %u out of range", row); return APK_ERR_ARG; }
+            inj_trace_val_.push_back(reinterpret_cast<const Fr*>(d->qk)[row]);
+            if (row == 0) continue;   // L_0 is l0_4_
+            // L_row(X) = (1/n) sum_i omega^(-row i) X^i
+            CHK(inj_tab_[j].alloc(f4));
+            CHK(powers(st, ptr<Fr>(s.tmp), n_, Fr::pow_u64(omega_inv_, row), n_inv_));
+            CHK(coset_ntt_4n(st, ptr<Fr>(s.tmp), n_, ptr<Fr>(inj_tab_[j])));
+        }
+        HIPCHK(hipStreamSynchronize(st));
+    }
     for (uint32_t k = 0; k < nb_commit_; k++) {
         CHK(qcp_c_[k].alloc(fn)); CHK(eqcp_[k].alloc(f4));
         HIPCHK(hipMemcpyAsync(s.wl.p, d->qcp[k], fn, hipMemcpyHostToDevice, st));
@@ -776,7 +818,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::setup_trace(const apk_circuit_desc* d) {
         a.batch = total - base < MSM_MAX_BATCH ? total - base : MSM_MAX_BATCH;
         for (uint32_t b = 0; b < a.batch; b++) { a.scalars[b] = polys[base + b]; a.len[b] = n_; a.offset[b] = 0; }
         CHK(run_msm(s, tab_can_, a, reinterpret_cast<Aff*>(s.h_pinned)));
-        HIPCHK(hipStreamSynchronize(st));
+        CHK(sync_results(s));
         memcpy(&vk_pts_[base], s.h_pinned, a.batch * sizeof(Aff));
     }
     return APK_OK;
@@ -823,7 +865,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         CHK(run_msm(s, tab_lag_, a, hp));
         CHK(inv_ntt_n(st, ptr<Fr>(s.pi2_lag[k]), ptr<Fr>(s.pi2_can[k])));
         CHK(coset_ntt_4n(st, ptr<Fr>(s.pi2_can[k]), n, ptr<Fr>(s.epi2[k])));
-        HIPCHK(hipStreamSynchronize(st));
+        CHK(sync_results(s));
         bsb[k] = hp[0];
         g1_raw_bytes(bsb[k], bsb_bytes[k]);
         cval[k] = hash_fr_point(bsb_bytes[k], 2 * FPB);
@@ -848,18 +890,20 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         CHK(run_msm(s, tab_can_, a, hp));
     }
     // completed Qk: public inputs and commitment values written into the Lagrange column, then iNTT
-    HIPCHK(hipMemcpyAsync(s.qk_lag.p, qk_lag_trace_.p, fn, hipMemcpyDeviceToDevice, st));
-    if (nb_public_) HIPCHK(hipMemcpyAsync(s.qk_lag.p, pub, (size_t)nb_public_ * sizeof(Fr), hipMemcpyHostToDevice, st));
-    for (uint32_t k = 0; k < nb_commit_; k++)
-        HIPCHK(hipMemcpyAsync(ptr<Fr>(s.qk_lag) + nb_public_ + cci_[k], &cval[k], sizeof(Fr), hipMemcpyHostToDevice, st));
-    CHK(inv_ntt_n(st, ptr<Fr>(s.qk_lag), ptr<Fr>(s.qk_can)));
-    CHK(coset_ntt_4n(st, ptr<Fr>(s.qk_can), n, ptr<Fr>(s.eqk)));
+    if (!qk_direct_) {
+        HIPCHK(hipMemcpyAsync(s.qk_lag.p, qk_lag_trace_.p, fn, hipMemcpyDeviceToDevice, st));
+        if (nb_public_) HIPCHK(hipMemcpyAsync(s.qk_lag.p, pub, (size_t)nb_public_ * sizeof(Fr), hipMemcpyHostToDevice, st));
+        for (uint32_t k = 0; k < nb_commit_; k++)
+            HIPCHK(hipMemcpyAsync(ptr<Fr>(s.qk_lag) + nb_public_ + cci_[k], &cval[k], sizeof(Fr), hipMemcpyHostToDevice, st));
+        CHK(inv_ntt_n(st, ptr<Fr>(s.qk_lag), ptr<Fr>(s.qk_can)));
+        CHK(coset_ntt_4n(st, ptr<Fr>(s.qk_can), n, ptr<Fr>(s.eqk)));
+    }
     {
         Fr* ev[3] = {ptr<Fr>(s.el), ptr<Fr>(s.er), ptr<Fr>(s.eo)};
         const uint32_t lens[3] = {n + 2, n + 2, n + 2};
         CHK(run_ntt_batch(st, 1, false, 3, canon, ev, lens, n4_, ptr<Fr>(coset_pre_), nullptr, nullptr));
     }
-    HIPCHK(hipStreamSynchronize(st));
+    CHK(sync_results(s));
     Aff lro[3] = {hp[0], hp[1], hp[2]};
     for (int j = 0; j < 3; j++) store_pt(out->lro[j], lro[j]);
 
@@ -909,7 +953,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         CHK(run_msm(s, tab_can_, a, hp));
     }
     CHK(coset_ntt_4n(st, ptr<Fr>(s.cz), n + 3, ptr<Fr>(s.ez)));
-    HIPCHK(hipStreamSynchronize(st));
+    CHK(sync_results(s));
     const Aff zcom = hp[0];
     store_pt(out->z, zcom);
     uint8_t z_bytes[2 * FPB];
@@ -926,6 +970,15 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     {
         QuotientArgs<FRP> q{};
         q.l = ptr<Fr>(s.el); q.r = ptr<Fr>(s.er); q.o = ptr<Fr>(s.eo); q.z = ptr<Fr>(s.ez); q.qk = ptr<Fr>(s.eqk);
+        if (qk_direct_) {
+            q.qk = ptr<Fr>(eqk_trace_);
+            q.nb_inject = (int)inj_row_.size();
+            for (size_t j = 0; j < inj_row_.size(); j++) {
+                const Fr written = j < nb_public_ ? pubv[j] : cval[j - nb_public_];
+                q.inj_delta[j] = written - inj_trace_val_[j];
+                q.inj_tab[j] = inj_row_[j] == 0 ? ptr<Fr>(l0_4_) : ptr<Fr>(inj_tab_[j]);
+            }
+        }
         q.ql = ptr<Fr>(eql_); q.qr = ptr<Fr>(eqr_); q.qm = ptr<Fr>(eqm_); q.qo = ptr<Fr>(eqo_);
         q.s1 = ptr<Fr>(es_[0]); q.s2 = ptr<Fr>(es_[1]); q.s3 = ptr<Fr>(es_[2]);
         q.x = ptr<Fr>(x4_); q.l0 = ptr<Fr>(l0_4_);
@@ -944,7 +997,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         // the quotient is a polynomial of degree < 3n+6 iff the witness satisfies the circuit: check the tail
         HIPCHK(hipMemcpyAsync(hfr, ptr<Fr>(s.hcan) + 3 * (n + 2), sizeof(Fr) * ((n4_ - 3 * (n + 2)) < 8 ? (n4_ - 3 * (n + 2)) : 8), hipMemcpyDeviceToHost, st));
     }
-    HIPCHK(hipStreamSynchronize(st));
+    CHK(sync_results(s));
     {
         uint32_t tail = (n4_ - 3 * (n + 2)) < 8 ? (n4_ - 3 * (n + 2)) : 8;
         for (uint32_t i = 0; i < tail; i++)
@@ -974,12 +1027,12 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         ea.count = 5;
         for (uint32_t k = 0; k < nb_commit_; k++) { ea.f[ea.count] = ptr<Fr>(qcp_c_[k]); ea.len[ea.count] = n; ea.count++; }
         CHK(eval_many(s, ea, ptr<Fr>(s.pw_z), hfr));
-        HIPCHK(hipStreamSynchronize(st));
+        CHK(sync_results(s));
         for (int i = 0; i < ea.count; i++) ev[i] = hfr[i];
         EvalArgs<FRP> eb{};
         eb.f[0] = ptr<Fr>(s.cz); eb.len[0] = n + 3; eb.count = 1;
         CHK(eval_many(s, eb, ptr<Fr>(s.pw_zw), hfr));
-        HIPCHK(hipStreamSynchronize(st));
+        CHK(sync_results(s));
     }
     const Fr lz = ev[0], rz = ev[1], oz = ev[2], s1z = ev[3], s2z = ev[4];
     const Fr zshift = hfr[0];
@@ -1014,7 +1067,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         ea.f[0] = ptr<Fr>(s.lin); ea.len[0] = n + 3; ea.count = 1;
         CHK(eval_many(s, ea, ptr<Fr>(s.pw_z), hfr));
     }
-    HIPCHK(hipStreamSynchronize(st));
+    CHK(sync_results(s));
     const Aff lin_com = hp[0], zshift_h = hp[1];
     const Fr lin_z = hfr[0];
     store_pt(out->zshift_h, zshift_h);
@@ -1053,7 +1106,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         a.batch = 1; a.scalars[0] = s.q1.p; a.len[0] = n + 2; a.offset[0] = 0;
         CHK(run_msm(s, tab_can_, a, hp));
     }
-    HIPCHK(hipStreamSynchronize(st));
+    CHK(sync_results(s));
     store_pt(out->batched_h, hp[0]);
     memcpy(out->gamma, &gamma, sizeof(Fr)); memcpy(out->beta, &beta, sizeof(Fr)); memcpy(out->alpha, &alpha, sizeof(Fr));
     memcpy(out->zeta, &zeta, sizeof(Fr)); memcpy(out->gamma_kzg, &gk, sizeof(Fr));

@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(64) msm_final_kernel(const XYZZ<FP, FeU<FP>>* 
     if (t == 0) {
         XYZZ<FP> g = to_fe_point<FP>(acc);  // back to gnark's Montgomery radix
         if (result_xyzz) result_xyzz[m] = g;
-        result[m] = g.to_affine();
+        if (result) result[m] = g.to_affine();
     }
 }
 

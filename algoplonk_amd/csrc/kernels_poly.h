@@ -197,6 +197,7 @@ __global__ void __launch_bounds__(POLY_THREADS) scan_apply_kernel(const Fe<FR>* 
 // ---- quotient numerator on the 4n coset, divided by Z_H ---------------------------------------------------
 // gate + alpha*(Z(wX) prod(w_j + beta S_j + gamma) - Z(X) prod(w_j + beta u^j X + gamma)) + alpha^2 L_0 (Z - 1)
 // (the linearised twin is templateLogicSigBN254.go:203-278).
+constexpr int QK_INJECT_MAX = 6;
 template <class FR>
 struct QuotientArgs {
     const Fe<FR>*l, *r, *o, *z, *qk;                // per proof, 4n evaluations
@@ -205,6 +206,11 @@ struct QuotientArgs {
     const Fe<FR>* qcp[2];
     const Fe<FR>* pi2[2];
     int nb_commit;
+    // Qk completion without transforms: qk(x) = trace_qk(x) + sum_j delta[j] * L_row[j](x) for the few rows the prover writes
+    // (public inputs, BSB22 commitment values); nb_inject = 0 means `qk` already holds the completed column's evaluations
+    int nb_inject;
+    const Fe<FR>* inj_tab[QK_INJECT_MAX];
+    Fe<FR> inj_delta[QK_INJECT_MAX];
     Fe<FR> alpha, beta, gamma, beta_u, beta_u2, alpha2;
     Fe<FR> zh_inv[4];
     uint32_t n4;
@@ -220,6 +226,7 @@ __global__ void __launch_bounds__(POLY_THREADS) quotient_kernel(QuotientArgs<FR>
     Fr zs = a.z[is];
     Fr gate = a.ql[i] * l + a.qr[i] * r + a.qm[i] * (l * r) + a.qo[i] * o + a.qk[i];
     for (int k = 0; k < a.nb_commit; k++) gate = gate + a.qcp[k][i] * a.pi2[k][i];
+    for (int j = 0; j < a.nb_inject; j++) gate = gate + a.inj_delta[j] * a.inj_tab[j][i];
     Fr lg = l + a.gamma, rg = r + a.gamma, og = o + a.gamma;
     Fr x = a.x[i];
     Fr pa = zs * (lg + a.beta * a.s1[i]) * (rg + a.beta * a.s2[i]) * (og + a.beta * a.s3[i]);
