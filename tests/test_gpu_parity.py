@@ -249,6 +249,28 @@ def test_msm_only_context_and_index_range_sharding(gpu, cname):
     assert cv.g1_from_bytes(acc) == ov.mul(ov.g1, oplonk.poly_eval(scalars, tau, cv.r))
 
 
+@pytest.mark.parametrize("cname", ["bn254", "bls12-381"])
+def test_msm_over_degenerate_bases_hits_the_doubling_and_cancellation_paths(gpu, cname):
+    """SRS-shaped bases from tau = 1, -1 and a 4th root of unity repeat the same few points (and their negatives), so a
+    bucket keeps meeting its own sum: the lazy mixed addition's P == Q (doubling) and P == -Q (infinity) branches, and
+    additions into an infinity accumulator, all run on the device.  Expected value: (sum s_i tau^i) * G."""
+    from algoplonk_amd import parallel
+    cv, ov = CURVES[cname]
+    n = 1 << 10
+    g = SplitMix64(0xDE6E)
+    i4 = pow(ov.omega(4), 1, cv.r)
+    for tau in (1, cv.r - 1, i4):
+        srs = ap_setup.unsafe_srs(cv, n, tau, device=gpu)
+        sm = parallel.ShardedMsm(cv, srs.g1, device=gpu, rank=0, world=1)
+        x = g.fr(cv.r)
+        cases = [[g.fr(cv.r) for _ in range(n + 3)], [x] * (n + 3), [x if i % 2 == 0 else cv.r - x for i in range(n + 3)],
+                 [g.below(4) for _ in range(n + 3)], [1] * (n + 3)]
+        for sc in cases:
+            got = cv.g1_from_bytes(sm.partial(cv.fr_vector(sc)))
+            assert got == ov.mul(ov.g1, oplonk.poly_eval(sc, tau, cv.r)), (cname, tau == 1, len(sc))
+        sm.close()
+
+
 class _Bsb22Circuit(frontend.Circuit):
     """bsb22_test.go:18-39."""
     X = frontend.Public()
