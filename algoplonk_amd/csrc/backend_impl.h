@@ -270,7 +270,8 @@ class CurveBackend : public Backend {
         if (G > msm_G_max_) G = msm_G_max_;
         dim3 gd(G, a.batch);
         const size_t lds = (size_t)NB_ * 4;
-        msm_digits_kernel<FRP, false><<<gd, 256, lds, st>>>(a, win_, NB_, T.n_bases, G, ptr<uint32_t>(s.counts), nullptr, nullptr);
+        static const int dth = getenv("APK_MSM_DIGITS_THREADS") ? atoi(getenv("APK_MSM_DIGITS_THREADS")) : MSM_DIGITS_THREADS;
+        msm_digits_kernel<FRP, false><<<gd, dth, lds, st>>>(a, win_, NB_, T.n_bases, G, ptr<uint32_t>(s.counts), nullptr, nullptr);
         KCHK();
         msm_colscan_kernel<0><<<cdiv(total_buckets, 256), 256, 0, st>>>(ptr<uint32_t>(s.counts), NB_, G, total_buckets, ptr<uint32_t>(s.hist));
         KCHK();
@@ -286,7 +287,7 @@ class CurveBackend : public Backend {
                                                                       ptr<uint32_t>(s.unit_off));
             KCHK();
         }
-        msm_digits_kernel<FRP, true><<<gd, 256, lds, st>>>(a, win_, NB_, T.n_bases, G, ptr<uint32_t>(s.counts), ptr<uint32_t>(s.offsets),
+        msm_digits_kernel<FRP, true><<<gd, dth, lds, st>>>(a, win_, NB_, T.n_bases, G, ptr<uint32_t>(s.counts), ptr<uint32_t>(s.offsets),
                                                             ptr<uint32_t>(s.sorted));
         KCHK();
         if (stats_on_) HIPCHK(hipEventRecord(s.ev2, st));

@@ -64,8 +64,9 @@ __device__ __forceinline__ uint32_t window_bits(const uint32_t (&s)[N], int bit,
 //   SCATTER = false : counts[(b*G + g)*nb + k] = entries of slice g of msm b that fall into bucket k
 //   SCATTER = true  : LDS cursors start at offsets[b*nb+k] + (exclusive prefix of counts over g); every entry takes
 //                     the next slot of its bucket with an LDS atomic and is written to `sorted`
+constexpr int MSM_DIGITS_THREADS = 1024;  // per sort workgroup: the slice's LDS atomics and scattered stores are latency-bound
 template <class FR, bool SCATTER>
-__global__ void __launch_bounds__(256) msm_digits_kernel(MsmBatchArgs a, MsmWindows win, uint32_t nb, uint32_t n_max, uint32_t G,
+__global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_digits_kernel(MsmBatchArgs a, MsmWindows win, uint32_t nb, uint32_t n_max, uint32_t G,
                                                          uint32_t* __restrict__ counts,         // [batch][G][nb]
                                                          const uint32_t* __restrict__ offsets,  // SCATTER only
                                                          uint32_t* __restrict__ sorted) {
