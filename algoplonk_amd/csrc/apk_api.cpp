@@ -162,10 +162,10 @@ static int g1_op_t(int op, const void* p, const void* q, void* out) {
             static const int script[17][2] = {{0, 0}, {0, 0}, {0, 1}, {0, 1}, {1, 0}, {1, 0}, {0, 0}, {1, 0}, {0, 1}, {1, 1}, {1, 1},
                                               {2, 0}, {0, 0}, {1, 0}, {1, 0}, {0, 1}, {0, 0}};
             XU acc = XU::inf();
-            bool flipped = false;
+            bool flipped = false, unit_z = false;
             for (const auto& st : script) {
                 const auto& pt = st[0] == 0 ? pa : st[0] == 1 ? pb : pinf;
-                if (op == 12) acc.madd_lazy(pt, st[1] != 0, flipped); else acc.madd(pt, st[1] != 0);
+                if (op == 12) acc.madd_lazy(pt, st[1] != 0, flipped, unit_z); else acc.madd(pt, st[1] != 0);
             }
             if (op == 12) { acc.lazy_fix_sign(flipped); acc.canonicalize(); }
             r = to_fe_point<FPP>(acc).to_affine();

@@ -113,7 +113,7 @@ struct XYZZ {
     // Same formulas as madd / add / dbl, but no conditional subtraction anywhere: differences add a multiple of p,
     // products skip the final reduction, and Y3 = A*(B - X3) - C*D is taken as -(A*(X3 - B) + C*D) with ONE Montgomery
     // reduction for both products.  Points are then held in the LAZY CLASS - limbs normalised, values only congruent:
-    //     X < 5.1p,  Y <= 2p,  ZZ, ZZZ < 1.1p,  infinity <=> ZZ is exactly zero
+    //     X < 5.1p,  Y <= 2p,  ZZ, ZZZ < 1.4p,  infinity <=> ZZ is exactly zero
     // which every lazy operation maps into itself (R'/p >= 160: a product of operands below a*p and b*p is below
     // (1 + a*b/160)*p; the bounds of the intermediates are noted per line).  to_fe_point() accepts the class as it is, so
     // the affine result is bit for bit the one the canonical formulas give.
@@ -121,17 +121,20 @@ struct XYZZ {
     // this += +-q for a canonical affine q.  Inside the accumulation loop the negation of Y3 is not paid for: each call
     // flips the sign of the point the state stands for (`flipped`) and the next call adds -q instead: -(A) + -(q) = -(A+q).
     // lazy_fix_sign() ends the loop.
-    APK_HD void madd_lazy(const Aff& q, bool negate, bool& flipped) {
+    // `unit_z` (in/out): the state is a plain affine point (ZZ = ZZZ = 1, as after the first point of a bucket slice), which
+    // saves the four products by ZZ / ZZZ on the second point.
+    APK_HD void madd_lazy(const Aff& q, bool negate, bool& flipped, bool& unit_z) {
         if (q.is_inf()) return;
         const bool ng = negate != flipped;
         if (is_inf()) {
             X = q.x; Y = negate ? F::neg(q.y) : q.y; ZZ = F::one(); ZZZ = F::one();
             flipped = false;
+            unit_z = true;
             return;
         }
         const F qy = ng ? F::template neg_k<1>(q.y) : q.y;
-        const F U2 = F::mul_nr(q.x, ZZ);                       // < 1.01
-        const F S2 = F::mul_nr(qy, ZZZ);                       // < 1.01
+        const F U2 = unit_z ? q.x : F::mul_nr(q.x, ZZ);        // < 1.01
+        const F S2 = unit_z ? qy : F::mul_nr(qy, ZZZ);         // < 1.01
         const F Pd = F::template sub_k<6>(U2, X);              // < 7.1
         const F R = F::template sub_k<2>(S2, Y);               // < 3.1
         const F PP = F::sqr_nr(Pd);                            // < 1.4
@@ -143,6 +146,7 @@ struct XYZZ {
                     *this = inf();
                     flipped = false;
                 }
+                unit_z = false;
                 return;
             }
         }
@@ -152,9 +156,10 @@ struct XYZZ {
         const F T = F::template sub_k<2>(X3, Q);               // < 7.1
         Y = F::mul2_nr(R, T, Y, PPP);                          // = -Y3, < 1.2
         X = X3;
-        ZZ = F::mul_nr(ZZ, PP);
-        ZZZ = F::mul_nr(ZZZ, PPP);
+        ZZ = unit_z ? PP : F::mul_nr(ZZ, PP);
+        ZZZ = unit_z ? PPP : F::mul_nr(ZZZ, PPP);
         flipped = !flipped;
+        unit_z = false;
     }
     APK_HD void lazy_fix_sign(bool flipped) {
         if (flipped) Y = F::template neg_k<2>(Y);

@@ -204,11 +204,11 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const Affine<FP>* _
     // table records are packed R'-domain words: unpack to unsaturated limbs, accumulate carry-free (ffu.h)
     // (madd_lazy: no conditional subtractions; every XYZZ buffer of the MSM holds points of ec.h's lazy class)
     XYZZ<FP, FeU<FP>> acc = XYZZ<FP, FeU<FP>>::inf();
-    bool flipped = false;
+    bool flipped = false, unit_z = false;
     for (uint32_t e = beg; e < end; e++) {
         uint32_t v = sorted[e];
         Affine<FP> rec = table[v & 0x7fffffffu];
-        acc.madd_lazy(unpack_affine<FP>(rec), (v >> 31) != 0, flipped);
+        acc.madd_lazy(unpack_affine<FP>(rec), (v >> 31) != 0, flipped, unit_z);
     }
     acc.lazy_fix_sign(flipped);
     partial[u] = acc;
