@@ -131,7 +131,7 @@ class CurveBackend : public Backend {
         DevBuf pi2_lag[APK_MAX_COMMITMENTS], pi2_can[APK_MAX_COMMITMENTS], epi2[APK_MAX_COMMITMENTS];
         DevBuf scratch_in;  // upload staging for primitives
         // MSM workspace
-        DevBuf counts, hist, offsets, unit_off, scan_blk, sorted, partial, bucket_sum, rowcol, bit_partial, result, result_xyzz;
+        DevBuf counts, hist, offsets, unit_off, full_off, rem_rank, rem_list, scan_blk, sorted, partial, bucket_sum, rowcol, bit_partial, result, result_xyzz;
         void* h_pinned = nullptr;  // small pinned staging for results: [0,1024) affine, [1024,2048) XYZZ, [2048,4096) scalars
         uint32_t pending_pts = 0;  // MSM sums waiting in h_pinned for their affine conversion (sync_results)
     };
@@ -261,7 +261,9 @@ class CurveBackend : public Backend {
             entries += (uint64_t)a.len[b] * W_;
         }
         const uint32_t total_buckets = a.batch * NB_;
-        const uint32_t max_units = (uint32_t)(entries / MSM_UNIT) + total_buckets;
+        static const uint32_t unit = getenv("APK_MSM_UNIT") ? (uint32_t)atoi(getenv("APK_MSM_UNIT")) : (uint32_t)MSM_UNIT;
+        if (unit < (uint32_t)MSM_UNIT_MIN || unit > (uint32_t)MSM_UNIT_MAX) { set_error("APK_MSM_UNIT out of [%d, %d]", MSM_UNIT_MIN, MSM_UNIT_MAX); return APK_ERR_ARG; }
+        const uint32_t max_units = (uint32_t)(entries / unit) + total_buckets;
         if (stats_on_) HIPCHK(hipEventRecord(s.ev0, st));
         // counting sort by bucket: LDS-private histograms per scalar slice, column scan, bucket scan, scatter
         static const uint32_t slice = getenv("APK_MSM_SLICE") ? (uint32_t)atoi(getenv("APK_MSM_SLICE")) : 2048u;  // scalars per sort workgroup
@@ -277,14 +279,18 @@ class CurveBackend : public Backend {
         KCHK();
         {
             const uint32_t nblk = cdiv(total_buckets, MSM_SCAN_BLOCK);   // <= 1024: total_buckets <= 4 * 2^15... checked at init
-            msm_scan_local_kernel<MSM_UNIT><<<nblk, MSM_SCAN_BLOCK, 0, st>>>(ptr<uint32_t>(s.hist), total_buckets, ptr<uint32_t>(s.offsets),
-                                                                             ptr<uint32_t>(s.unit_off), ptr<uint32_t>(s.scan_blk), nblk);
+            uint32_t* blk_tot = ptr<uint32_t>(s.scan_blk);
+            uint32_t* blk_bins = blk_tot + 3 * nblk;
+            msm_scan_local_kernel<0><<<nblk, MSM_SCAN_BLOCK, 0, st>>>(ptr<uint32_t>(s.hist), total_buckets, unit, ptr<uint32_t>(s.offsets),
+                                                                       ptr<uint32_t>(s.unit_off), ptr<uint32_t>(s.full_off), ptr<uint32_t>(s.rem_rank),
+                                                                       blk_tot, blk_bins, nblk);
             KCHK();
-            msm_scan_totals_kernel<0><<<1, MSM_SCAN_BLOCK, 0, st>>>(ptr<uint32_t>(s.scan_blk), nblk, total_buckets, ptr<uint32_t>(s.offsets),
-                                                                     ptr<uint32_t>(s.unit_off));
+            msm_scan_totals_kernel<0><<<1, MSM_SCAN_BLOCK, 0, st>>>(blk_tot, blk_bins, nblk, total_buckets, ptr<uint32_t>(s.offsets),
+                                                                     ptr<uint32_t>(s.unit_off), ptr<uint32_t>(s.full_off));
             KCHK();
-            msm_scan_apply_kernel<0><<<nblk, MSM_SCAN_BLOCK, 0, st>>>(ptr<uint32_t>(s.scan_blk), nblk, total_buckets, ptr<uint32_t>(s.offsets),
-                                                                      ptr<uint32_t>(s.unit_off));
+            msm_scan_apply_kernel<0><<<nblk, MSM_SCAN_BLOCK, 0, st>>>(blk_tot, blk_bins, ptr<uint32_t>(s.hist), ptr<uint32_t>(s.rem_rank), nblk,
+                                                                      total_buckets, unit, ptr<uint32_t>(s.offsets), ptr<uint32_t>(s.unit_off),
+                                                                      ptr<uint32_t>(s.full_off), ptr<uint32_t>(s.rem_list));
             KCHK();
         }
         msm_digits_kernel<FRP, true><<<gd, dth, lds, st>>>(a, win_, NB_, T.n_bases, G, ptr<uint32_t>(s.counts), ptr<uint32_t>(s.offsets),
@@ -292,13 +298,14 @@ class CurveBackend : public Backend {
         KCHK();
         if (stats_on_) HIPCHK(hipEventRecord(s.ev2, st));
         msm_accumulate_kernel<FPP><<<cdiv(max_units, 128), 128, 0, st>>>(ptr<Aff>(T.table), ptr<uint32_t>(s.sorted), ptr<uint32_t>(s.offsets),
-                                                                        ptr<uint32_t>(s.unit_off), total_buckets, max_units, ptr<PtU>(s.partial));
+                                                                        ptr<uint32_t>(s.unit_off), ptr<uint32_t>(s.full_off), ptr<uint32_t>(s.rem_list),
+                                                                        total_buckets, max_units, unit, ptr<PtU>(s.partial));
         KCHK();
         if (stats_on_) HIPCHK(hipEventRecord(s.ev3, st));
         // lanes per bucket: ~5 unit partials per lane, so the sequential part and the shuffle tree are balanced
         int lanes_log = 0;
         {
-            const uint64_t upb = (entries / MSM_UNIT) / total_buckets + 1;  // unit partials per bucket (estimate)
+            const uint64_t upb = (entries / unit) / total_buckets + 1;  // unit partials per bucket (estimate)
             while ((1u << lanes_log) < MSM_COMBINE_LANES && (upb >> lanes_log) > 5) lanes_log++;
         }
         msm_combine_kernel<FPP><<<cdiv((uint64_t)total_buckets << lanes_log, 256), 256, 0, st>>>(
@@ -381,10 +388,11 @@ class CurveBackend : public Backend {
         const uint32_t tb = batch * NB_;
         CHK(s.hist.alloc((size_t)(tb + 1) * 4)); CHK(s.offsets.alloc((size_t)(tb + 1) * 4));
         CHK(s.unit_off.alloc((size_t)(tb + 1) * 4));
-        CHK(s.scan_blk.alloc((size_t)2 * (cdiv(tb, MSM_SCAN_BLOCK) + 1) * 4));
+        CHK(s.scan_blk.alloc((size_t)(3 + MSM_UNIT_MAX) * (cdiv(tb, MSM_SCAN_BLOCK) + 1) * 4));
+        CHK(s.full_off.alloc((size_t)(tb + 1) * 4)); CHK(s.rem_rank.alloc((size_t)(tb + 1) * 4)); CHK(s.rem_list.alloc((size_t)(tb + 1) * 4));
         CHK(s.counts.alloc((size_t)tb * msm_G_max_ * 4));
         CHK(s.sorted.alloc(entries * 4));
-        CHK(s.partial.alloc((entries / MSM_UNIT + tb) * sizeof(PtU)));
+        CHK(s.partial.alloc((entries / MSM_UNIT_MIN + tb) * sizeof(PtU)));
         CHK(s.bucket_sum.alloc((size_t)tb * sizeof(PtU)));
         {
             const int m_bits = c_ - 1;

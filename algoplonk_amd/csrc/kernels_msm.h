@@ -23,7 +23,10 @@
 namespace apk {
 
 constexpr int MSM_MAX_BATCH = 4;
-constexpr int MSM_UNIT = 16;        // entries per accumulation work unit (8 and 32 measured within 5 % on throughput)
+constexpr int MSM_UNIT = 16;        // entries per full accumulation work unit; a run-time value in the kernels (APK_MSM_UNIT).
+                                    // With the remainder units sorted, 2^17: 16 -> 360, 24 -> 357, 32 -> 349, 64 -> 328 proofs/s
+                                    // (longer units quantise worse over the 1024 SIMDs and halve the lanes of a lone MSM)
+constexpr int MSM_UNIT_MIN = 16, MSM_UNIT_MAX = 64;
 constexpr int MSM_COMBINE_LANES = 16;
 constexpr uint32_t MSM_HEAVY_UNITS = 512;  // unit partials above which a bucket is merged by a whole workgroup
 
@@ -124,59 +127,101 @@ __global__ void __launch_bounds__(256) msm_colscan_kernel(uint32_t* __restrict__
 }
 
 // ---- exclusive scans of the bucket counts: entry offsets and work-unit offsets ------------------------------------------
-// offsets[k] = sum_{i<k} hist[i]; unit_off[k] = sum_{i<k} ceil(hist[i]/UNIT).  Three small launches (a single block took
-// 58 us for 49 k buckets): 1024 counters per block -> block totals -> one block scans the totals -> blocks add their base.
+// A bucket of h entries is cut into floor(h/unit) FULL work units and, if h % unit != 0, one REMAINDER unit.
+//   offsets[k]  = sum_{i<k} hist[i]                 (entries)
+//   unit_off[k] = sum_{i<k} ceil(hist[i]/unit)      (slots of the per-unit partial sums: a bucket's slots are contiguous)
+//   full_off[k] = sum_{i<k} floor(hist[i]/unit)     (lane -> bucket map of the full units)
+//   rem_list    = the buckets that have a remainder unit, sorted by remainder length (descending, counting sort): the
+//                 accumulate kernel runs them after the full units, so the 64 lanes of a wave loop the same number of times
+//                 (interleaved with full units, the remainders idled 6 % of the lanes at unit = 16).
+// Three small launches (a single block took 58 us for 49 k buckets): 1024 counters per block -> block totals -> one block
+// scans the totals -> blocks add their base.
 constexpr int MSM_SCAN_BLOCK = 1024;
 
-template <int UNIT>
-__global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_local_kernel(const uint32_t* __restrict__ hist, uint32_t total,
+template <int DUMMY>
+__global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_local_kernel(const uint32_t* __restrict__ hist, uint32_t total, uint32_t unit,
                                                                          uint32_t* __restrict__ offsets, uint32_t* __restrict__ unit_off,
-                                                                         uint32_t* __restrict__ block_tot /* [2][nblocks] */, uint32_t nblocks) {
+                                                                         uint32_t* __restrict__ full_off, uint32_t* __restrict__ rem_rank,
+                                                                         uint32_t* __restrict__ block_tot /* [3][nblocks] */,
+                                                                         uint32_t* __restrict__ block_bins /* [nblocks][MSM_UNIT_MAX] */, uint32_t nblocks) {
     __shared__ uint32_t s_cnt[MSM_SCAN_BLOCK];
     __shared__ uint32_t s_unit[MSM_SCAN_BLOCK];
+    __shared__ uint32_t s_full[MSM_SCAN_BLOCK];
+    __shared__ uint32_t s_bins[MSM_UNIT_MAX];
     const uint32_t t = threadIdx.x, i = blockIdx.x * MSM_SCAN_BLOCK + t;
-    const uint32_t h = i < total ? hist[i] : 0u, hu = (h + UNIT - 1) / UNIT;
-    s_cnt[t] = h; s_unit[t] = hu;
+    if (t < MSM_UNIT_MAX) s_bins[t] = 0;
+    __syncthreads();
+    const uint32_t h = i < total ? hist[i] : 0u, hf = h / unit, rem = h - hf * unit, hu = hf + (rem ? 1u : 0u);
+    if (rem) rem_rank[i] = atomicAdd(&s_bins[rem], 1u);   // rank of this bucket among the block's buckets with the same remainder
+    s_cnt[t] = h; s_unit[t] = hu; s_full[t] = hf;
     __syncthreads();
     for (uint32_t d = 1; d < MSM_SCAN_BLOCK; d <<= 1) {
-        uint32_t vc = 0, vu = 0;
-        if (t >= d) { vc = s_cnt[t - d]; vu = s_unit[t - d]; }
+        uint32_t vc = 0, vu = 0, vf = 0;
+        if (t >= d) { vc = s_cnt[t - d]; vu = s_unit[t - d]; vf = s_full[t - d]; }
         __syncthreads();
-        s_cnt[t] += vc; s_unit[t] += vu;
+        s_cnt[t] += vc; s_unit[t] += vu; s_full[t] += vf;
         __syncthreads();
     }
-    if (i < total) { offsets[i] = s_cnt[t] - h; unit_off[i] = s_unit[t] - hu; }   // exclusive, block-local
-    if (t == MSM_SCAN_BLOCK - 1) { block_tot[blockIdx.x] = s_cnt[t]; block_tot[nblocks + blockIdx.x] = s_unit[t]; }
+    if (i < total) { offsets[i] = s_cnt[t] - h; unit_off[i] = s_unit[t] - hu; full_off[i] = s_full[t] - hf; }   // exclusive, block-local
+    if (t == MSM_SCAN_BLOCK - 1) {
+        block_tot[blockIdx.x] = s_cnt[t]; block_tot[nblocks + blockIdx.x] = s_unit[t]; block_tot[2 * nblocks + blockIdx.x] = s_full[t];
+    }
+    if (t < MSM_UNIT_MAX) block_bins[blockIdx.x * MSM_UNIT_MAX + t] = s_bins[t];
 }
 
-// one block: exclusive scan of the (<= 1024) block totals in place; grand totals to offsets[total] / unit_off[total]
+// one block: exclusive scan of the (<= 1024) block totals in place; grand totals to offsets[total] / unit_off[total] /
+// full_off[total]; block_bins[blk][r] becomes the first rem_list position of block blk's buckets with remainder r
 template <int DUMMY>
-__global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_totals_kernel(uint32_t* __restrict__ block_tot, uint32_t nblocks, uint32_t total,
-                                                                          uint32_t* __restrict__ offsets, uint32_t* __restrict__ unit_off) {
+__global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_totals_kernel(uint32_t* __restrict__ block_tot, uint32_t* __restrict__ block_bins,
+                                                                          uint32_t nblocks, uint32_t total, uint32_t* __restrict__ offsets,
+                                                                          uint32_t* __restrict__ unit_off, uint32_t* __restrict__ full_off) {
     __shared__ uint32_t s_cnt[MSM_SCAN_BLOCK];
     __shared__ uint32_t s_unit[MSM_SCAN_BLOCK];
+    __shared__ uint32_t s_full[MSM_SCAN_BLOCK];
+    __shared__ uint32_t s_bintot[MSM_UNIT_MAX];
     const uint32_t t = threadIdx.x;
-    const uint32_t h = t < nblocks ? block_tot[t] : 0u, hu = t < nblocks ? block_tot[nblocks + t] : 0u;
-    s_cnt[t] = h; s_unit[t] = hu;
+    const uint32_t h = t < nblocks ? block_tot[t] : 0u, hu = t < nblocks ? block_tot[nblocks + t] : 0u,
+                   hf = t < nblocks ? block_tot[2 * nblocks + t] : 0u;
+    s_cnt[t] = h; s_unit[t] = hu; s_full[t] = hf;
+    if (t < MSM_UNIT_MAX) {   // per remainder length: exclusive prefix over the blocks
+        uint32_t run = 0;
+        for (uint32_t blk = 0; blk < nblocks; blk++) {
+            const uint32_t v = block_bins[blk * MSM_UNIT_MAX + t];
+            block_bins[blk * MSM_UNIT_MAX + t] = run;
+            run += v;
+        }
+        s_bintot[t] = run;
+    }
     __syncthreads();
     for (uint32_t d = 1; d < MSM_SCAN_BLOCK; d <<= 1) {
-        uint32_t vc = 0, vu = 0;
-        if (t >= d) { vc = s_cnt[t - d]; vu = s_unit[t - d]; }
+        uint32_t vc = 0, vu = 0, vf = 0;
+        if (t >= d) { vc = s_cnt[t - d]; vu = s_unit[t - d]; vf = s_full[t - d]; }
         __syncthreads();
-        s_cnt[t] += vc; s_unit[t] += vu;
+        s_cnt[t] += vc; s_unit[t] += vu; s_full[t] += vf;
         __syncthreads();
     }
-    if (t < nblocks) { block_tot[t] = s_cnt[t] - h; block_tot[nblocks + t] = s_unit[t] - hu; }
-    if (t == MSM_SCAN_BLOCK - 1) { offsets[total] = s_cnt[t]; unit_off[total] = s_unit[t]; }
+    if (t < nblocks) { block_tot[t] = s_cnt[t] - h; block_tot[nblocks + t] = s_unit[t] - hu; block_tot[2 * nblocks + t] = s_full[t] - hf; }
+    if (t == MSM_SCAN_BLOCK - 1) { offsets[total] = s_cnt[t]; unit_off[total] = s_unit[t]; full_off[total] = s_full[t]; }
+    if (t < MSM_UNIT_MAX) {   // longest remainders first
+        uint32_t base = 0;
+        for (uint32_t r = MSM_UNIT_MAX - 1; r > t; r--) base += s_bintot[r];
+        for (uint32_t blk = 0; blk < nblocks; blk++) block_bins[blk * MSM_UNIT_MAX + t] += base;
+    }
 }
 
 template <int DUMMY>
-__global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_apply_kernel(const uint32_t* __restrict__ block_tot, uint32_t nblocks, uint32_t total,
-                                                                         uint32_t* __restrict__ offsets, uint32_t* __restrict__ unit_off) {
+__global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_apply_kernel(const uint32_t* __restrict__ block_tot, const uint32_t* __restrict__ block_bins,
+                                                                         const uint32_t* __restrict__ hist, const uint32_t* __restrict__ rem_rank,
+                                                                         uint32_t nblocks, uint32_t total, uint32_t unit,
+                                                                         uint32_t* __restrict__ offsets, uint32_t* __restrict__ unit_off,
+                                                                         uint32_t* __restrict__ full_off, uint32_t* __restrict__ rem_list) {
     const uint32_t i = blockIdx.x * MSM_SCAN_BLOCK + threadIdx.x;
     if (i >= total) return;
     offsets[i] += block_tot[blockIdx.x];
     unit_off[i] += block_tot[nblocks + blockIdx.x];
+    full_off[i] += block_tot[2 * nblocks + blockIdx.x];
+    const uint32_t rem = hist[i] % unit;
+    if (rem) rem_list[block_bins[blockIdx.x * MSM_UNIT_MAX + rem] + rem_rank[i]] = i;
 }
 
 // ---- bucket accumulation: one lane per work unit ---------------------------------------------------------
@@ -185,22 +230,36 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const Affine<FP>* _
                                                              const uint32_t* __restrict__ sorted,
                                                              const uint32_t* __restrict__ offsets,
                                                              const uint32_t* __restrict__ unit_off,
-                                                             uint32_t total_buckets, uint32_t max_units,
+                                                             const uint32_t* __restrict__ full_off,
+                                                             const uint32_t* __restrict__ rem_list,
+                                                             uint32_t total_buckets, uint32_t max_units, uint32_t unit,
                                                              XYZZ<FP, FeU<FP>>* __restrict__ partial) {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= max_units) return;
     const uint32_t total_units = unit_off[total_buckets];
     if (u >= total_units) return;
-    // bucket = last k with unit_off[k] <= u  (empty buckets have unit_off[k] == unit_off[k+1])
-    uint32_t lo = 0, hi = total_buckets;  // invariant: unit_off[lo] <= u < unit_off[hi]
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (unit_off[mid] <= u) lo = mid; else hi = mid;
+    const uint32_t n_full = full_off[total_buckets];
+    uint32_t beg, end, slot;
+    if (u < n_full) {
+        // full unit: bucket = last k with full_off[k] <= u  (buckets without a full unit have full_off[k] == full_off[k+1])
+        uint32_t lo = 0, hi = total_buckets;  // invariant: full_off[lo] <= u < full_off[hi]
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (full_off[mid] <= u) lo = mid; else hi = mid;
+        }
+        const uint32_t slice = u - full_off[lo];
+        beg = offsets[lo] + slice * unit;
+        end = beg + unit;
+        slot = unit_off[lo] + slice;
+    } else {
+        // remainder unit (sorted by length): the tail of its bucket's entries
+        const uint32_t k = rem_list[u - n_full];
+        const uint32_t o0 = offsets[k], o1 = offsets[k + 1];
+        const uint32_t nf = (o1 - o0) / unit;
+        beg = o0 + nf * unit;
+        end = o1;
+        slot = unit_off[k] + nf;
     }
-    const uint32_t k = lo;
-    const uint32_t slice = u - unit_off[k];
-    const uint32_t beg = offsets[k] + slice * MSM_UNIT;
-    const uint32_t end = min(beg + MSM_UNIT, offsets[k + 1]);
     // table records are packed R'-domain words: unpack to unsaturated limbs, accumulate carry-free (ffu.h)
     // (madd_lazy: no conditional subtractions; every XYZZ buffer of the MSM holds points of ec.h's lazy class)
     XYZZ<FP, FeU<FP>> acc = XYZZ<FP, FeU<FP>>::inf();
@@ -211,7 +270,7 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const Affine<FP>* _
         acc.madd_lazy(unpack_affine<FP>(rec), (v >> 31) != 0, flipped, unit_z);
     }
     acc.lazy_fix_sign(flipped);
-    partial[u] = acc;
+    partial[slot] = acc;
 }
 
 template <class PT>
