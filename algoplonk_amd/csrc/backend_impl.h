@@ -168,6 +168,7 @@ class CurveBackend : public Backend {
     std::condition_variable cv_;
     // stats
     bool stats_on_ = false;
+    uint32_t simds_ = 1024;  // SIMDs of the device (4 per CU); set at init
     std::mutex stats_mu_;
     apk_stats stats_{};
 
@@ -261,7 +262,20 @@ class CurveBackend : public Backend {
             entries += (uint64_t)a.len[b] * W_;
         }
         const uint32_t total_buckets = a.batch * NB_;
-        static const uint32_t unit = getenv("APK_MSM_UNIT") ? (uint32_t)atoi(getenv("APK_MSM_UNIT")) : (uint32_t)MSM_UNIT;
+        // Work-unit length: every resident wave of the accumulate kernel loops `unit` times, and the launch lasts as long as the
+        // SIMD that was handed the most waves - so pick the length in [16, 18] whose full-unit waves fill the SIMDs in the fewest
+        // whole rounds (2^17, c = 15, one MSM: 16 -> 2056 waves = 3 rounds on some of the 1024 SIMDs, 17 -> 1930 waves = 2 rounds).
+        // Longer units lose more to fewer resident waves than the round count says (measured: 20..24 are slower than 16).
+        static const uint32_t unit_env = getenv("APK_MSM_UNIT") ? (uint32_t)atoi(getenv("APK_MSM_UNIT")) : 0u;
+        uint32_t unit = unit_env;
+        if (!unit) {
+            uint64_t best = ~0ull;
+            for (uint32_t u = MSM_UNIT; u <= MSM_UNIT + 2; u++) {
+                const uint64_t full_units = entries / u > total_buckets / 2 ? entries / u - total_buckets / 2 : 1;
+                const uint64_t cost = (uint64_t)cdiv(cdiv(full_units, 64), simds_) * u;
+                if (cost < best) { best = cost; unit = u; }
+            }
+        }
         if (unit < (uint32_t)MSM_UNIT_MIN || unit > (uint32_t)MSM_UNIT_MAX) { set_error("APK_MSM_UNIT out of [%d, %d]", MSM_UNIT_MIN, MSM_UNIT_MAX); return APK_ERR_ARG; }
         const uint32_t max_units = (uint32_t)(entries / unit) + total_buckets;
         if (stats_on_) HIPCHK(hipEventRecord(s.ev0, st));
@@ -475,6 +489,7 @@ class CurveBackend : public Backend {
         if (device < 0 || device >= ndev) { set_error("device %d out of range (%d devices)", device, ndev); return APK_ERR_ARG; }
         device_ = device;
         HIPCHK(hipSetDevice(device_));
+        { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_) == hipSuccess && cus > 0) simds_ = 4u * (uint32_t)cus; }
         msm_only_ = true;
         msm_bases_ = (uint32_t)count;
         n_ = (uint32_t)count;
@@ -508,6 +523,7 @@ class CurveBackend : public Backend {
         if (d->device < 0 || d->device >= ndev) { set_error("device %d out of range (%d devices)", d->device, ndev); return APK_ERR_ARG; }
         device_ = d->device;
         HIPCHK(hipSetDevice(device_));
+        { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_) == hipSuccess && cus > 0) simds_ = 4u * (uint32_t)cus; }
         n_ = (uint32_t)d->n;
         n4_ = 4 * n_;
         log_n_ = 0;
