@@ -117,10 +117,18 @@ __global__ void __launch_bounds__(256) msm_colscan_kernel(uint32_t* __restrict__
     if (kk >= total_buckets) return;
     const uint32_t b = kk / nb, k = kk % nb;
     uint32_t run = 0;
-    for (uint32_t g = 0; g < G; g++) {
-        uint32_t* p = counts + ((size_t)b * G + g) * nb + k;
-        uint32_t v = *p;
-        *p = run;
+    uint32_t* col = counts + (size_t)b * G * nb + k;
+    uint32_t g = 0;
+    for (; g + 8 <= G; g += 8) {   // the 8 loads go out together: the loop is latency-bound (one counter per slice)
+        uint32_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = col[(size_t)(g + j) * nb];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { col[(size_t)(g + j) * nb] = run; run += v[j]; }
+    }
+    for (; g < G; g++) {
+        uint32_t v = col[(size_t)g * nb];
+        col[(size_t)g * nb] = run;
         run += v;
     }
     hist[kk] = run;
