@@ -965,7 +965,10 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         KCHK();
         gp_scan_block_kernel<FRP><<<dim3(nb, 2), POLY_THREADS, 0, st>>>(g, n); KCHK();
         gp_scan_totals_kernel<FRP><<<2, POLY_THREADS, 0, st>>>(g, nb); KCHK();
-        gp_finish_kernel<FRP><<<cdiv(n, POLY_THREADS), POLY_THREADS, 0, st>>>(g, n, nb, ptr<Fr>(s.zlag)); KCHK();
+        HIPCHK(hipMemcpyAsync(hfr, g.tot[1] + nb, sizeof(Fr), hipMemcpyDeviceToHost, st));
+        CHK(sync_results(s));
+        const Fr den_total_inv = Fr::inv(hfr[0]);
+        gp_finish_kernel<FRP><<<cdiv(n, POLY_THREADS), POLY_THREADS, 0, st>>>(g, n, den_total_inv, ptr<Fr>(s.zlag)); KCHK();
     }
     HIPCHK(hipMemsetAsync(ptr<Fr>(s.cz) + n, 0, 4 * sizeof(Fr), st));
     CHK(inv_ntt_n(st, ptr<Fr>(s.zlag), ptr<Fr>(s.cz)));

@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(POLY_THREADS) scan_totals_kernel(Fe<FR>* __res
 template <class FR>
 struct GpScan {
     Fe<FR>* data[2];
-    Fe<FR>* tot[2];   // tot[1] has one extra slot: the inverse of the product of all denominators
+    Fe<FR>* tot[2];   // tot[1] has one extra slot: the product of all denominators
 };
 template <class FR>
 __global__ void __launch_bounds__(POLY_THREADS) gp_scan_block_kernel(GpScan<FR> g, uint32_t count) {
@@ -162,18 +162,19 @@ __global__ void __launch_bounds__(POLY_THREADS) gp_scan_block_kernel(GpScan<FR> 
 template <class FR>
 __global__ void __launch_bounds__(POLY_THREADS) gp_scan_totals_kernel(GpScan<FR> g, uint32_t nblocks) {
     Fe<FR> total = scan_totals_body<FR, OpMul>(g.tot[blockIdx.x], nblocks);
-    if (blockIdx.x == 1 && threadIdx.x == POLY_THREADS - 1) g.tot[1][nblocks] = Fe<FR>::inv(total);
+    // the product of all denominators: inverted on the HOST (a lone GPU lane needs ~100 us for one Kaliski inversion)
+    if (blockIdx.x == 1 && threadIdx.x == POLY_THREADS - 1) g.tot[1][nblocks] = total;
 }
 // Z[0] = 1; Z[k] = num_prefix_incl[k-1] * den_suffix_incl[k] / den_total
 template <class FR>
-__global__ void __launch_bounds__(POLY_THREADS) gp_finish_kernel(GpScan<FR> g, uint32_t n, uint32_t nblocks, Fe<FR>* __restrict__ z) {
+__global__ void __launch_bounds__(POLY_THREADS) gp_finish_kernel(GpScan<FR> g, uint32_t n, Fe<FR> den_total_inv, Fe<FR>* __restrict__ z) {
     using Fr = Fe<FR>;
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     if (k == 0) { z[0] = Fr::one(); return; }
     Fr np = g.tot[0][(k - 1) / SCAN_BLOCK] * g.data[0][k - 1];
     Fr ds = g.tot[1][(n - 1 - k) / SCAN_BLOCK] * g.data[1][k];
-    z[k] = np * (ds * g.tot[1][nblocks]);
+    z[k] = np * (ds * den_total_inv);
 }
 
 // phase 3: fold the block prefix in.  `shift` turns the inclusive scan into the exclusive one the grand
