@@ -382,6 +382,7 @@ class CurveBackend : public Backend {
         }
         CHK(s.wl.alloc(fn)); CHK(s.wr.alloc(fn)); CHK(s.wo.alloc(fn));
         CHK(s.cl.alloc(fn3)); CHK(s.cr.alloc(fn3)); CHK(s.co.alloc(fn3)); CHK(s.cz.alloc(fn3));
+        for (DevBuf* b : {&s.cl, &s.cr, &s.co, &s.cz}) HIPCHK(hipMemset(b->p, 0, fn3));
         CHK(s.qk_lag.alloc(fn)); CHK(s.qk_can.alloc(fn));
         CHK(s.ratio.alloc(fn)); CHK(s.zlag.alloc(fn));
         CHK(s.scan_tot.alloc((size_t)(2 * (cdiv(n_ + 4, SCAN_BLOCK) + 1) + 2) * sizeof(Fr)));
@@ -898,15 +899,15 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     }
     Fr* canon[3] = {ptr<Fr>(s.cl), ptr<Fr>(s.cr), ptr<Fr>(s.co)};
     const Fr* wires[3] = {dL, dR, dO};
-    for (int j = 0; j < 3; j++) HIPCHK(hipMemsetAsync(canon[j] + n, 0, 4 * sizeof(Fr), st));
+    // (no zero-fill of the tails: blind_kernel assigns the coefficients n .. n+d-1 and nothing reads beyond them)
     {
         const uint32_t lens[3] = {n, n, n};
         CHK(run_ntt_batch(st, 0, true, 3, wires, canon, lens, n, nullptr, nullptr, ptr<Fr>(scales_)));
     }
-    for (int j = 0; j < 3; j++) {
-        Fr4<FRP> b{};
-        b.v[0] = bl[2 * j]; b.v[1] = bl[2 * j + 1];
-        blind_kernel<FRP><<<1, 64, 0, st>>>(canon[j], n, b, 2); KCHK();
+    {
+        Blind3<FRP> b3{};
+        for (int j = 0; j < 3; j++) { b3.p[j] = canon[j]; b3.b[j].v[0] = bl[2 * j]; b3.b[j].v[1] = bl[2 * j + 1]; }
+        blind3_kernel<FRP><<<3, 64, 0, st>>>(b3, n, 2); KCHK();
     }
     {
         MsmBatchArgs a{};
@@ -970,7 +971,6 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         const Fr den_total_inv = Fr::inv(hfr[0]);
         gp_finish_kernel<FRP><<<cdiv(n, POLY_THREADS), POLY_THREADS, 0, st>>>(g, n, den_total_inv, ptr<Fr>(s.zlag)); KCHK();
     }
-    HIPCHK(hipMemsetAsync(ptr<Fr>(s.cz) + n, 0, 4 * sizeof(Fr), st));
     CHK(inv_ntt_n(st, ptr<Fr>(s.zlag), ptr<Fr>(s.cz)));
     {
         Fr4<FRP> b{};

@@ -25,13 +25,29 @@ __global__ void fill_zero_kernel(Fe<FR>* p, uint32_t count) {
     if (i < count) p[i] = Fe<FR>::zero();
 }
 
-// p(X) += b(X) (X^n - 1), deg b = d-1 <= 2;  p has capacity n+d, p[n..n+d) must be zero on entry
+// p(X) += b(X) (X^n - 1), deg b = d-1 <= 2;  p has capacity n+d and holds n coefficients: p[n..n+d) is assigned, not added to
 template <class FR>
 __global__ void blind_kernel(Fe<FR>* p, uint32_t n, Fr4<FR> b, int d) {
     int i = threadIdx.x;
     if (i < d) {
         p[i] = p[i] - b.v[i];
         p[n + i] = b.v[i];
+    }
+}
+// the three wire polynomials in one launch (blockIdx.x = wire)
+template <class FR>
+struct Blind3 {
+    Fe<FR>* p[3];
+    Fr4<FR> b[3];
+};
+template <class FR>
+__global__ void blind3_kernel(Blind3<FR> a, uint32_t n, int d) {
+    int i = threadIdx.x;
+    Fe<FR>* p = a.p[blockIdx.x];
+    if (i < d) {
+        const Fe<FR> v = a.b[blockIdx.x].v[i];
+        p[i] = p[i] - v;
+        p[n + i] = v;
     }
 }
 
