@@ -150,7 +150,9 @@ class CurveBackend : public Backend {
     Fr omega_, omega_inv_, omega4_, omega4_inv_, shift_, shift_inv_, n_inv_, n4_inv_;
     Fr zh_inv_[4];
     // circuit-level device data
-    DevBuf tw_n_, twi_n_, tw_4n_, twi_4n_, coset_pre_, coset_post_inv_, scales_;  // scales_: [1/n, 1/(4n)]
+    // NTT tables hold w * R' (R' = 2^261, the radix of the tile arithmetic: kernels_ntt.h); tw_n_ = omega^i in gnark's radix
+    // is what the grand product and the permutation columns read
+    DevBuf tw_n_, twu_n_, twi_n_, tw_4n_, twi_4n_, coset_pre_, coset_post_inv_, scales_;  // scales_: [1/n, 1/(4n)]
     DevBuf x4_, l0_4_;
     DevBuf s_lag_[3], ql_c_, qr_c_, qm_c_, qo_c_, qk_c_, s_c_[3], qcp_c_[APK_MAX_COMMITMENTS];
     DevBuf qk_lag_trace_;
@@ -191,7 +193,7 @@ class CurveBackend : public Backend {
     int run_ntt_batch(hipStream_t st, int which, bool inverse, int count, const Fr* const* ins, Fr* const* outs, const uint32_t* in_lens,
                       uint32_t out_len, const Fr* pre, const Fr* post, const Fr* scale) {
         const int log_n = which ? (int)log_n_ + 2 : (int)log_n_;
-        const Fr* tw = which ? (inverse ? ptr<Fr>(twi_4n_) : ptr<Fr>(tw_4n_)) : (inverse ? ptr<Fr>(twi_n_) : ptr<Fr>(tw_n_));
+        const Fr* tw = which ? (inverse ? ptr<Fr>(twi_4n_) : ptr<Fr>(tw_4n_)) : (inverse ? ptr<Fr>(twi_n_) : ptr<Fr>(twu_n_));
         // small transforms are latency-bound: 512-element tiles (16 KiB LDS) give >= 256 workgroups at 2^17;
         // large ones are bandwidth-bound: 2048-element tiles and fewer passes
         int tile_log = log_n <= 19 ? 9 : NTT_TILE_LOG;
@@ -215,7 +217,7 @@ class CurveBackend : public Backend {
             a.first = (p == 0); a.last = (p == passes - 1);
             a.out_len = out_len;
             const dim3 grid(1u << (log_n - tile_log), count);
-            const size_t lds = ((size_t)1 << tile_log) * sizeof(Fr);
+            const size_t lds = ((size_t)1 << tile_log) * sizeof(FeU<FRP>);
             ntt_pass_kernel<FRP><<<grid, NTT_THREADS, lds, st>>>(nb, tw, pre, post, scale, a);
             KCHK();
             t0 += s;
@@ -556,17 +558,22 @@ class CurveBackend : public Backend {
         hipStream_t st = nullptr;  // default stream during setup
         const size_t fn = (size_t)n_ * sizeof(Fr), f4 = (size_t)n4_ * sizeof(Fr);
         CHK(tw_n_.alloc(fn / 2)); CHK(twi_n_.alloc(fn / 2)); CHK(tw_4n_.alloc(f4 / 2)); CHK(twi_4n_.alloc(f4 / 2));
+        const Fr ru = fr_u64(32);   // R'/R = 2^5: x R -> x R'
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<FRP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(((size_t)1 << NTT_TILE_LOG) * sizeof(FeU<FRP>))));
+        CHK(twu_n_.alloc(fn / 2));
         CHK(powers(st, ptr<Fr>(tw_n_), n_ / 2, omega_, Fr::one()));
-        CHK(powers(st, ptr<Fr>(twi_n_), n_ / 2, omega_inv_, Fr::one()));
-        CHK(powers(st, ptr<Fr>(tw_4n_), n4_ / 2, omega4_, Fr::one()));
-        CHK(powers(st, ptr<Fr>(twi_4n_), n4_ / 2, omega4_inv_, Fr::one()));
+        CHK(powers(st, ptr<Fr>(twu_n_), n_ / 2, omega_, ru));
+        CHK(powers(st, ptr<Fr>(twi_n_), n_ / 2, omega_inv_, ru));
+        CHK(powers(st, ptr<Fr>(tw_4n_), n4_ / 2, omega4_, ru));
+        CHK(powers(st, ptr<Fr>(twi_4n_), n4_ / 2, omega4_inv_, ru));
         CHK(coset_pre_.alloc((size_t)(n_ + 4) * sizeof(Fr)));
-        CHK(powers(st, ptr<Fr>(coset_pre_), n_ + 4, shift_, Fr::one()));
+        CHK(powers(st, ptr<Fr>(coset_pre_), n_ + 4, shift_, ru));
         CHK(coset_post_inv_.alloc(f4));
-        CHK(powers(st, ptr<Fr>(coset_post_inv_), n4_, shift_inv_, n4_inv_));
+        CHK(powers(st, ptr<Fr>(coset_post_inv_), n4_, shift_inv_, n4_inv_ * ru));
         CHK(scales_.alloc(2 * sizeof(Fr)));
         {
-            Fr sc[2] = {n_inv_, n4_inv_};
+            Fr sc[2] = {n_inv_ * ru, n4_inv_ * ru};
             HIPCHK(hipMemcpy(scales_.p, sc, sizeof sc, hipMemcpyHostToDevice));
         }
         CHK(x4_.alloc(f4));
@@ -658,7 +665,7 @@ class CurveBackend : public Backend {
                         inverse ? ptr<Fr>(scales_) + (which ? 1 : 0) : nullptr));
         } else if (!inverse) {
             // forward coset needs shift^i for all i < 4n: build it in hcan for this call
-            CHK(powers(s.stream, ptr<Fr>(s.hcan), N, shift_, Fr::one()));
+            CHK(powers(s.stream, ptr<Fr>(s.hcan), N, shift_, fr_u64(32)));   // R' form, like every NTT table
             CHK(run_ntt(s.stream, 1, false, din, dout, N, N, ptr<Fr>(s.hcan), nullptr, nullptr));
         } else {
             CHK(run_ntt(s.stream, 1, true, din, dout, N, N, nullptr, ptr<Fr>(coset_post_inv_), nullptr));

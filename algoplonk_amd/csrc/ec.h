@@ -124,6 +124,7 @@ struct XYZZ {
     // `unit_z` (in/out): the state is a plain affine point (ZZ = ZZZ = 1, as after the first point of a bucket slice), which
     // saves the four products by ZZ / ZZZ on the second point.
     APK_HD void madd_lazy(const Aff& q, bool negate, bool& flipped, bool& unit_z) {
+        static_assert(F::HEADROOM >= 160, "the bounds of the lazy class need R'/p >= 160");
         if (q.is_inf()) return;
         const bool ng = negate != flipped;
         if (is_inf()) {
@@ -175,6 +176,7 @@ struct XYZZ {
 
     // 2p for p in the lazy class
     APK_HD static XYZZ dbl_lazy(const XYZZ& p) {
+        static_assert(F::HEADROOM >= 160, "the bounds of the lazy class need R'/p >= 160");
         if (p.is_inf()) return inf();
         if (p.Y.l[0] == 0u || p.Y.l[0] == FP::umod(0) || p.Y.l[0] == F::template kp<2>(0)) {   // Y = 0 mod p: a 2-torsion point
             if (F::template canon<2>(p.Y).is_zero()) return inf();
@@ -195,6 +197,7 @@ struct XYZZ {
 
     // this += q, both in the lazy class
     APK_HD void add_lazy(const XYZZ& q) {
+        static_assert(F::HEADROOM >= 160, "the bounds of the lazy class need R'/p >= 160");
         if (q.is_inf()) return;
         if (is_inf()) { *this = q; return; }
         const F U1 = F::mul_nr(X, q.ZZ);                       // < 1.1

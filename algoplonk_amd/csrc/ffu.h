@@ -183,12 +183,11 @@ struct FeU {
 
     // ---- lazy forms: the bucket-accumulation inner loop (ec.h XYZZ::madd_lazy) --------------------------------------
     // R'/p is large (BN254: 169, BLS12-381: 2520), so a Montgomery product of operands below A*p and C*p comes out
-    // below p*(1 + A*C*p/R') < 2p without the conditional subtraction as long as A*C <= HEADROOM, and a difference can
+    // below p*(1 + A*C*p/R') < 2p without the conditional subtraction as long as A*C <= HEADROOM = R'/p, and a difference can
     // be kept positive by adding a multiple of p instead of testing for a borrow.  Values are then only congruent mod p
     // (still with every limb but the top one below 2^B); canon<K>() brings them back.  Column sums stay below 2^64:
     // 2L products of limbs below 2^B plus L of m*p, or L products with one operand's limbs below 2^(B+1).
-    static constexpr uint32_t HEADROOM = 160;
-    static_assert(((uint64_t)P::umod(L - 1) + 1) * HEADROOM <= (1ull << B), "R'/p too small for the lazy forms");
+    static constexpr uint32_t HEADROOM = (uint32_t)((1ull << B) / ((uint64_t)P::umod(L - 1) + 1));   // <= R'/p; users assert what they need
     static_assert((uint64_t)(3 * L + 1) <= (1ull << (64 - 2 * B)), "column sums of mul2_nr must fit 64 bits");
 
     // limb i of K*p, normalised (the top limb keeps the excess)

@@ -7,12 +7,13 @@
 //
 // Design: decimation-in-time over a bit-reversed gather.  The log2(N) butterfly stages are cut into
 // passes of <= NTT_PASS_BITS stages; inside a pass a workgroup owns a tile of NTT_TILE = 2048 elements in
-// LDS (64 KiB) - 2^s "mid" positions x C adjacent groups, so global traffic is C*32-byte contiguous runs -
+// LDS (72 KiB: 36-byte unsaturated-limb elements) - 2^s "mid" positions x C adjacent groups, so global traffic is C*32-byte contiguous runs -
 // and runs its s stages out of LDS.  Each pass is one read + one write of the vector (64 B/element,
 // SURVEY.md §8d).  Optional fused pre-/post-multiplication by a table (coset powers, 1/N) and a zero-padded
 // short input remove the separate scaling / padding passes.
 #pragma once
 #include "ff.h"
+#include "ffu.h"
 
 namespace apk {
 
@@ -39,7 +40,16 @@ struct NttPassArgs {
     uint32_t out_len;    // last pass: elements >= out_len are not written
 };
 
-// tw[j] = w^j for j < N/2 (w = omega or omega^-1), Montgomery form
+// Inside the tile the elements are UNSATURATED-limb values (ffu.h, 9 x 29 bits for both scalar fields) handled lazily:
+//   * data stays in gnark's Montgomery radix R = 2^256; the twiddle / scaling TABLES are stored in the radix R' = 2^261 of
+//     the carry-free product (w * R'), so  mul_nr(w R', x R) = w x R  needs no domain conversion;
+//   * a butterfly is one product without its final subtraction (below 2p), one limb-wise sum and one difference kept
+//     positive by adding 2p: no comparisons.  Values grow by at most 2p per stage (below 24p after 10 stages, R'/p >= 71);
+//   * canonical 8-word elements again only when the tile is written back.
+// Against the saturated-limb butterfly (128 v_mad_u64_u32 + 128 v_addc per product, two conditional subtractions) this is
+// 171 mads + ~150 other instructions.
+//
+// tw[j] = w^j * R' for j < N/2 (w = omega or omega^-1); pre / post / scale tables likewise in R' form
 template <class FR>
 __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, const Fe<FR>* __restrict__ tw,
                                                                const Fe<FR>* __restrict__ pre,   // or null
@@ -47,8 +57,10 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, cons
                                                                const Fe<FR>* __restrict__ scale, // or null: one element
                                                                NttPassArgs a) {
     using Fr = Fe<FR>;
+    using Fu = FeU<FR>;
+    static_assert(Fu::HEADROOM >= 64, "a pass of up to 10 lazy stages needs R'/p above 24");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Fr* sm = reinterpret_cast<Fr*>(smem_raw);
+    Fu* sm = reinterpret_cast<Fu*>(smem_raw);
     Fr* __restrict__ out = reinterpret_cast<Fr*>(nb.out[blockIdx.y]);
     const Fr* __restrict__ in = a.first ? reinterpret_cast<const Fr*>(nb.in[blockIdx.y]) : out;
     const uint32_t in_len = nb.in_len[blockIdx.y];
@@ -65,17 +77,19 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, cons
         uint32_t c = e & (C - 1), mid = e >> clog;
         uint32_t g = g0 + c;
         uint32_t idx = ((g >> a.t0) << a.t1) | (mid << a.t0) | (g & lomask);
-        Fr v;
+        Fu v;
         if (a.first) {
             uint32_t src = bitrev32(idx, a.log_n);
             if (src < in_len) {
-                v = in[src];
-                if (pre) v = v * pre[src];
+                Fr raw = in[src];
+                v = Fu::unpack(raw.l);
+                if (pre) { Fr pw = pre[src]; v = Fu::mul_nr(Fu::unpack(pw.l), v); }
             } else {
-                v = Fr::zero();
+                v = Fu::zero();
             }
         } else {
-            v = in[idx];
+            Fr raw = in[idx];
+            v = Fu::unpack(raw.l);
         }
         sm[e] = v;
     }
@@ -94,13 +108,13 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, cons
             uint32_t imod = (low << a.t0) | (g & lomask);
             uint32_t tidx = imod << (a.log_n - 1 - t);
             uint32_t e0 = (mid0 << clog) | c, e1 = (mid1 << clog) | c;
-            Fr u = sm[e0];
-            Fr v = sm[e1];
-            // skip the product for the unit twiddle (all of stage 0) and for zero operands (the first two stages of
-            // the zero-padded 4n transforms: their upper three quarters are zero) - both are wave-uniform in practice
-            if (tidx != 0 && !v.is_zero()) v = v * tw[tidx];
-            sm[e0] = u + v;
-            sm[e1] = u - v;
+            Fu u = sm[e0];
+            Fu v = sm[e1];
+            // no product in stage 0 (unit twiddles; the operands are fresh, i.e. below 2p as the difference needs) and for zero
+            // operands (the first two stages of the zero-padded 4n transforms) - both are wave-uniform in practice
+            if (t != 0 && !v.is_zero()) { Fr w = tw[tidx]; v = Fu::mul_nr(Fu::unpack(w.l), v); }
+            sm[e0] = Fu::add_n(u, v);
+            sm[e1] = Fu::template sub_k<2>(u, v);
         }
         __syncthreads();
     }
@@ -108,13 +122,16 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, cons
         uint32_t c = e & (C - 1), mid = e >> clog;
         uint32_t g = g0 + c;
         uint32_t idx = ((g >> a.t0) << a.t1) | (mid << a.t0) | (g & lomask);
-        Fr v = sm[e];
+        Fu v = sm[e];
         if (a.last) {
             if (idx >= a.out_len) continue;
-            if (post) v = v * post[idx];
-            if (scale) v = v * scale[0];
+            if (post) { Fr pw = post[idx]; v = Fu::mul_nr(Fu::unpack(pw.l), v); }
+            if (scale) { Fr sc = scale[0]; v = Fu::mul_nr(Fu::unpack(sc.l), v); }
         }
-        out[idx] = v;
+        v = (a.last && (post || scale)) ? Fu::template canon<1>(v) : Fu::template canon<16>(v);
+        Fr o;
+        v.pack(o.l);
+        out[idx] = o;
     }
 }
 
