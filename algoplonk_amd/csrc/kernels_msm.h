@@ -145,6 +145,7 @@ __global__ void __launch_bounds__(256) msm_colscan_kernel(uint32_t* __restrict__
 // Three small launches (a single block took 58 us for 49 k buckets): 1024 counters per block -> block totals -> one block
 // scans the totals -> blocks add their base.
 constexpr int MSM_SCAN_BLOCK = 1024;
+constexpr int MSM_SCAN_MAX_BLOCKS = 128;   // MSM_MAX_BATCH * 2^15 buckets / MSM_SCAN_BLOCK
 
 template <int DUMMY>
 __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_local_kernel(const uint32_t* __restrict__ hist, uint32_t total, uint32_t unit,
@@ -187,15 +188,18 @@ __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_totals_kernel(uint32_
     __shared__ uint32_t s_unit[MSM_SCAN_BLOCK];
     __shared__ uint32_t s_full[MSM_SCAN_BLOCK];
     __shared__ uint32_t s_bintot[MSM_UNIT_MAX];
+    __shared__ uint32_t s_bins[MSM_SCAN_MAX_BLOCKS * MSM_UNIT_MAX];   // the per-block remainder histograms, scanned in LDS
     const uint32_t t = threadIdx.x;
     const uint32_t h = t < nblocks ? block_tot[t] : 0u, hu = t < nblocks ? block_tot[nblocks + t] : 0u,
                    hf = t < nblocks ? block_tot[2 * nblocks + t] : 0u;
     s_cnt[t] = h; s_unit[t] = hu; s_full[t] = hf;
+    for (uint32_t i = t; i < nblocks * MSM_UNIT_MAX; i += MSM_SCAN_BLOCK) s_bins[i] = block_bins[i];
+    __syncthreads();
     if (t < MSM_UNIT_MAX) {   // per remainder length: exclusive prefix over the blocks
         uint32_t run = 0;
         for (uint32_t blk = 0; blk < nblocks; blk++) {
-            const uint32_t v = block_bins[blk * MSM_UNIT_MAX + t];
-            block_bins[blk * MSM_UNIT_MAX + t] = run;
+            const uint32_t v = s_bins[blk * MSM_UNIT_MAX + t];
+            s_bins[blk * MSM_UNIT_MAX + t] = run;
             run += v;
         }
         s_bintot[t] = run;
@@ -210,11 +214,14 @@ __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_totals_kernel(uint32_
     }
     if (t < nblocks) { block_tot[t] = s_cnt[t] - h; block_tot[nblocks + t] = s_unit[t] - hu; block_tot[2 * nblocks + t] = s_full[t] - hf; }
     if (t == MSM_SCAN_BLOCK - 1) { offsets[total] = s_cnt[t]; unit_off[total] = s_unit[t]; full_off[total] = s_full[t]; }
+    __shared__ uint32_t s_base[MSM_UNIT_MAX];
     if (t < MSM_UNIT_MAX) {   // longest remainders first
         uint32_t base = 0;
         for (uint32_t r = MSM_UNIT_MAX - 1; r > t; r--) base += s_bintot[r];
-        for (uint32_t blk = 0; blk < nblocks; blk++) block_bins[blk * MSM_UNIT_MAX + t] += base;
+        s_base[t] = base;
     }
+    __syncthreads();
+    for (uint32_t i = t; i < nblocks * MSM_UNIT_MAX; i += MSM_SCAN_BLOCK) block_bins[i] = s_bins[i] + s_base[i % MSM_UNIT_MAX];
 }
 
 template <int DUMMY>
