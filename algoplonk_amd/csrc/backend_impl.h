@@ -1061,16 +1061,15 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         for (int i = 0; i < 5; i++) { ea.f[i] = fs[i]; ea.len[i] = ls[i]; }
         ea.count = 5;
         for (uint32_t k = 0; k < nb_commit_; k++) { ea.f[ea.count] = ptr<Fr>(qcp_c_[k]); ea.len[ea.count] = n; ea.count++; }
+        // Z(omega*zeta) rides in the same launch with its own table of powers
+        const int iz = ea.count;
+        ea.f[iz] = ptr<Fr>(s.cz); ea.len[iz] = n + 3; ea.pw[iz] = ptr<Fr>(s.pw_zw); ea.count++;
         CHK(eval_many(s, ea, ptr<Fr>(s.pw_z), hfr));
         CHK(sync_results(s));
         for (int i = 0; i < ea.count; i++) ev[i] = hfr[i];
-        EvalArgs<FRP> eb{};
-        eb.f[0] = ptr<Fr>(s.cz); eb.len[0] = n + 3; eb.count = 1;
-        CHK(eval_many(s, eb, ptr<Fr>(s.pw_zw), hfr));
-        CHK(sync_results(s));
     }
     const Fr lz = ev[0], rz = ev[1], oz = ev[2], s1z = ev[3], s2z = ev[4];
-    const Fr zshift = hfr[0];
+    const Fr zshift = ev[5 + nb_commit_];
     // coefficients of the linearised polynomial (templateLogicSigBN254.go:195-201,231-254)
     const Fr zn_m1 = Fr::pow_u64(zeta, n) - Fr::one();
     const Fr lag0 = zn_m1 * n_inv_ * Fr::inv(zeta - Fr::one());

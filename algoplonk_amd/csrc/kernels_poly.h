@@ -258,6 +258,7 @@ constexpr int EVAL_MAX = 12;
 template <class FR>
 struct EvalArgs {
     const Fe<FR>* f[EVAL_MAX];
+    const Fe<FR>* pw[EVAL_MAX];   // per polynomial: its table of powers of the evaluation point, or null = the kernel's `pw`
     uint32_t len[EVAL_MAX];
     int count;
 };
@@ -272,11 +273,12 @@ __global__ void __launch_bounds__(POLY_THREADS) eval_partial_kernel(EvalArgs<FR>
     const int p = blockIdx.y;
     const uint32_t t = threadIdx.x;
     const Fr* f = a.f[p];
+    const Fr* __restrict__ pwp = a.pw[p] ? a.pw[p] : pw;
     const uint32_t len = a.len[p];
     Fr acc = Fr::zero();
     for (int k = 0; k < EVAL_PER_THREAD; k++) {
         uint32_t i = blockIdx.x * EVAL_BLOCK + k * POLY_THREADS + t;
-        if (i < len) acc = acc + f[i] * pw[i];
+        if (i < len) acc = acc + f[i] * pwp[i];
     }
     sm[t] = acc;
     __syncthreads();
