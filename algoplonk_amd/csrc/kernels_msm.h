@@ -48,19 +48,7 @@ struct MsmBatchArgs {
 };
 
 // ---- signed-digit recoding ---------------------------------------------------------------------------
-// canonical scalar limbs -> W digits d_j in [-2^(c-1), 2^(c-1)), s = sum d_j 2^(c j)
-template <int N>
-__device__ __forceinline__ uint32_t window_bits(const uint32_t (&s)[N], int bit, int c) {
-    const int w = bit >> 5, o = bit & 31;
-    uint32_t lo = 0, hi = 0;  // select limbs w, w+1 with compares so the limbs stay in registers
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        lo = (i == w) ? s[i] : lo;
-        hi = (i == w + 1) ? s[i] : hi;
-    }
-    uint64_t v = ((uint64_t)hi << 32) | lo;
-    return (uint32_t)(v >> o) & ((1u << c) - 1u);
-}
+// canonical scalar limbs -> W digits d_j in [-2^(w_j - 1), 2^(w_j - 1)], s = sum d_j 2^(off_j)  (inside msm_digits_kernel)
 
 // Counting sort of the (digit, point) pairs by bucket WITHOUT global atomics (device-scope atomics leave the XCD's
 // L2 and were 25 % of an MSM): a workgroup owns a contiguous slice of the scalars and a private LDS histogram.
@@ -87,19 +75,33 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_digits_kernel(MsmBatch
         Fr s = Fr::from_mont(reinterpret_cast<const Fr*>(a.scalars[b])[i]);
         uint32_t carry = 0;
         const uint32_t base_idx = a.offset[b] + i;
-        for (int j = 0; j < win.W; j++) {
-            const int bit = win.off[j], c = win.width[j];
-            const uint32_t half = 1u << (c - 1);
-            uint32_t d = (bit < 32 * Fr::N ? window_bits<Fr::N>(s.l, bit, c) : 0u) + carry;
-            uint32_t neg = 0;
-            if (d > half) { d = (1u << c) - d; neg = 1; carry = 1; }  // d in (half, 2^c] -> -(2^c - d)
-            else carry = 0;
-            if (d == 0) continue;  // also the d == 2^c case (digit 0, carry 1)
-            if (!SCATTER) {
-                atomicAdd(&lds[d - 1], 1u);
-            } else {
-                uint32_t pos = atomicAdd(&lds[d - 1], 1u);
-                sorted[pos] = ((uint32_t)j * n_max + base_idx) | (neg << 31);
+        // The windows are consecutive bit fields (off[j+1] = off[j] + width[j]): stream the limbs through a 64-bit buffer and
+        // peel windows off its low end - no per-window limb selection (the limbs must stay in registers, so indexing them by
+        // a run-time window offset costs a compare-select chain per window).  j is uniform across the wave.
+        uint64_t buf = 0;
+        int avail = 0, j = 0;
+#pragma unroll
+        for (int li = 0; li < Fr::N; li++) {
+            buf |= (uint64_t)s.l[li] << avail;
+            avail += 32;
+            while (j < win.W && (avail >= (int)win.width[j] || li == Fr::N - 1)) {   // after the last limb the buffer's zeros serve the top windows
+                const int c = win.width[j];
+                const uint32_t half = 1u << (c - 1);
+                uint32_t d = ((uint32_t)buf & ((1u << c) - 1u)) + carry;
+                buf >>= c;
+                avail -= c;
+                uint32_t neg = 0;
+                if (d > half) { d = (1u << c) - d; neg = 1; carry = 1; }  // d in (half, 2^c] -> -(2^c - d)
+                else carry = 0;
+                if (d != 0) {  // d == 0 also covers the d == 2^c case (digit 0, carry 1)
+                    if (!SCATTER) {
+                        atomicAdd(&lds[d - 1], 1u);
+                    } else {
+                        uint32_t pos = atomicAdd(&lds[d - 1], 1u);
+                        sorted[pos] = ((uint32_t)j * n_max + base_idx) | (neg << 31);
+                    }
+                }
+                j++;
             }
         }
     }
