@@ -109,6 +109,27 @@ static int fe_op_t(int op, const void* a, const void* b, void* out) {
                 set_error("field has no unsaturated-limb form");
                 return APK_ERR_ARG;
             }
+        // 14: ten lazy butterfly stages as the NTT tile runs them (kernels_ntt.h): (u, v) <- (u + w v, u - w v + 2p) with the
+        // twiddle w = y in the R' radix, no comparison until the final canon<16>; returns u
+        case 14:
+            if constexpr (HasUnsat<P>::value) {
+                using U = FeU<P>;
+                F ratio = F::zero();
+                ratio.l[0] = 1u << (U::B * U::L - 32 * F::N);          // R'/R (2^5 for the 9 x 29-bit fields)
+                const U w = U::unpack(F::mul(y, F::to_mont(ratio)).l);  // y * R'/R: gnark's radix -> R'
+                U u = U::unpack(x.l), v = U::unpack(y.l);
+                for (int i = 0; i < 10; i++) {
+                    const U t = U::mul_nr(w, v);
+                    const U nu = U::add_n(u, t);
+                    v = U::template sub_k<2>(u, t);
+                    u = nu;
+                }
+                U::template canon<16>(u).pack(r.l);
+                break;
+            } else {
+                set_error("field has no unsaturated-limb form");
+                return APK_ERR_ARG;
+            }
         default: set_error("unknown field op %d", op); return APK_ERR_ARG;
     }
     memcpy(out, &r, sizeof r);

@@ -163,7 +163,8 @@ int apk_hash_fr(int curve, const void* g1_affine, void* out_fr);
 
 /* ---- diagnostics: run the library's own field / curve templates on the HOST (no GPU).  The kernels are built
  * from the same templates, so the CPU-only test tier can pin the formulas against the oracle.
- * field ops: 0 add, 1 sub, 2 mul (Montgomery), 3 inverse, 4 neg.  field: 0 = Fr, 1 = Fp.
+ * field ops: 0 add, 1 sub, 2 mul (Montgomery), 3 inverse, 4 neg; 10-13 = mul / add / sub / neg on unsaturated limbs; 14 = ten
+ * lazy butterfly stages (u, v) <- (u + b v, u - b v) from (a, b) as the NTT tile runs them, returns u.  field: 0 = Fr, 1 = Fp.
  * g1 ops: 0 mixed add p+q, 1 full XYZZ add p+q, 2 double p, 3 scalar mul q*p (q = Fr Montgomery); 10/11 = 0/1 on the
  * MSM's unsaturated limbs; 12/13 = a fixed 17-step signed chain ending at p+3q through the accumulate loop's lazy
  * mixed addition / the plain one; 14 = lazy full additions and doublings ending at 4p+6q. */

@@ -60,10 +60,16 @@ def test_host_field_and_curve_templates_match_oracle(cname):
                 assert dec(out.raw) == exp, (cname, field, op)
             check(lib.apk_host_fe_op(cv.abi, field, 3, enc(a), None, out))
             assert dec(out.raw) == (pow(a, -1, mod) if a else 0)
-            if field == 1:   # the MSM's unsaturated-limb field (ffu.h), converted in and out of gnark's radix
-                for op, exp in ((10, a * b % mod), (11, (a + b) % mod), (12, (a - b) % mod), (13, (-a) % mod), (10, a * a % mod)):
-                    check(lib.apk_host_fe_op(cv.abi, 1, op, enc(a), enc(a) if exp == a * a % mod and op == 10 and a != b else enc(b), out))
-                    assert dec(out.raw) == exp, (cname, "unsat", op)
+            # the unsaturated-limb forms (ffu.h: Fp inside the MSM, Fr inside the NTT tiles), converted in and out of gnark's radix
+            for op, exp in ((10, a * b % mod), (11, (a + b) % mod), (12, (a - b) % mod), (13, (-a) % mod), (10, a * a % mod)):
+                check(lib.apk_host_fe_op(cv.abi, field, op, enc(a), enc(a) if exp == a * a % mod and op == 10 and a != b else enc(b), out))
+                assert dec(out.raw) == exp, (cname, field, "unsat", op)
+            # 14: ten comparison-free butterfly stages (u, v) <- (u + b v, u - b v) as the NTT tile runs them, u0 = a, v0 = b
+            u, v = a, b
+            for _ in range(10):
+                u, v = (u + b * v) % mod, (u - b * v) % mod
+            check(lib.apk_host_fe_op(cv.abi, field, 14, enc(a), enc(b), out))
+            assert dec(out.raw) == u, (cname, field, "lazy butterflies")
         # canonical big-endian codecs
         be = C.create_string_buffer(nb)
         check(lib.apk_fe_to_be(cv.abi, field, enc(12345), be))
