@@ -196,8 +196,12 @@ class CurveBackend : public Backend {
         const Fr* tw = which ? (inverse ? ptr<Fr>(twi_4n_) : ptr<Fr>(tw_4n_)) : (inverse ? ptr<Fr>(twi_n_) : ptr<Fr>(twu_n_));
         // small transforms are latency-bound: 512-element tiles (16 KiB LDS) give >= 256 workgroups at 2^17;
         // large ones are bandwidth-bound: 2048-element tiles and fewer passes
+        static const int tile_env = getenv("APK_NTT_TILE_LOG") ? atoi(getenv("APK_NTT_TILE_LOG")) : 0;
+        static const int stages_env = getenv("APK_NTT_STAGES") ? atoi(getenv("APK_NTT_STAGES")) : 0;
         int tile_log = log_n <= 19 ? 9 : NTT_TILE_LOG;
         int max_s = log_n <= 19 ? 7 : 9;
+        if (tile_env) tile_log = tile_env;
+        if (stages_env) max_s = stages_env;
         if (tile_log > log_n) tile_log = log_n;
         if (max_s > tile_log) max_s = tile_log;
         const int passes = (log_n + max_s - 1) / max_s;
