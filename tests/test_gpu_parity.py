@@ -153,11 +153,11 @@ def test_unsatisfied_witness_is_an_error_not_a_proof(gpu, cname):
     pk.close()
 
 
-@pytest.mark.parametrize("window", [7, 9, 12, 16])
-def test_msm_window_sizes_and_skewed_scalars(gpu, window):
+@pytest.mark.parametrize("cname,window", [("bn254", 7), ("bn254", 9), ("bn254", 12), ("bn254", 16), ("bls12-381", 8), ("bls12-381", 13)])
+def test_msm_window_sizes_and_skewed_scalars(gpu, cname, window):
     """Every window width gives the same group element; skewed inputs (all ones, two distinct values, tiny values)
-    stress the bucket work-unit split."""
-    cv, ov = CURVES["bn254"]
+    stress the bucket work-unit split (full units, sorted remainder units, heavy buckets)."""
+    cv, ov = CURVES[cname]
     ccs, w, sol = random_chain_ccs(cv, 9, 77)
     pk, vk, opk, srs = _setup_pair(cv, ov, ccs, 4, gpu, msm_window=window)
     n = ccs.domain_size()
