@@ -602,7 +602,10 @@ class CurveBackend : public Backend {
         }
         // proving slots
         int nslots = d->slots > 0 ? d->slots : 1;
-        if (nslots > 16) nslots = 16;
+        // more than 16 concurrently active streams collapse the throughput (24: -25 %, 32: -40 %, 48: -55 % at 2^17); callers
+        // beyond the cap wait for a slot, which also hides their host-side gaps
+        static const int max_slots = getenv("APK_MAX_SLOTS") ? atoi(getenv("APK_MAX_SLOTS")) : 16;
+        if (nslots > max_slots) nslots = max_slots;
         for (int i = 0; i < nslots; i++) {
             Slot* s = new Slot();
             slots_.push_back(s);

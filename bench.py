@@ -40,7 +40,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=17)
     ap.add_argument("--curve", default="bn254", choices=["bn254", "bls12_381"])
-    ap.add_argument("--inflight", type=int, default=24, help="independent proofs per step (context slots)")
+    ap.add_argument("--inflight", type=int, default=32,
+                    help="independent proofs per step = concurrent apk_prove callers (the context runs 16 at a time, the rest wait for a slot)")
     ap.add_argument("--msm-window", type=int, default=0)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
