@@ -76,7 +76,7 @@ typedef struct {
     const void* qcp[APK_MAX_COMMITMENTS];               /* n Fr each */
     uint32_t commitment_constraint_index[APK_MAX_COMMITMENTS]; /* VK CommitmentConstraintIndexes */
     int msm_window;            /* signed-digit window bits; 0 = choose from n */
-    int slots;                 /* concurrent proofs in flight on this context; 0 = 1 */
+    int slots;                 /* concurrent proofs in flight on this context; 0 = 1; capped at 16 (more callers wait their turn) */
 } apk_circuit_desc;
 
 int apk_ctx_create(const apk_circuit_desc* desc, apk_ctx** out);
