@@ -10,7 +10,7 @@ rocprofv3 --kernel-trace --stats -d $O/${TAG}_kt1 -o r -- python bench.py --infl
 python tools/rocprof_summary.py $O/${TAG}_kt1/r_results.db > $O/${TAG}_kernel_trace_bn254_2p17.txt
 grep '"metric"' $O/${TAG}_kt1.log | tail -1 > $O/${TAG}_kernel_trace_bn254_2p17_benchline.json
 rocprofv3 --kernel-trace --stats -d $O/${TAG}_kt24 -o r -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/${TAG}_kt24.log 2>&1
-python tools/rocprof_summary.py $O/${TAG}_kt24/r_results.db > $O/${TAG}_kernel_trace_bn254_2p17_inflight24.txt
+python tools/rocprof_summary.py $O/${TAG}_kt24/r_results.db > $O/${TAG}_kernel_trace_bn254_2p17_saturated.txt
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES"; do
   N=$(echo $C | tr ' ' '_')
   rocprofv3 --kernel-trace --pmc $C -d $O/${TAG}_pmc_$N -o p -- python tools/prof_msm.py 17 4 0 > $O/${TAG}_pmc_$N.log 2>&1
