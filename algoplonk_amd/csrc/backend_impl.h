@@ -130,6 +130,7 @@ class CurveBackend : public Backend {
         DevBuf eval_partial, eval_result;
         DevBuf pi2_lag[APK_MAX_COMMITMENTS], pi2_can[APK_MAX_COMMITMENTS], epi2[APK_MAX_COMMITMENTS];
         DevBuf scratch_in;  // upload staging for primitives
+        DevBuf ntt_wide;    // NTT_MAX_BATCH transforms of 4n unsaturated-limb elements: the NTT's inter-pass form
         // MSM workspace
         DevBuf counts, hist, offsets, unit_off, full_off, rem_rank, rem_list, scan_blk, sorted, partial, bucket_sum, rowcol, bit_partial, result, result_xyzz;
         void* h_pinned = nullptr;  // small pinned staging for results: [0,1024) affine, [1024,2048) XYZZ, [2048,4096) scalars
@@ -209,10 +210,13 @@ class CurveBackend : public Backend {
         for (int i = 0; i < count; i++) { nb.in[i] = ins[i]; nb.out[i] = outs[i]; nb.in_len[i] = in_lens[i]; }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         Slot* owner = nullptr;
-        if (stats_on_) {
-            for (Slot* s : slots_) if (s->stream == st) owner = s;
-            if (owner) { e0 = owner->ev2; e1 = owner->ev3; HIPCHK(hipEventRecord(e0, st)); }
+        for (Slot* s : slots_) if (s->stream == st) owner = s;
+        if (passes > 1) {   // the passes hand each other unsaturated-limb elements through the slot's scratch
+            if (!owner || log_n > 30) { set_error("ntt: no workspace for this stream"); return APK_ERR_STATE; }
+            for (int i = 0; i < count; i++) nb.wide[i] = ptr<FeU<FRP>>(owner->ntt_wide) + ((size_t)i << log_n);
         }
+        Slot* timed = stats_on_ ? owner : nullptr;
+        if (timed) { e0 = timed->ev2; e1 = timed->ev3; HIPCHK(hipEventRecord(e0, st)); }
         int t0 = 0;
         for (int p = 0; p < passes; p++) {
             int s = (log_n - t0 + (passes - p) - 1) / (passes - p);
@@ -226,7 +230,7 @@ class CurveBackend : public Backend {
             KCHK();
             t0 += s;
         }
-        if (owner) {
+        if (timed) {
             HIPCHK(hipEventRecord(e1, st));
             HIPCHK(hipEventSynchronize(e1));
             float ms = 0;
@@ -400,6 +404,7 @@ class CurveBackend : public Backend {
         CHK(s.eval_result.alloc(EVAL_MAX * sizeof(Fr)));
         for (uint32_t k = 0; k < nb_commit_; k++) { CHK(s.pi2_lag[k].alloc(fn)); CHK(s.pi2_can[k].alloc(fn)); CHK(s.epi2[k].alloc(f4)); }
         CHK(s.scratch_in.alloc(f4));
+        CHK(s.ntt_wide.alloc((size_t)NTT_MAX_BATCH * n4_ * sizeof(FeU<FRP>)));
         return alloc_msm_workspace(s, MSM_MAX_BATCH);
     }
 

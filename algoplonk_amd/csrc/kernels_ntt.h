@@ -30,6 +30,7 @@ struct NttBatch {
     const void* in[NTT_MAX_BATCH];
     void* out[NTT_MAX_BATCH];
     uint32_t in_len[NTT_MAX_BATCH];  // elements >= in_len read as zero (first pass only)
+    void* wide[NTT_MAX_BATCH];       // N unsaturated-limb elements (36 B): what the passes hand to each other
 };
 
 struct NttPassArgs {
@@ -45,7 +46,8 @@ struct NttPassArgs {
 //     the carry-free product (w * R'), so  mul_nr(w R', x R) = w x R  needs no domain conversion;
 //   * a butterfly is one product without its final subtraction (below 2p), one limb-wise sum and one difference kept
 //     positive by adding 2p: no comparisons.  Values grow by at most 2p per stage (below 24p after 10 stages, R'/p >= 71);
-//   * canonical 8-word elements again only when the tile is written back.
+//   * between the passes of one transform the elements stay in that form (NttBatch::wide, 36 bytes each, values below
+//     (2 + 2 log2 N) p < R'); canonical 8-word elements are read by the first pass and written by the last one only.
 // Against the saturated-limb butterfly (128 v_mad_u64_u32 + 128 v_addc per product, two conditional subtractions) this is
 // 171 mads + ~150 other instructions.
 //
@@ -58,11 +60,12 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, cons
                                                                NttPassArgs a) {
     using Fr = Fe<FR>;
     using Fu = FeU<FR>;
-    static_assert(Fu::HEADROOM >= 64, "a pass of up to 10 lazy stages needs R'/p above 24");
+    static_assert(Fu::HEADROOM >= 64, "values reach (2 + 2 log2 N) p < 64 p over the stages of a transform (N <= 2^30)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Fu* sm = reinterpret_cast<Fu*>(smem_raw);
     Fr* __restrict__ out = reinterpret_cast<Fr*>(nb.out[blockIdx.y]);
-    const Fr* __restrict__ in = a.first ? reinterpret_cast<const Fr*>(nb.in[blockIdx.y]) : out;
+    const Fr* __restrict__ in = reinterpret_cast<const Fr*>(nb.in[blockIdx.y]);
+    Fu* __restrict__ wide = reinterpret_cast<Fu*>(nb.wide[blockIdx.y]);
     const uint32_t in_len = nb.in_len[blockIdx.y];
     const int s = a.t1 - a.t0;
     const int tile_log = a.tile_log;
@@ -88,8 +91,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, cons
                 v = Fu::zero();
             }
         } else {
-            Fr raw = in[idx];
-            v = Fu::unpack(raw.l);
+            v = wide[idx];
         }
         sm[e] = v;
     }
@@ -123,12 +125,11 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, cons
         uint32_t g = g0 + c;
         uint32_t idx = ((g >> a.t0) << a.t1) | (mid << a.t0) | (g & lomask);
         Fu v = sm[e];
-        if (a.last) {
-            if (idx >= a.out_len) continue;
-            if (post) { Fr pw = post[idx]; v = Fu::mul_nr(Fu::unpack(pw.l), v); }
-            if (scale) { Fr sc = scale[0]; v = Fu::mul_nr(Fu::unpack(sc.l), v); }
-        }
-        v = (a.last && (post || scale)) ? Fu::template canon<1>(v) : Fu::template canon<16>(v);
+        if (!a.last) { wide[idx] = v; continue; }
+        if (idx >= a.out_len) continue;
+        if (post) { Fr pw = post[idx]; v = Fu::mul_nr(Fu::unpack(pw.l), v); }
+        if (scale) { Fr sc = scale[0]; v = Fu::mul_nr(Fu::unpack(sc.l), v); }
+        v = (post || scale) ? Fu::template canon<1>(v) : Fu::template canon<32>(v);
         Fr o;
         v.pack(o.l);
         out[idx] = o;
