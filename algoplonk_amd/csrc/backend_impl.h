@@ -799,7 +799,12 @@ int CurveBackend<FRP, FPP, CURVE_ID>::setup_trace(const apk_circuit_desc* d) {
         HIPCHK(hipMemcpyAsync(s.wl.p, cols[i], fn, hipMemcpyHostToDevice, st));
         if (i == 4) { CHK(qk_lag_trace_.alloc(fn)); HIPCHK(hipMemcpyAsync(qk_lag_trace_.p, s.wl.p, fn, hipMemcpyDeviceToDevice, st)); }
         CHK(inv_ntt_n(st, ptr<Fr>(s.wl), ptr<Fr>(*can[i])));
-        if (i < 4) { CHK(cos[i]->alloc(f4)); CHK(coset_ntt_4n(st, ptr<Fr>(*can[i]), n_, ptr<Fr>(*cos[i]))); }
+        if (i < 4) {
+            CHK(cos[i]->alloc(f4));
+            CHK(coset_ntt_4n(st, ptr<Fr>(*can[i]), n_, ptr<Fr>(*cos[i])));
+            // into the quotient kernel's radix (kernels_poly.h): 32 q, and 1024 q for qm
+            scale_kernel<FRP><<<cdiv(n4_, POLY_THREADS), POLY_THREADS, 0, st>>>(ptr<Fr>(*cos[i]), fr_u64(i == 2 ? 1u << 10 : 1u << 5), n4_); KCHK();
+        }
         HIPCHK(hipStreamSynchronize(st));
     }
     // rows of Qk the prover writes per proof: public inputs 0..nb_public-1 and the commitment rows.  With few of them the
@@ -828,6 +833,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::setup_trace(const apk_circuit_desc* d) {
         HIPCHK(hipMemcpyAsync(s.wl.p, d->qcp[k], fn, hipMemcpyHostToDevice, st));
         CHK(inv_ntt_n(st, ptr<Fr>(s.wl), ptr<Fr>(qcp_c_[k])));
         CHK(coset_ntt_4n(st, ptr<Fr>(qcp_c_[k]), n_, ptr<Fr>(eqcp_[k])));
+        scale_kernel<FRP><<<cdiv(n4_, POLY_THREADS), POLY_THREADS, 0, st>>>(ptr<Fr>(eqcp_[k]), fr_u64(1u << 5), n4_); KCHK();
         HIPCHK(hipStreamSynchronize(st));
     }
     // permutation polynomials: S_j[i] = u^(p/n) * omega^(p mod n), p = perm[j n + i]   (gnark trace.S)
@@ -1031,8 +1037,12 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         q.x = ptr<Fr>(x4_); q.l0 = ptr<Fr>(l0_4_);
         q.nb_commit = (int)nb_commit_;
         for (uint32_t k = 0; k < nb_commit_; k++) { q.qcp[k] = ptr<Fr>(eqcp_[k]); q.pi2[k] = ptr<Fr>(s.epi2[k]); }
-        q.alpha = alpha; q.beta = beta; q.gamma = gamma; q.beta_u = beta_u; q.beta_u2 = beta_u2; q.alpha2 = alpha * alpha;
-        for (int k = 0; k < 4; k++) q.zh_inv[k] = zh_inv_[k];
+        // the kernel multiplies in the radix R' = 32 R: constants carry the factors its header lists
+        const Fr c5 = fr_u64(1u << 5), c10 = fr_u64(1u << 10), c20 = fr_u64(1u << 20);
+        q.alpha = alpha * c20; q.beta = beta * c5; q.gamma = gamma; q.beta_u = beta_u * c5; q.beta_u2 = beta_u2 * c5;
+        q.alpha2 = alpha * alpha * c10;
+        for (int k = 0; k < 4; k++) q.zh_inv[k] = zh_inv_[k] * c5;
+        for (int j = 0; j < q.nb_inject; j++) q.inj_delta[j] = q.inj_delta[j] * c5;
         q.n4 = n4_;
         quotient_kernel<FRP><<<cdiv(n4_, POLY_THREADS), POLY_THREADS, 0, st>>>(q, ptr<Fr>(s.quot)); KCHK();
         CHK(run_ntt(st, 1, true, ptr<Fr>(s.quot), ptr<Fr>(s.hcan), n4_, n4_, nullptr, ptr<Fr>(coset_post_inv_), nullptr));

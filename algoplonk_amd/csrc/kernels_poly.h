@@ -8,6 +8,7 @@
 // All are HBM-streaming kernels: 32 B/element/operand, one read of each operand and one write.
 #pragma once
 #include "ff.h"
+#include "ffu.h"
 
 namespace apk {
 
@@ -233,24 +234,55 @@ struct QuotientArgs {
     uint32_t n4;
 };
 
+// The kernel works on unsaturated limbs (ffu.h) without conditional subtractions, like the NTT tiles: polynomial VALUES stay in
+// gnark's radix R, while what multiplies them is handed over in the product's own radix R' = 32 R, so w'(R') * v(R) / R' = w v (R):
+//   * the selector tables ql, qr, qo, qcp hold 32 q and qm holds 1024 q (its operand l*r is a product of two values: / 32 more);
+//   * beta, beta_u, beta_u2, zh_inv, inj_delta arrive as 32 x, alpha as 2^20 alpha (three value products behind it),
+//     alpha2 as 2^10 alpha^2 (one value product behind it); gamma stays in R (it is added, not multiplied).
+// Bounds (R'/r >= 71): sums of a few products stay below 16 r, every product of such a sum with a canonical factor below 2 r.
 template <class FR>
 __global__ void __launch_bounds__(POLY_THREADS) quotient_kernel(QuotientArgs<FR> a, Fe<FR>* __restrict__ out) {
     using Fr = Fe<FR>;
+    using U = FeU<FR>;
+    static_assert(U::HEADROOM >= 64, "lazy sums of up to 16 r times a canonical factor must stay below 2 r");
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n4) return;
-    Fr l = a.l[i], r = a.r[i], o = a.o[i], z = a.z[i];
-    uint32_t is = i + 4 < a.n4 ? i + 4 : i + 4 - a.n4;
-    Fr zs = a.z[is];
-    Fr gate = a.ql[i] * l + a.qr[i] * r + a.qm[i] * (l * r) + a.qo[i] * o + a.qk[i];
-    for (int k = 0; k < a.nb_commit; k++) gate = gate + a.qcp[k][i] * a.pi2[k][i];
-    for (int j = 0; j < a.nb_inject; j++) gate = gate + a.inj_delta[j] * a.inj_tab[j][i];
-    Fr lg = l + a.gamma, rg = r + a.gamma, og = o + a.gamma;
-    Fr x = a.x[i];
-    Fr pa = zs * (lg + a.beta * a.s1[i]) * (rg + a.beta * a.s2[i]) * (og + a.beta * a.s3[i]);
-    Fr pb = z * (lg + a.beta * x) * (rg + a.beta_u * x) * (og + a.beta_u2 * x);
-    Fr loc = a.l0[i] * (z - Fr::one());
-    Fr num = gate + a.alpha * (pa - pb) + a.alpha2 * loc;
-    out[i] = num * a.zh_inv[i & 3];
+    auto ld = [](const Fr* p, uint32_t k) { Fr v = p[k]; return U::unpack(v.l); };
+    auto cst = [](const Fr& v) { return U::unpack(v.l); };
+    const U l = ld(a.l, i), r = ld(a.r, i), o = ld(a.o, i), z = ld(a.z, i);
+    const uint32_t is = i + 4 < a.n4 ? i + 4 : i + 4 - a.n4;
+    const U zs = ld(a.z, is);
+    U gate = U::add_n(U::mul_nr(ld(a.ql, i), l), U::mul_nr(ld(a.qr, i), r));
+    gate = U::add_n(gate, U::mul_nr(ld(a.qm, i), U::mul_nr(l, r)));
+    gate = U::add_n(gate, U::mul_nr(ld(a.qo, i), o));
+    gate = U::add_n(gate, ld(a.qk, i));
+    for (int k = 0; k < a.nb_commit; k++) gate = U::add_n(gate, U::mul_nr(ld(a.qcp[k], i), ld(a.pi2[k], i)));
+    for (int j = 0; j < a.nb_inject; j++) gate = U::add_n(gate, U::mul_nr(cst(a.inj_delta[j]), ld(a.inj_tab[j], i)));
+    const U gm = cst(a.gamma), beta = cst(a.beta);
+    const U lg = U::add_n(l, gm), rg = U::add_n(r, gm), og = U::add_n(o, gm);          // < 2
+    const U x = ld(a.x, i);
+    U pa = U::mul_nr(zs, U::add_n(lg, U::mul_nr(beta, ld(a.s1, i))));                   // factors < 4, products < 1.1
+    pa = U::mul_nr(pa, U::add_n(rg, U::mul_nr(beta, ld(a.s2, i))));
+    pa = U::mul_nr(pa, U::add_n(og, U::mul_nr(beta, ld(a.s3, i))));
+    U pb = U::mul_nr(z, U::add_n(lg, U::mul_nr(beta, x)));
+    pb = U::mul_nr(pb, U::add_n(rg, U::mul_nr(cst(a.beta_u), x)));
+    pb = U::mul_nr(pb, U::add_n(og, U::mul_nr(cst(a.beta_u2), x)));
+    const U perm = U::mul_nr(cst(a.alpha), U::template sub_k<2>(pa, pb));
+    const Fr one_r = Fr::one();
+    const U one = U::unpack(one_r.l);
+    const U loc = U::mul_nr(cst(a.alpha2), U::mul_nr(ld(a.l0, i), U::template sub_k<1>(z, one)));
+    const U num = U::add_n(U::add_n(gate, perm), loc);                                   // < 16
+    const U res = U::template canon<1>(U::mul_nr(cst(a.zh_inv[i & 3]), num));
+    Fr w;
+    res.pack(w.l);
+    out[i] = w;
+}
+
+// p[i] *= c  (setup: selector tables into the quotient kernel's radix)
+template <class FR>
+__global__ void __launch_bounds__(POLY_THREADS) scale_kernel(Fe<FR>* __restrict__ p, Fe<FR> c, uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) p[i] = p[i] * c;
 }
 
 // ---- evaluation: partial[p][block] = sum_i f_p[i] * pw[i] -------------------------------------------------
