@@ -340,14 +340,33 @@ class CurveBackend : public Backend {
         // sum_k k*B_k: row/column sums of the bucket array, bit-wise weighted sums of those, final scaling + affine
         const int m_bits = c_ - 1, cols_log = m_bits - m_bits / 2;
         const uint32_t rows = 1u << (m_bits / 2), cols = 1u << cols_log;
-        msm_rowcol_kernel<FPP><<<dim3(rows + cols, a.batch), 256, 0, st>>>(ptr<PtU>(s.bucket_sum), NB_, rows, cols, ptr<PtU>(s.rowcol));
-        KCHK();
         const uint32_t nbits = (uint32_t)cols_log + 1;  // weights <= cols
-        msm_bitsum_kernel<FPP><<<dim3(nbits, 2, a.batch), 256, 0, st>>>(ptr<PtU>(s.rowcol), rows, cols, ptr<PtU>(s.bit_partial));
+        // Four lanes per point operation in the three reduction kernels (ec.h add_quad_general / dbl_quad_general): they are
+        // chains of dependent point operations on lone waves, and a quad finishes an addition in 4 product stages instead of 14
+        // products (2^17: bit sums 55 -> 30 us, final 97 -> 50 us, row/column sums 73 -> 45 us per batch).  The row/column kernel
+        // has real work (2 additions per bucket) and pays for the quads with 1.7x its VALU instructions: -3 % proofs/s at
+        // saturation, so contexts with more than two slots keep its one-lane form.  APK_MSM_QUAD_TAIL overrides the choice with
+        // a bit mask (1 row/column sums, 2 bit sums, 4 final).
+        // Logical threads per workgroup: the longer of rows / cols, at most 128 (512 lanes leave each lane 256 registers).
+        static const int quad_env = getenv("APK_MSM_QUAD_TAIL") ? atoi(getenv("APK_MSM_QUAD_TAIL")) : -1;
+        const int quad = quad_env >= 0 ? quad_env : (slots_.size() <= 2 ? 7 : 6);
+        const uint32_t lt = (rows > cols ? rows : cols) > 128 ? 128 : (rows > cols ? rows : cols);
+        if (quad & 1)
+            msm_rowcol_quad_kernel<FPP><<<dim3(rows + cols, a.batch), 4 * lt, lt * sizeof(PtU), st>>>(ptr<PtU>(s.bucket_sum), NB_, rows, cols, ptr<PtU>(s.rowcol));
+        else
+            msm_rowcol_kernel<FPP><<<dim3(rows + cols, a.batch), 256, 0, st>>>(ptr<PtU>(s.bucket_sum), NB_, rows, cols, ptr<PtU>(s.rowcol));
+        KCHK();
+        if (quad & 2)
+            msm_bitsum_quad_kernel<FPP><<<dim3(nbits, 2, a.batch), 4 * lt, lt * sizeof(PtU), st>>>(ptr<PtU>(s.rowcol), rows, cols, ptr<PtU>(s.bit_partial));
+        else
+            msm_bitsum_kernel<FPP><<<dim3(nbits, 2, a.batch), 256, 0, st>>>(ptr<PtU>(s.rowcol), rows, cols, ptr<PtU>(s.bit_partial));
         KCHK();
         // the sums leave the device in XYZZ form: the one field inversion of the affine conversion takes a lone GPU lane
-        // ~45 us and the host a few; sync_results() finishes them into h_out (= the slot's pinned buffer)
-        msm_final_kernel<FPP><<<a.batch, 64, 0, st>>>(ptr<PtU>(s.bit_partial), nbits, cols_log, nullptr, ptr<Pt>(s.result_xyzz));
+        // ~100 us and the host a few; sync_results() finishes them into h_out (= the slot's pinned buffer)
+        if (quad & 4)
+            msm_final_quad_kernel<FPP><<<a.batch, 256, 0, st>>>(ptr<PtU>(s.bit_partial), nbits, cols_log, nullptr, ptr<Pt>(s.result_xyzz));
+        else
+            msm_final_kernel<FPP><<<a.batch, 64, 0, st>>>(ptr<PtU>(s.bit_partial), nbits, cols_log, nullptr, ptr<Pt>(s.result_xyzz));
         KCHK();
         if (stats_on_) HIPCHK(hipEventRecord(s.ev1, st));
         (void)h_out;

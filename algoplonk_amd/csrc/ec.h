@@ -113,7 +113,7 @@ struct XYZZ {
     // Same formulas as madd / add / dbl, but no conditional subtraction anywhere: differences add a multiple of p,
     // products skip the final reduction, and Y3 = A*(B - X3) - C*D is taken as -(A*(X3 - B) + C*D) with ONE Montgomery
     // reduction for both products.  Points are then held in the LAZY CLASS - limbs normalised, values only congruent:
-    //     X < 5.1p,  Y <= 2p,  ZZ, ZZZ < 1.4p,  infinity <=> ZZ is exactly zero
+    //     X < 5.1p,  Y <= 4p (2p from the one-lane forms),  ZZ, ZZZ < 1.4p,  infinity <=> ZZ is exactly zero
     // which every lazy operation maps into itself (R'/p >= 160: a product of operands below a*p and b*p is below
     // (1 + a*b/160)*p; the bounds of the intermediates are noted per line).  to_fe_point() accepts the class as it is, so
     // the affine result is bit for bit the one the canonical formulas give.
@@ -165,21 +165,26 @@ struct XYZZ {
     APK_HD void lazy_fix_sign(bool flipped) {
         if (flipped) Y = F::template neg_k<2>(Y);
     }
-    APK_HD void lazy_neg() { Y = F::template neg_k<2>(Y); }
+    APK_HD void lazy_neg() { Y = F::template neg_k<4>(Y); }
     // lazy class -> canonical limbs (tests; to_fe_point does not need it)
     APK_HD void canonicalize() {
         X = F::template canon<4>(X);
-        Y = F::template canon<2>(Y);
+        Y = F::template canon<4>(Y);
         ZZ = F::template canon<1>(ZZ);
         ZZZ = F::template canon<1>(ZZZ);
     }
 
+    // cheap filter for Y in {0, p, 2p, 3p, 4p}
+    APK_HD static bool lazy_y_maybe_zero(const F& y) {
+        const uint32_t l0 = y.l[0];
+        return l0 == 0u || l0 == FP::umod(0) || l0 == F::template kp<2>(0) || l0 == F::template kp<3>(0) || l0 == F::template kp<4>(0);
+    }
     // 2p for p in the lazy class
     APK_HD static XYZZ dbl_lazy(const XYZZ& p) {
         static_assert(F::HEADROOM >= 160, "the bounds of the lazy class need R'/p >= 160");
         if (p.is_inf()) return inf();
-        if (p.Y.l[0] == 0u || p.Y.l[0] == FP::umod(0) || p.Y.l[0] == F::template kp<2>(0)) {   // Y = 0 mod p: a 2-torsion point
-            if (F::template canon<2>(p.Y).is_zero()) return inf();
+        if (lazy_y_maybe_zero(p.Y)) {                          // Y = 0 mod p: a 2-torsion point
+            if (F::template canon<4>(p.Y).is_zero()) return inf();
         }
         const F U = F::add_n(p.Y, p.Y);                        // <= 4
         const F V = F::sqr_nr(U);                              // < 1.1
@@ -223,6 +228,74 @@ struct XYZZ {
         ZZ = F::mul_nr(F::mul_nr(ZZ, q.ZZ), PP);
         ZZZ = F::mul_nr(F::mul_nr(ZZZ, q.ZZZ), PPP);
     }
+
+#if defined(__HIPCC__)
+    // ---- FOUR LANES PER POINT OPERATION (the latency-bound reduction kernels after the bucket accumulation) ----------
+    // The quad's lanes (4k .. 4k+3) hold identical copies of the operands; each stage is ONE field product per lane on
+    // lane-dependent operands (branch-free masks), the results are broadcast inside the quad with DPP quad_perm moves, the
+    // cheap sums are recomputed by every lane.  A full addition is 4 product stages instead of 12M + 2S on one lane, a
+    // doubling 3 stages instead of 6M + 3S.  Same lazy class, with Y3 = -(A + B) from two separately reduced products
+    // (<= 4p); all four lanes end with the same result.  Must be called by all four lanes of a quad together.
+    template <int SRC>
+    __device__ __forceinline__ static F quad_bcast(const F& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        F r;
+#pragma unroll
+        for (int i = 0; i < F::L; i++)
+            r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], SRC | (SRC << 2) | (SRC << 4) | (SRC << 6), 0xf, 0xf, true);
+        return r;
+#else
+        return v;
+#endif
+    }
+    __device__ __forceinline__ static F quad_sel(int q, const F& a0, const F& a1, const F& a2, const F& a3) {
+        // masks, not ternaries: hipcc turns a chain of ?: on values that live in registers into divergent branches
+        const uint32_t m0 = 0u - (uint32_t)(q == 0), m1 = 0u - (uint32_t)(q == 1), m2 = 0u - (uint32_t)(q == 2), m3 = 0u - (uint32_t)(q == 3);
+        F r;
+#pragma unroll
+        for (int i = 0; i < F::L; i++) r.l[i] = (a0.l[i] & m0) | (a1.l[i] & m1) | (a2.l[i] & m2) | (a3.l[i] & m3);
+        return r;
+    }
+    // 2p, p not at infinity (the caller checks; a point with Y = 0 doubles to infinity)
+    __device__ __forceinline__ static XYZZ dbl_quad_general(const XYZZ& p, int q) {
+        static_assert(F::HEADROOM >= 160, "the bounds of the lazy class need R'/p >= 160");
+        const F U = F::add_n(p.Y, p.Y);                                   // <= 8
+        const F s1 = quad_sel(q, U, p.X, U, p.X);
+        const F m1 = F::mul_nr(s1, s1);                                   // lane 0: V = U^2, lane 1: X^2
+        const F V = quad_bcast<0>(m1);
+        const F M = F::triple_n(quad_bcast<1>(m1));                       // < 3.6
+        const F m2 = F::mul_nr(quad_sel(q, U, p.X, V, M), quad_sel(q, V, V, p.ZZ, M));
+        const F W = quad_bcast<0>(m2), S = quad_bcast<1>(m2), MM = quad_bcast<3>(m2);   // U V, X V, M^2
+        XYZZ r;
+        r.ZZ = quad_bcast<2>(m2);                                         // V ZZ
+        r.X = F::template sub2_k<4>(MM, F::zero(), S);
+        const F T = F::template sub_k<2>(r.X, S);
+        const F m3 = F::mul_nr(quad_sel(q, M, W, W, M), quad_sel(q, T, p.Y, p.ZZZ, T));
+        r.Y = F::template neg_k<4>(F::add_n(quad_bcast<0>(m3), quad_bcast<1>(m3)));   // M (S - X3) - W Y
+        r.ZZZ = quad_bcast<2>(m3);                                        // W ZZZ
+        const bool y0 = lazy_y_maybe_zero(p.Y) && F::template canon<4>(p.Y).is_zero();
+        if (y0) r.ZZ = F::zero();                                         // 2-torsion: infinity (ZZ exactly zero)
+        return r;
+    }
+    // general case only: neither operand at infinity, operands not equal / opposite (the caller checks `ok` = quad-uniform)
+    __device__ __forceinline__ void add_quad_general(const XYZZ& o, int q, bool& degenerate) {
+        const F m1 = F::mul_nr(quad_sel(q, X, o.X, Y, o.Y), quad_sel(q, o.ZZ, ZZ, o.ZZZ, ZZZ));
+        const F U1 = quad_bcast<0>(m1), U2 = quad_bcast<1>(m1), S1 = quad_bcast<2>(m1), S2 = quad_bcast<3>(m1);
+        const F Pd = F::template sub_k<2>(U2, U1);
+        const F R = F::template sub_k<2>(S2, S1);
+        const F m2 = F::mul_nr(quad_sel(q, Pd, ZZ, R, ZZZ), quad_sel(q, Pd, o.ZZ, R, o.ZZZ));
+        const F PP = quad_bcast<0>(m2), ZZ12 = quad_bcast<1>(m2), RR = quad_bcast<2>(m2), ZZZ12 = quad_bcast<3>(m2);
+        degenerate = (PP.l[0] == 0u || PP.l[0] == FP::umod(0)) && PP.is_zero_mod_p();
+        const F m3 = F::mul_nr(quad_sel(q, Pd, U1, ZZ12, Pd), PP);
+        const F PPP = quad_bcast<0>(m3), Q = quad_bcast<1>(m3);
+        const F X3 = F::template sub2_k<4>(RR, PPP, Q);
+        const F T = F::template sub_k<2>(X3, Q);
+        const F m4 = F::mul_nr(quad_sel(q, R, S1, ZZZ12, R), quad_sel(q, T, PPP, PPP, T));
+        const F Y3 = F::template neg_k<4>(F::add_n(quad_bcast<0>(m4), quad_bcast<1>(m4)));
+        const F ZZ3 = quad_bcast<2>(m3), ZZZ3 = quad_bcast<2>(m4);
+        if (!degenerate) { X = X3; Y = Y3; ZZ = ZZ3; ZZZ = ZZZ3; }   // a degenerate pair is left untouched for the one-lane form
+    }
+#endif
 
     // this += q
     APK_HD void add(const XYZZ& q) {

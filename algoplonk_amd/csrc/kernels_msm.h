@@ -441,6 +441,104 @@ __global__ void __launch_bounds__(64) msm_final_kernel(const XYZZ<FP, FeU<FP>>* 
     }
 }
 
+// ---- the three reduction kernels with FOUR LANES PER POINT OPERATION (ec.h add_quad_general / dbl_quad_general) ---------------
+// They are chains of dependent point operations on a handful of waves: a lone lane needs ~7 us per addition.  With a quad per
+// logical thread (lanes 4t .. 4t+3 hold copies of the same point, LDS holds one copy) an addition is 4 product stages plus
+// branch-free operand selects and DPP broadcasts: ~1600 instructions instead of ~3700.  blockDim = 4 * logical threads.
+// The four-lane functions handle the general case only and keep no large temporaries (nothing may live in scratch memory):
+// infinities are copies, a degenerate pair (P = +-Q) falls back to the one-lane form on every lane.
+// one tree level: acc += o
+template <class PT>
+__device__ __forceinline__ void quad_tree_add(PT& acc, const PT& o, int q) {
+    if (acc.is_inf()) acc = o;
+    else if (!o.is_inf()) {
+        bool degenerate;
+        acc.add_quad_general(o, q, degenerate);
+        if (degenerate) acc.add_lazy(o);
+    }
+}
+
+template <class FP>
+__global__ void __launch_bounds__(512) msm_rowcol_quad_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum, uint32_t nb, uint32_t rows,
+                                                              uint32_t cols, XYZZ<FP, FeU<FP>>* __restrict__ rc) {
+    using PT = XYZZ<FP, FeU<FP>>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    PT* sm = reinterpret_cast<PT*>(smem_raw);
+    const uint32_t m = blockIdx.y, x = blockIdx.x, t = threadIdx.x >> 2, LT = blockDim.x >> 2;
+    const int q = threadIdx.x & 3;
+    const PT* src = bucket_sum + (size_t)m * nb;
+    PT acc = PT::inf();
+    if (x < rows) {
+        for (uint32_t lo = t; lo < cols; lo += LT) quad_tree_add(acc, src[x * cols + lo], q);
+    } else {
+        const uint32_t col = x - rows;
+        for (uint32_t hi = t; hi < rows; hi += LT) quad_tree_add(acc, src[hi * cols + col], q);
+    }
+    if (q == 0) sm[t] = acc;
+    __syncthreads();
+    for (uint32_t d = LT >> 1; d >= 1; d >>= 1) {
+        if (t < d) { PT o = sm[t + d]; quad_tree_add(acc, o, q); if (q == 0) sm[t] = acc; }
+        __syncthreads();
+    }
+    if (t == 0 && q == 0) rc[(size_t)m * (rows + cols) + x] = acc;
+}
+
+template <class FP>
+__global__ void __launch_bounds__(256) msm_final_quad_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ bit_partial, uint32_t nbits, int cols_log,
+                                                             Affine<FP>* __restrict__ result, XYZZ<FP>* __restrict__ result_xyzz) {
+    using PT = XYZZ<FP, FeU<FP>>;
+    __shared__ PT sm[64];
+    const uint32_t m = blockIdx.x, t = threadIdx.x >> 2;
+    const int q = threadIdx.x & 3;
+    const uint32_t which = t >> 5, bit = t & 31;
+    PT acc = PT::inf();
+    int dbl = 0;
+    if (bit < nbits) {
+        acc = bit_partial[((size_t)m * 2 + which) * 32 + bit];
+        dbl = (int)bit + (which == 0 ? cols_log : 0);
+    }
+    // every quad runs the same number of loop trips (the longest chain); quads that are done, or hold infinity, idle
+    const int max_dbl = (int)nbits - 1 + cols_log;
+    for (int i = 0; i < max_dbl; i++) {
+        if (i < dbl && !acc.is_inf()) acc = PT::dbl_quad_general(acc, q);
+    }
+    if (q == 0) sm[t] = acc;
+    __syncthreads();
+    for (uint32_t d = 32; d >= 1; d >>= 1) {
+        if (t < d) { PT o = sm[t + d]; quad_tree_add(acc, o, q); if (q == 0) sm[t] = acc; }
+        __syncthreads();
+    }
+    if (t == 0 && q == 0) {
+        XYZZ<FP> g = to_fe_point<FP>(acc);  // back to gnark's Montgomery radix
+        if (result_xyzz) result_xyzz[m] = g;
+        if (result) result[m] = g.to_affine();
+    }
+}
+
+template <class FP>
+__global__ void __launch_bounds__(512) msm_bitsum_quad_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ rc, uint32_t rows, uint32_t cols,
+                                                              XYZZ<FP, FeU<FP>>* __restrict__ bit_partial) {
+    using PT = XYZZ<FP, FeU<FP>>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    PT* sm = reinterpret_cast<PT*>(smem_raw);
+    const uint32_t bit = blockIdx.x, which = blockIdx.y, m = blockIdx.z, t = threadIdx.x >> 2, LT = blockDim.x >> 2;
+    const int q = threadIdx.x & 3;
+    const PT* src = rc + (size_t)m * (rows + cols) + (which ? rows : 0);
+    const uint32_t count = which ? cols : rows;
+    PT acc = PT::inf();
+    for (uint32_t i = t; i < count; i += LT) {
+        const uint32_t weight = which ? i + 1 : i;
+        if ((weight >> bit) & 1u) acc.add_lazy(src[i]);      // at most a couple per lane: the first is a copy
+    }
+    if (q == 0) sm[t] = acc;
+    __syncthreads();
+    for (uint32_t d = LT >> 1; d >= 1; d >>= 1) {
+        if (t < d) { PT o = sm[t + d]; quad_tree_add(acc, o, q); if (q == 0) sm[t] = acc; }
+        __syncthreads();
+    }
+    if (t == 0 && q == 0) bit_partial[((size_t)m * 2 + which) * 32 + bit] = acc;
+}
+
 // ---- table construction: table[j*n + i] = 2^(off[j]) * P_i (affine), stored as packed R'-domain records (ffu.h) ----------------------------------------
 template <class FP>
 __global__ void __launch_bounds__(256) msm_table_kernel(const Affine<FP>* __restrict__ bases, uint32_t n, MsmWindows win,
