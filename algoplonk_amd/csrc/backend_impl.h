@@ -346,13 +346,15 @@ class CurveBackend : public Backend {
         // products (2^17: bit sums 55 -> 30 us, final 97 -> 50 us, row/column sums 73 -> 45 us per batch).  The row/column kernel
         // has real work (2 additions per bucket) and pays for the quads with 1.7x its VALU instructions: -3 % proofs/s at
         // saturation, so contexts with more than two slots keep its one-lane form.  APK_MSM_QUAD_TAIL overrides the choice with
-        // a bit mask (1 row/column sums, 2 bit sums, 4 final).
+        // a bit mask (1 row/column sums, 2 bit sums, 4 final, 8 row/column sums with quads in the last five tree levels only).
         // Logical threads per workgroup: the longer of rows / cols, at most 128 (512 lanes leave each lane 256 registers).
         static const int quad_env = getenv("APK_MSM_QUAD_TAIL") ? atoi(getenv("APK_MSM_QUAD_TAIL")) : -1;
-        const int quad = quad_env >= 0 ? quad_env : (slots_.size() <= 2 ? 7 : 6);
+        const int quad = quad_env >= 0 ? quad_env : (slots_.size() <= 2 ? 7 : 14);
         const uint32_t lt = (rows > cols ? rows : cols) > 128 ? 128 : (rows > cols ? rows : cols);
         if (quad & 1)
             msm_rowcol_quad_kernel<FPP><<<dim3(rows + cols, a.batch), 4 * lt, lt * sizeof(PtU), st>>>(ptr<PtU>(s.bucket_sum), NB_, rows, cols, ptr<PtU>(s.rowcol));
+        else if (quad & 8)
+            msm_rowcol_hybrid_kernel<FPP><<<dim3(rows + cols, a.batch), 256, 0, st>>>(ptr<PtU>(s.bucket_sum), NB_, rows, cols, ptr<PtU>(s.rowcol));
         else
             msm_rowcol_kernel<FPP><<<dim3(rows + cols, a.batch), 256, 0, st>>>(ptr<PtU>(s.bucket_sum), NB_, rows, cols, ptr<PtU>(s.rowcol));
         KCHK();

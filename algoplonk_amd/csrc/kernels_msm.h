@@ -458,6 +458,41 @@ __device__ __forceinline__ void quad_tree_add(PT& acc, const PT& o, int q) {
     }
 }
 
+// Row / column sums for throughput contexts: one lane per operation while a level still has more than 16 additions to do
+// (they run side by side at no extra cost), four lanes per operation for the last five levels, where the chain of dependent
+// additions is all that is left: the latency of those levels halves for a fraction of a percent more VALU work.
+template <class FP>
+__global__ void __launch_bounds__(256) msm_rowcol_hybrid_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum, uint32_t nb, uint32_t rows,
+                                                                uint32_t cols, XYZZ<FP, FeU<FP>>* __restrict__ rc) {
+    using PT = XYZZ<FP, FeU<FP>>;
+    __shared__ PT sm[256];
+    const uint32_t m = blockIdx.y, x = blockIdx.x, t = threadIdx.x;
+    const PT* src = bucket_sum + (size_t)m * nb;
+    PT acc = PT::inf();
+    if (x < rows) {
+        for (uint32_t lo = t; lo < cols; lo += 256) acc.add_lazy(src[x * cols + lo]);
+    } else {
+        const uint32_t col = x - rows;
+        for (uint32_t hi = t; hi < rows; hi += 256) acc.add_lazy(src[hi * cols + col]);
+    }
+    sm[t] = acc;
+    __syncthreads();
+    uint32_t d = 128;
+    for (; d > 16; d >>= 1) {
+        if (t < d) { PT o = sm[t + d]; acc.add_lazy(o); sm[t] = acc; }
+        __syncthreads();
+    }
+    const uint32_t tq = t >> 2;
+    const int q = t & 3;
+    PT qa = PT::inf();
+    if (tq < 16) qa = sm[tq];
+    for (; d >= 1; d >>= 1) {
+        if (tq < d) { PT o = sm[tq + d]; quad_tree_add(qa, o, q); if (q == 0) sm[tq] = qa; }
+        __syncthreads();
+    }
+    if (t == 0) rc[(size_t)m * (rows + cols) + x] = qa;
+}
+
 template <class FP>
 __global__ void __launch_bounds__(512) msm_rowcol_quad_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum, uint32_t nb, uint32_t rows,
                                                               uint32_t cols, XYZZ<FP, FeU<FP>>* __restrict__ rc) {
