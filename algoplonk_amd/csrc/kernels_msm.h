@@ -342,6 +342,11 @@ __global__ void __launch_bounds__(256) msm_combine_heavy_kernel(const XYZZ<FP, F
     const uint32_t t = threadIdx.x;
     const uint32_t per = (total_buckets + gridDim.x - 1) / gridDim.x;
     const uint32_t k0 = blockIdx.x * per, k1 = min(k0 + per, total_buckets);
+    // the common case has no heavy bucket at all: every thread looks at its own buckets first (one round of loads instead of
+    // a serial walk over the slice), and the block only walks the slice if somebody saw one
+    bool any = false;
+    for (uint32_t k = k0 + t; k < k1; k += 256) any |= unit_off[k + 1] - unit_off[k] > MSM_HEAVY_UNITS;
+    if (!__syncthreads_or(any)) return;
     for (uint32_t k = k0; k < k1; k++) {
         const uint32_t beg = unit_off[k], end = unit_off[k + 1];
         if (end - beg <= MSM_HEAVY_UNITS) continue;   // uniform across the block
