@@ -24,7 +24,7 @@ SYMBOLS = [
     "apk_last_error", "apk_abi_version", "apk_device_count", "apk_g1_bytes", "apk_fp_bytes",
     "apk_ctx_create", "apk_ctx_destroy", "apk_msm_ctx_create", "apk_ctx_get_vk", "apk_msm_g1", "apk_msm_g1_device", "apk_ntt",
     "apk_prove", "apk_prove_device", "apk_g1_mul_batch", "apk_g1_decompress", "apk_g1_to_lagrange", "apk_marshal_proof", "apk_marshal_public_inputs",
-    "apk_fe_from_be", "apk_fe_to_be", "apk_hash_fr", "apk_host_fe_op", "apk_host_g1_op",
+    "apk_fe_from_be", "apk_fe_to_be", "apk_hash_fr", "apk_host_fe_op", "apk_host_g1_op", "apk_g1_sum",
     "apk_device_alloc", "apk_device_free", "apk_device_upload", "apk_device_download",
     "apk_stats_enable", "apk_stats_read",
 ]
@@ -105,6 +105,7 @@ def _load() -> C.CDLL:
     lib.apk_hash_fr.argtypes = [i32, vp, vp]
     lib.apk_host_fe_op.argtypes = [i32, i32, i32, vp, vp, vp]
     lib.apk_host_g1_op.argtypes = [i32, i32, vp, vp, vp]
+    lib.apk_g1_sum.argtypes = [i32, vp, u64, vp]
     lib.apk_device_alloc.argtypes = [vp, sz, C.POINTER(vp)]
     lib.apk_device_free.argtypes = [vp, vp]
     lib.apk_device_upload.argtypes = [vp, vp, vp, sz]

@@ -11,6 +11,10 @@ namespace apk {
 
 void set_error(const char* fmt, ...);
 
+// Run-time knob from the environment, clamped to [lo, hi] (a value outside the range can never reach a launch configuration
+// or an allocation size: nothing may abort across the C-ABI); `dflt` when the variable is unset or not a number.
+int env_int(const char* name, int dflt, int lo, int hi);
+
 struct Backend {
     virtual ~Backend() {}
     virtual int init(const apk_circuit_desc* d) = 0;

@@ -135,6 +135,8 @@ class CurveBackend : public Backend {
         DevBuf counts, hist, offsets, unit_off, full_off, rem_rank, rem_list, scan_blk, sorted, partial, bucket_sum, rowcol, bit_partial, result, result_xyzz;
         void* h_pinned = nullptr;  // small pinned staging for results: [0,1024) affine, [1024,2048) XYZZ, [2048,4096) scalars
         uint32_t pending_pts = 0;  // MSM sums waiting in h_pinned for their affine conversion (sync_results)
+        DevBuf tail_flag;          // epoch of the last proof whose quotient had a non-zero tail (tail_nonzero_kernel)
+        uint32_t epoch = 0;
     };
 
     int curve_ = CURVE_ID;
@@ -197,8 +199,8 @@ class CurveBackend : public Backend {
         const Fr* tw = which ? (inverse ? ptr<Fr>(twi_4n_) : ptr<Fr>(tw_4n_)) : (inverse ? ptr<Fr>(twi_n_) : ptr<Fr>(twu_n_));
         // small transforms are latency-bound: 512-element tiles (16 KiB LDS) give >= 256 workgroups at 2^17;
         // large ones are bandwidth-bound: 2048-element tiles and fewer passes
-        static const int tile_env = getenv("APK_NTT_TILE_LOG") ? atoi(getenv("APK_NTT_TILE_LOG")) : 0;
-        static const int stages_env = getenv("APK_NTT_STAGES") ? atoi(getenv("APK_NTT_STAGES")) : 0;
+        static const int tile_env = env_int("APK_NTT_TILE_LOG", 0, 0, NTT_TILE_LOG);     // 0 = default; clamped to what the LDS tile holds
+        static const int stages_env = env_int("APK_NTT_STAGES", 0, 0, NTT_TILE_LOG);
         int tile_log = log_n <= 19 ? 9 : NTT_TILE_LOG;
         int max_s = log_n <= 19 ? 7 : 9;
         if (tile_env) tile_log = tile_env;
@@ -276,7 +278,7 @@ class CurveBackend : public Backend {
         // SIMD that was handed the most waves - so pick the length in [16, 18] whose full-unit waves fill the SIMDs in the fewest
         // whole rounds (2^17, c = 15, one MSM: 16 -> 2056 waves = 3 rounds on some of the 1024 SIMDs, 17 -> 1930 waves = 2 rounds).
         // Longer units lose more to fewer resident waves than the round count says (measured: 20..24 are slower than 16).
-        static const uint32_t unit_env = getenv("APK_MSM_UNIT") ? (uint32_t)atoi(getenv("APK_MSM_UNIT")) : 0u;
+        static const uint32_t unit_env = (uint32_t)env_int("APK_MSM_UNIT", 0, 0, MSM_UNIT_MAX);
         uint32_t unit = unit_env;
         if (!unit) {
             uint64_t best = ~0ull;
@@ -286,17 +288,18 @@ class CurveBackend : public Backend {
                 if (cost < best) { best = cost; unit = u; }
             }
         }
-        if (unit < (uint32_t)MSM_UNIT_MIN || unit > (uint32_t)MSM_UNIT_MAX) { set_error("APK_MSM_UNIT out of [%d, %d]", MSM_UNIT_MIN, MSM_UNIT_MAX); return APK_ERR_ARG; }
+        if (unit < (uint32_t)MSM_UNIT_MIN) unit = MSM_UNIT_MIN;
+        if (unit > (uint32_t)MSM_UNIT_MAX) unit = MSM_UNIT_MAX;
         const uint32_t max_units = (uint32_t)(entries / unit) + total_buckets;
         if (stats_on_) HIPCHK(hipEventRecord(s.ev0, st));
         // counting sort by bucket: LDS-private histograms per scalar slice, column scan, bucket scan, scatter
-        static const uint32_t slice = getenv("APK_MSM_SLICE") ? (uint32_t)atoi(getenv("APK_MSM_SLICE")) : 2048u;  // scalars per sort workgroup
+        static const uint32_t slice = (uint32_t)env_int("APK_MSM_SLICE", 2048, 64, 1 << 20);  // scalars per sort workgroup
         uint32_t G = cdiv(maxlen, slice ? slice : 2048u);
         if (G < 1) G = 1;
         if (G > msm_G_max_) G = msm_G_max_;
         dim3 gd(G, a.batch);
         const size_t lds = (size_t)NB_ * 4;
-        static const int dth = getenv("APK_MSM_DIGITS_THREADS") ? atoi(getenv("APK_MSM_DIGITS_THREADS")) : MSM_DIGITS_THREADS;
+        static const int dth = env_int("APK_MSM_DIGITS_THREADS", MSM_DIGITS_THREADS, 64, MSM_DIGITS_THREADS) & ~63;   // whole waves, <= the launch bound
         msm_digits_kernel<FRP, false><<<gd, dth, lds, st>>>(a, win_, NB_, T.n_bases, G, ptr<uint32_t>(s.counts), nullptr, nullptr);
         KCHK();
         msm_colscan_kernel<0><<<cdiv(total_buckets, 256), 256, 0, st>>>(ptr<uint32_t>(s.counts), NB_, G, total_buckets, ptr<uint32_t>(s.hist));
@@ -348,7 +351,7 @@ class CurveBackend : public Backend {
         // saturation, so contexts with more than two slots keep its one-lane form.  APK_MSM_QUAD_TAIL overrides the choice with
         // a bit mask (1 row/column sums, 2 bit sums, 4 final, 8 row/column sums with quads in the last five tree levels only).
         // Logical threads per workgroup: the longer of rows / cols, at most 128 (512 lanes leave each lane 256 registers).
-        static const int quad_env = getenv("APK_MSM_QUAD_TAIL") ? atoi(getenv("APK_MSM_QUAD_TAIL")) : -1;
+        static const int quad_env = env_int("APK_MSM_QUAD_TAIL", -1, -1, 15);
         const int quad = quad_env >= 0 ? quad_env : (slots_.size() <= 2 ? 7 : 14);
         const uint32_t lt = (rows > cols ? rows : cols) > 128 ? 128 : (rows > cols ? rows : cols);
         if (quad & 1)
@@ -425,6 +428,8 @@ class CurveBackend : public Backend {
         CHK(s.eval_result.alloc(EVAL_MAX * sizeof(Fr)));
         for (uint32_t k = 0; k < nb_commit_; k++) { CHK(s.pi2_lag[k].alloc(fn)); CHK(s.pi2_can[k].alloc(fn)); CHK(s.epi2[k].alloc(f4)); }
         CHK(s.scratch_in.alloc(f4));
+        CHK(s.tail_flag.alloc(16));
+        HIPCHK(hipMemset(s.tail_flag.p, 0, 16));
         CHK(s.ntt_wide.alloc((size_t)NTT_MAX_BATCH * n4_ * sizeof(FeU<FRP>)));
         return alloc_msm_workspace(s, MSM_MAX_BATCH);
     }
@@ -488,8 +493,8 @@ class CurveBackend : public Backend {
     int choose_window(int requested, int log_size) {
         c_ = requested;
         if (c_ == 0) {
-            const char* env = getenv("APK_MSM_WINDOW");
-            if (env) c_ = atoi(env);
+            c_ = env_int("APK_MSM_WINDOW", 0, 0, 16);
+            if (c_ != 0 && c_ < 7) c_ = 7;
         }
         // measured flat between log2(n)-4 and log2(n)-2 (tools/sweep.sh); 16 only pays from 2^21 up (128 KiB LDS histograms)
         if (c_ == 0) { c_ = log_size - 2; if (c_ < 8) c_ = 8; if (c_ > 15) c_ = 15; if (log_size >= 21) c_ = 16; }
@@ -563,7 +568,11 @@ class CurveBackend : public Backend {
         while ((1u << log_n_) < n_) log_n_++;
         nb_public_ = d->nb_public;
         nb_commit_ = d->nb_commitments;
-        for (uint32_t k = 0; k < nb_commit_; k++) cci_[k] = d->commitment_constraint_index[k];
+        for (uint32_t k = 0; k < nb_commit_; k++) {
+            cci_[k] = d->commitment_constraint_index[k];
+            // the prover writes the commitment's hash into row nb_public + cci of Qk: must be a row of the domain on every path
+            if ((uint64_t)nb_public_ + cci_[k] >= n_) { set_error("commitment_constraint_index[%u] = %u: row %llu is outside the domain (n = %u)", k, cci_[k], (unsigned long long)nb_public_ + cci_[k], n_); return APK_ERR_ARG; }
+        }
         msm_bases_ = n_ + 3;
         CHK(choose_window(d->msm_window, (int)log_n_));
         // domain constants on the host (gnark fft.NewDomain [UPSTREAM]; generator = VK Generator,
@@ -630,7 +639,7 @@ class CurveBackend : public Backend {
         int nslots = d->slots > 0 ? d->slots : 1;
         // more than 16 concurrently active streams collapse the throughput (24: -25 %, 32: -40 %, 48: -55 % at 2^17); callers
         // beyond the cap wait for a slot, which also hides their host-side gaps
-        static const int max_slots = getenv("APK_MAX_SLOTS") ? atoi(getenv("APK_MAX_SLOTS")) : 16;
+        static const int max_slots = env_int("APK_MAX_SLOTS", 16, 1, 64);
         if (nslots > max_slots) nslots = max_slots;
         for (int i = 0; i < nslots; i++) {
             Slot* s = new Slot();
@@ -1072,14 +1081,18 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         a.batch = 3;
         for (int j = 0; j < 3; j++) { a.scalars[j] = ptr<Fr>(s.hcan) + (size_t)j * (n + 2); a.len[j] = n + 2; a.offset[j] = 0; }
         CHK(run_msm(s, tab_can_, a, hp));
-        // the quotient is a polynomial of degree < 3n+6 iff the witness satisfies the circuit: check the tail
-        HIPCHK(hipMemcpyAsync(hfr, ptr<Fr>(s.hcan) + 3 * (n + 2), sizeof(Fr) * ((n4_ - 3 * (n + 2)) < 8 ? (n4_ - 3 * (n + 2)) : 8), hipMemcpyDeviceToHost, st));
+        // the quotient is a polynomial of degree < 3n+6 iff the witness satisfies the circuit: every coefficient of the tail
+        // h[3(n+2) .. 4n) must vanish (OR-reduce on the device, one flag word back)
+        s.epoch++;
+        const uint32_t tail4 = (n4_ - 3 * (n + 2)) * (uint32_t)(sizeof(Fr) / 16);
+        tail_nonzero_kernel<0><<<cdiv(tail4, 256 * 8) < 512 ? cdiv(tail4, 256 * 8) : 512, 256, 0, st>>>(
+            reinterpret_cast<const uint4*>(ptr<Fr>(s.hcan) + 3 * (size_t)(n + 2)), tail4, s.epoch, ptr<uint32_t>(s.tail_flag)); KCHK();
+        HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(s.h_pinned) + 3072, s.tail_flag.p, 4, hipMemcpyDeviceToHost, st));
     }
     CHK(sync_results(s));
-    {
-        uint32_t tail = (n4_ - 3 * (n + 2)) < 8 ? (n4_ - 3 * (n + 2)) : 8;
-        for (uint32_t i = 0; i < tail; i++)
-            if (!hfr[i].is_zero()) { set_error("quotient is not a polynomial: the witness does not satisfy the circuit"); return APK_ERR_WITNESS; }
+    if (*reinterpret_cast<const volatile uint32_t*>(reinterpret_cast<const uint8_t*>(s.h_pinned) + 3072) == s.epoch) {
+        set_error("quotient is not a polynomial: the witness does not satisfy the circuit");
+        return APK_ERR_WITNESS;
     }
     Aff hcom[3] = {hp[0], hp[1], hp[2]};
     uint8_t h_bytes[3][2 * FPB];
@@ -1228,7 +1241,7 @@ static inline int pick_device(int device) {
     return APK_OK;
 }
 
-template <class FPP, int CURVE_ID>
+template <class FRP, class FPP, int CURVE_ID>
 int g1_decompress_impl(int device, const uint8_t* in, uint64_t count, void* out) {
     using Aff = Affine<FPP>;
     CHK(pick_device(device));
@@ -1239,7 +1252,7 @@ int g1_decompress_impl(int device, const uint8_t* in, uint64_t count, void* out)
     CHK(derr.alloc(4));
     HIPCHK(hipMemcpy(din.p, in, count * nb, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(derr.p, 0, 4));
-    g1_decompress_kernel<FPP, CURVE_ID><<<cdiv(count, 256), 256>>>(ptr<uint8_t>(din), (uint32_t)count, ptr<Aff>(dout), ptr<uint32_t>(derr));
+    g1_decompress_kernel<FRP, FPP, CURVE_ID><<<cdiv(count, 256), 256>>>(ptr<uint8_t>(din), (uint32_t)count, ptr<Aff>(dout), ptr<uint32_t>(derr));
     KCHK();
     uint32_t bad = 0;
     HIPCHK(hipMemcpy(&bad, derr.p, 4, hipMemcpyDeviceToHost));

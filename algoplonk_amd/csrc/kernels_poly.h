@@ -372,6 +372,19 @@ __global__ void __launch_bounds__(POLY_THREADS) div_finish_kernel(const Fe<FR>* 
 }
 
 // z == 0 fallback: q[j] = f[j+1]
+// The quotient is a polynomial of degree < 3(n+2) iff the witness satisfies the circuit: OR-reduce ALL the words of the
+// coefficients above it (h[3(n+2) .. 4n)).  A non-zero word stamps the proof's epoch into *flag (atomicMax: no zeroing between
+// proofs, nothing is written in the normal case); the host compares the flag with the epoch after the stream sync.
+template <int DUMMY>
+__global__ void __launch_bounds__(256) tail_nonzero_kernel(const uint4* __restrict__ words, uint32_t count4, uint32_t epoch, uint32_t* __restrict__ flag) {
+    uint32_t acc = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += gridDim.x * blockDim.x) {
+        const uint4 v = words[i];
+        acc |= v.x | v.y | v.z | v.w;
+    }
+    if (__ballot(acc != 0) != 0 && (threadIdx.x & 63) == 0) atomicMax(flag, epoch);
+}
+
 template <class FR>
 __global__ void shift_down_kernel(const Fe<FR>* __restrict__ f, uint32_t len, Fe<FR>* __restrict__ q) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;

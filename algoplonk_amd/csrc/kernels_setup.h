@@ -10,8 +10,28 @@
 
 namespace apk {
 
-// in: count x (4*N) big-endian bytes with gnark's flag bits; out: affine Montgomery; err[0] != 0 on a bad point
-template <class FP, int CURVE_ID>
+// k * P for a canonical (non-Montgomery) scalar k
+template <class FR, class FP>
+__device__ __forceinline__ XYZZ<FP> scalar_mul_point(const XYZZ<FP>& P, const Fe<FR>& k) {
+    XYZZ<FP> acc = XYZZ<FP>::inf();
+    bool started = false;
+    for (int w = Fe<FR>::N - 1; w >= 0; w--) {
+        for (int b = 31; b >= 0; b--) {
+            if (started) acc = XYZZ<FP>::dbl(acc);
+            if ((k.l[w] >> b) & 1u) {
+                acc.add(P);
+                started = true;
+            }
+        }
+    }
+    return acc;
+}
+
+// in: count x (4*N) big-endian bytes with gnark's flag bits; out: affine Montgomery; err[0] != 0 on a bad point.
+// Same acceptance as gnark's kzg SRS ReadFrom -> G1Affine.SetBytes [UPSTREAM]: flags, x < p, on the curve, and - on
+// BLS12-381, whose G1 has a cofactor - membership of the order-r subgroup ([r]P = infinity; setup-time only, so the plain
+// 255-bit chain is fine); an infinity encoding must carry nothing but its flag.
+template <class FR, class FP, int CURVE_ID>
 __global__ void __launch_bounds__(256) g1_decompress_kernel(const uint8_t* __restrict__ in, uint32_t count, Affine<FP>* __restrict__ out,
                                                             uint32_t* __restrict__ err) {
     using F = Fe<FP>;
@@ -38,7 +58,11 @@ __global__ void __launch_bounds__(256) g1_decompress_kernel(const uint8_t* __res
         inf = f == 6; largest = f == 5; bad = !(f == 4 || f == 5 || f == 6);
         x.l[N - 1] &= 0x1fffffffu;
     }
-    if (inf) { out[i] = Affine<FP>::inf(); return; }
+    if (inf) {
+        if (!x.is_zero()) atomicAdd(err, 1u);   // non-zero payload under the infinity flag
+        out[i] = Affine<FP>::inf();
+        return;
+    }
     // canonical range check then Montgomery form
     F m = F::modulus();
     bool lt = false;
@@ -62,25 +86,12 @@ __global__ void __launch_bounds__(256) g1_decompress_kernel(const uint8_t* __res
         if (yc.l[w] != h) { y_large = yc.l[w] > h; break; }
     }
     if (y_large != largest) y = F::neg(y);
+    if (CURVE_ID == 1 && !bad) {
+        const XYZZ<FP> rp = scalar_mul_point<FR, FP>(XYZZ<FP>::from_affine(Affine<FP>{xm, y}), Fe<FR>::modulus());
+        if (!rp.is_inf()) bad = true;   // a point of the curve outside G1
+    }
     if (bad) { atomicAdd(err, 1u); out[i] = Affine<FP>::inf(); return; }
     out[i] = Affine<FP>{xm, y};
-}
-
-// k * P for a canonical (non-Montgomery) scalar k
-template <class FR, class FP>
-__device__ __forceinline__ XYZZ<FP> scalar_mul_point(const XYZZ<FP>& P, const Fe<FR>& k) {
-    XYZZ<FP> acc = XYZZ<FP>::inf();
-    bool started = false;
-    for (int w = Fe<FR>::N - 1; w >= 0; w--) {
-        for (int b = 31; b >= 0; b--) {
-            if (started) acc = XYZZ<FP>::dbl(acc);
-            if ((k.l[w] >> b) & 1u) {
-                acc.add(P);
-                started = true;
-            }
-        }
-    }
-    return acc;
 }
 
 // load affine points bit-reversed into XYZZ work space

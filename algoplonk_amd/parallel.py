@@ -11,7 +11,7 @@ ROCm; "gloo" in the CPU tests).
 from __future__ import annotations
 
 import ctypes as C
-from typing import Callable, List, Optional, Sequence, Tuple
+from typing import Tuple
 
 from . import ecc
 from ._lib import lib, check
@@ -31,8 +31,17 @@ def g1_add(curve: ecc.ID, P: bytes, Q: bytes) -> bytes:
     return out.raw
 
 
+def g1_sum(curve: ecc.ID, points: bytes) -> bytes:
+    """Sum of len(points) / (64|96) gnark-layout affine points in ONE library call (apk_g1_sum, host)."""
+    nb = 2 * curve.fp_bytes
+    out = C.create_string_buffer(nb)
+    check(lib.apk_g1_sum(curve.abi, points, len(points) // nb, out))
+    return out.raw
+
+
 def gather_and_add(curve: ecc.ID, partial: bytes, group=None) -> bytes:
-    """All-gather one affine point per rank and add them up locally (same result on every rank)."""
+    """The one exchange step of a sharded MSM: all-gather one affine point per rank into ONE (world x 64|96)-byte tensor,
+    one device-to-host copy, one library call for the world-1 point additions (same result on every rank)."""
     import torch
     import torch.distributed as dist
 
@@ -40,40 +49,38 @@ def gather_and_add(curve: ecc.ID, partial: bytes, group=None) -> bytes:
     world = dist.get_world_size(group)
     dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
     mine = torch.frombuffer(bytearray(partial), dtype=torch.uint8).to(dev)
-    bufs = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(world)]
-    dist.all_gather(bufs, mine, group=group)
-    acc = bytes(nb)  # infinity
-    for t in bufs:
-        acc = g1_add(curve, acc, bytes(t.cpu().numpy().tobytes()))
-    return acc
+    allpts = torch.empty(world * nb, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(allpts, mine, group=group)
+    return g1_sum(curve, allpts.cpu().numpy().tobytes())
 
 
 class ShardedMsm:
-    """sum_i s_i * P_i with the index range split across the ranks of a process group."""
+    """sum_i s_i * P_i with the index range split across the ranks of a process group: rank r keeps the windowed tables of
+    bases [lo_r, hi_r) resident in its own HBM (an MSM-only libapk context)."""
 
-    def __init__(self, curve: ecc.ID, bases: bytes, device: int, rank: int, world: int, msm_window: int = 0,
-                 local_msm: Optional[Callable[[bytes, int], bytes]] = None):
+    def __init__(self, curve: ecc.ID, bases: bytes, device: int, rank: int, world: int, msm_window: int = 0):
         self.curve, self.rank, self.world = curve, rank, world
         nb = 2 * curve.fp_bytes
         self.total = len(bases) // nb
         self.lo, self.hi = my_share(self.total, rank, world)
-        self._local = local_msm
         self._ctx = C.c_void_p()
-        self._bases = bases[self.lo * nb: self.hi * nb]
-        if local_msm is None and self.hi > self.lo:
-            check(lib.apk_msm_ctx_create(curve.abi, device, self._bases, self.hi - self.lo, msm_window, C.byref(self._ctx)))
+        if self.hi > self.lo:
+            self._open(bases[self.lo * nb: self.hi * nb], device, msm_window)
+
+    def _open(self, my_bases: bytes, device: int, msm_window: int) -> None:
+        check(lib.apk_msm_ctx_create(self.curve.abi, device, my_bases, self.hi - self.lo, msm_window, C.byref(self._ctx)))
+
+    def local_partial(self, mine: bytes) -> bytes:
+        """Partial sum over this rank's `mine` = scalars[lo:hi] (Montgomery bytes), on this rank's GPU."""
+        out = C.create_string_buffer(2 * self.curve.fp_bytes)
+        check(lib.apk_msm_g1(self._ctx, 0, mine, self.hi - self.lo, out))
+        return out.raw
 
     def partial(self, scalars: bytes) -> bytes:
         """This rank's partial sum over its index range; `scalars` = the FULL Montgomery scalar vector."""
-        cv = self.curve
-        mine = scalars[self.lo * 32: self.hi * 32]
         if self.hi == self.lo:
-            return bytes(2 * cv.fp_bytes)
-        if self._local is not None:
-            return self._local(mine, self.lo)
-        out = C.create_string_buffer(2 * cv.fp_bytes)
-        check(lib.apk_msm_g1(self._ctx, 0, mine, self.hi - self.lo, out))
-        return out.raw
+            return bytes(2 * self.curve.fp_bytes)
+        return self.local_partial(scalars[self.lo * 32: self.hi * 32])
 
     def run(self, scalars: bytes, group=None) -> bytes:
         return gather_and_add(self.curve, self.partial(scalars), group)

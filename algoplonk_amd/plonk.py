@@ -160,17 +160,16 @@ def Setup(ccs: frontend.ConstraintSystem, srs: SRS, device: int = 0, msm_window:
     return pk, vk
 
 
-def Prove(ccs: frontend.ConstraintSystem, pk: ProvingKey, witness: frontend.Witness,
-          blinding: Optional[Sequence[int]] = None, hiding=None) -> Proof:
-    """plonk.Prove(ccs, pk, witness) (/root/reference/algoplonk.go:89).  `blinding` = the 9 scalars gnark draws
-    from crypto/rand; drawn from os.urandom when omitted."""
+def solve_with_commitments(ccs: frontend.ConstraintSystem, pk: ProvingKey, witness: frontend.Witness, hiding=None):
+    """Round 0 of plonk.Prove for circuits with BSB22 commitments: gnark's solver with its bsb22 hint - kzg.Commit(committed
+    column, Lagrange SRS) on the GPU (apk_msm_g1, basis 1), then hash_to_field on the host (apk_hash_fr).  Returns
+    (solution, pi2 columns)."""
     cv = pk.curve
     nbc = len(ccs.commitments)
     if hiding is None:
         hiding = [(int.from_bytes(os.urandom(48), "big") % cv.r, int.from_bytes(os.urandom(48), "big") % cv.r) for _ in range(nbc)]
 
     def commit_hint(col):
-        # gnark's bsb22 hint: kzg.Commit(column, Lagrange SRS) on the GPU, then hash_to_field (host)
         pt = C.create_string_buffer(2 * cv.fp_bytes)
         check(lib.apk_msm_g1(pk.ctx, 1, cv.fr_vector(col), len(col), pt))
         out = C.create_string_buffer(32)
@@ -179,6 +178,16 @@ def Prove(ccs: frontend.ConstraintSystem, pk: ProvingKey, witness: frontend.Witn
 
     pi2_cols: List[List[int]] = []
     solution = frontend.solve(ccs, witness, commit_hint if nbc else None, hiding, pi2_cols)
+    return solution, pi2_cols
+
+
+def Prove(ccs: frontend.ConstraintSystem, pk: ProvingKey, witness: frontend.Witness,
+          blinding: Optional[Sequence[int]] = None, hiding=None) -> Proof:
+    """plonk.Prove(ccs, pk, witness) (/root/reference/algoplonk.go:89).  `blinding` = the 9 scalars gnark draws
+    from crypto/rand; drawn from os.urandom when omitted."""
+    cv = pk.curve
+    nbc = len(ccs.commitments)
+    solution, pi2_cols = solve_with_commitments(ccs, pk, witness, hiding)
     L, R, O = frontend.wire_columns(ccs, solution)
     if blinding is None:
         blinding = [int.from_bytes(os.urandom(48), "big") % cv.r for _ in range(_lib.NB_BLINDING)]

@@ -25,12 +25,13 @@ from ._lib import lib, check
 
 
 class Name(IntEnum):
-    """setup.Name (setup/setup.go:23-36)."""
-    TestOnlyBN254 = 0
-    TestOnlyBLS12381 = 1
-    PerpetualPowersOfTauBN254 = 2
-    EthereumKzgCeremonyBLS12381 = 3
-    DuskBLS12381 = 4
+    """setup.Name (setup/setup.go:23-36): the numeric values are the reference's iota order, so an integer id carried
+    over from the Go side names the same setup (0 is the trusted PPoT ceremony, never a TestOnly setup)."""
+    PerpetualPowersOfTauBN254 = 0
+    EthereumKzgCeremonyBLS12381 = 1
+    DuskBLS12381 = 2
+    TestOnlyBN254 = 3
+    TestOnlyBLS12381 = 4
 
 
 @dataclass(frozen=True)
@@ -42,11 +43,11 @@ class Setup:
 
 
 _setups: Dict[Name, Setup] = {
-    Name.TestOnlyBN254: Setup(ecc.BN254, False, "", 1 << 24),
-    Name.TestOnlyBLS12381: Setup(ecc.BLS12_381, False, "", 1 << 24),
     Name.PerpetualPowersOfTauBN254: Setup(ecc.BN254, True, "PerpetualPowersOfTauBN254", 1 << 17),
     Name.EthereumKzgCeremonyBLS12381: Setup(ecc.BLS12_381, True, "EethereumKzgCeremonyBLS12_381", 1 << 14),
     Name.DuskBLS12381: Setup(ecc.BLS12_381, True, "DuskBLS12_381", 1 << 20),
+    Name.TestOnlyBN254: Setup(ecc.BN254, False, "test_only", 1 << 24),
+    Name.TestOnlyBLS12381: Setup(ecc.BLS12_381, False, "test_only", 1 << 24),
 }
 
 

@@ -6,13 +6,25 @@ workload : configs[1] = BN254 random circuit, 2^17 constraints, synthetic SRS (s
            not in the mount - SURVEY.md §0.7), 1 MI355X per rank
 step     : one batch of `--inflight` independent proofs of that circuit, proved concurrently on the context's
            slots (one host thread + one HIP stream per proof)
-N > 1    : one process per GPU, every rank proves its own independent proofs (no data-path collective:
-           "replicas only" for proofs) -> weak scaling; the only torch.distributed traffic is the
-           timing barrier / MAX reduction the contract asks for.
 
-Extra objects on the JSON line (prompt ④): `roofline` for the dominant kernel (msm_accumulate_kernel, HIP events on
-the stream it runs on, algorithmic bytes = 96 B per (scalar, point) pair) and `cpu_baseline` (the C oracle timed on
-this box's host cores on the same workload).
+Launch contract:
+  * `python bench.py --gpus N ...` with no WORLD_SIZE in the environment and N > 1 re-executes ITSELF as
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+    (one rank per GPU over RCCL) and relays rank 0's JSON line;
+  * launched by that command (or by the driver's own torchrun) it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
+    environment; `--gpus` must then equal WORLD_SIZE.
+Modes:
+  prove (default)  : every rank proves its own independent proofs - "replicas only", no data-path collective, weak scaling
+                     (BASELINE configs[1], and configs[4] with --curve bls12_381 --log-n 21 --bsb22 1);
+  msm-sharded      : configs[3] - ONE 2^log_n MSM split by index range over the ranks, one all-gather of a 64/96-byte point
+                     per rank + local point additions; strong scaling;
+  launcher-selftest: NOT a measurement - the launcher, rendezvous, barrier / MAX reduction and JSON plumbing with a no-op
+                     step on gloo (CPU tier test of this file).
+
+Extra objects on the JSON line (prompt ④): `roofline` for the dominant kernel (msm_accumulate_kernel, HIP events on the
+stream it runs on, algorithmic bytes = 96 B per (scalar, point) pair on BN254; `traffic` = HBM bytes per launch from
+rocprofv3 PMC passes run by this script) and `cpu_baseline` (the C oracle timed on this box's host cores on the same
+workload, plus the result of probing for a Go toolchain that could run the real gnark prover: bench/gnark_cpu).
 """
 from __future__ import annotations
 
@@ -20,78 +32,304 @@ import argparse
 import ctypes as C
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
 import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# one hardware queue per in-flight proof stream (the ROCm default of 4 serialises 16 streams onto 4 queues:
-# 172 -> 205 proofs/s measured with 16; 24 queues / 24 proofs in flight is the plateau); set before HIP initialises
+# one hardware queue per in-flight proof stream (libapk sets the same default when it is loaded; set here too because torch
+# may initialise HIP first: the ROCm default of 4 serialises 16 streams onto 4 queues, 172 -> 205 proofs/s measured with 16)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def main() -> None:
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log-n", type=int, default=17)
     ap.add_argument("--curve", default="bn254", choices=["bn254", "bls12_381"])
+    ap.add_argument("--bsb22", type=int, default=0, help="BSB22 commitments in the circuit (configs[4]: 1)")
     ap.add_argument("--inflight", type=int, default=32,
                     help="independent proofs per step = concurrent apk_prove callers (the context runs 16 at a time, the rest wait for a slot)")
     ap.add_argument("--msm-window", type=int, default=0)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="prove", choices=["prove", "msm-sharded"],
-                    help="prove (default, BASELINE configs[1]) | msm-sharded (configs[3]: ONE MSM split by index range over the ranks)")
-    args = ap.parse_args()
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes behind roofline.traffic")
+    ap.add_argument("--mode", default="prove", choices=["prove", "msm-sharded", "launcher-selftest"])
+    return ap.parse_args(argv)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
 
-    import torch  # device plumbing + torch.distributed only
-    import torch.distributed as dist
+# ---------------------------------------------------------------------------------------------------- launcher
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from algoplonk_amd import _lib, ecc, frontend, plonk, setup, workloads
+def launch_command(argv, gpus: int, port: int):
+    """The command line the contract prescribes for N > 1 (one rank per GPU on ONE node)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.join(ROOT, "bench.py")] + list(argv)
+
+
+def maybe_self_launch(args, argv) -> bool:
+    """`--gpus N` outside torchrun: re-execute under torch.distributed.run.  Returns True when this process was the launcher."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return False
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+    cmd = launch_command(argv, args.gpus, free_port())
+    r = subprocess.run(cmd, env=env)
+    if r.returncode != 0:
+        raise SystemExit("bench.py launcher: %s exited with %d" % (" ".join(cmd[:8]), r.returncode))
+    return True
+
+
+class Ranks:
+    """RANK / LOCAL_RANK / WORLD_SIZE + the barrier / MAX-over-ranks timing of the contract."""
+
+    def __init__(self, args, backend: str):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.backend = backend
+        if self.world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world))
+        self.cuda = backend == "nccl"
+        if self.cuda:
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py needs an MI355X: no HIP device visible (the HIP path has no CPU fallback)")
+            torch.cuda.set_device(self.local_rank)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.cuda:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group("gloo")
+
+    def fence(self):
+        if self.world > 1:
+            self.dist.barrier()
+        if self.cuda:
+            self.torch.cuda.synchronize()
+
+    def timed(self, step, steps: int, warmup: int) -> float:
+        """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize; MAX over ranks."""
+        for _ in range(warmup):
+            step()
+        self.fence()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.fence()
+        elapsed = time.perf_counter() - t1
+        if self.world > 1:
+            t = self.torch.tensor([elapsed], dtype=self.torch.float64, device="cuda" if self.cuda else "cpu")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------- probes
+def go_probe() -> dict:
+    """is there a Go toolchain (and a module cache with gnark) that could run bench/gnark_cpu - the REAL
+    reference CPU prover?  Recorded in cpu_baseline; when it succeeds the gnark number replaces the port's."""
+    go = shutil.which("go")
+    if not go:
+        return {"go": None, "gnark_cpu": "not run: no Go toolchain on this box (go: command not found)"}
+    try:
+        ver = subprocess.run([go, "version"], capture_output=True, text=True, timeout=20).stdout.strip()
+    except Exception as e:
+        return {"go": "error: %s" % e, "gnark_cpu": "not run"}
+    return {"go": ver, "gnark_cpu": "untried"}
+
+
+def gnark_cpu_baseline(probe: dict, curve: str, log_n: int, budget_s: float):
+    """build and run bench/gnark_cpu (gnark v0.15.0 plonk.Prove on the same circuit shape).  Needs the Go
+    modules in the module cache (no network here); any failure is reported, never fatal."""
+    if not probe.get("go") or probe["gnark_cpu"] != "untried":
+        return None
+    src = os.path.join(ROOT, "bench", "gnark_cpu")
+    env = dict(os.environ, GOFLAGS="-mod=mod", GOPROXY="off")
+    try:
+        b = subprocess.run(["go", "build", "-o", os.path.join(ROOT, "oracle", "_ref", "gnark_cpu"), "."], cwd=src, env=env,
+                           capture_output=True, text=True, timeout=300)
+        if b.returncode != 0:
+            probe["gnark_cpu"] = "go build failed: %s" % (b.stderr.strip().splitlines() or ["?"])[-1][:200]
+            return None
+        r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "gnark_cpu"), "-curve", curve, "-log-n", str(log_n), "-seconds", str(budget_s)],
+                           capture_output=True, text=True, timeout=budget_s * 4 + 600)
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        probe["gnark_cpu"] = "ran"
+        return {"value": line["proofs_per_sec"], "unit": "proofs/sec", "cores": line["cores"], "kind": "reference",
+                "sample": "%d gnark v0.15.0 plonk.Prove runs of a 2^%d %s circuit in %.1f s (bench/gnark_cpu)" % (line["proofs"], log_n, curve, line["seconds"])}
+    except Exception as e:
+        probe["gnark_cpu"] = "failed: %s" % str(e)[:200]
+        return None
+
+
+def pmc_traffic(curve: str, log_n: int, window: int, timeout_s: float = 420.0):
+    """HBM bytes per (scalar, point) pair of msm_accumulate_kernel, measured NOW on this box: two separate rocprofv3 --pmc
+    passes (FETCH_SIZE, WRITE_SIZE - one counter per pass and no trace domains, as MI355X_MICROARCH.md's HBM section
+    prescribes) over tools/prof_msm.py (4 single MSMs + the 8 trace commitments of Setup).  gfx950 correction from the same
+    guide: FETCH_SIZE counts 64-byte units reported in KB at half weight -> doubled; WRITE_SIZE as is.  None when rocprofv3 is
+    missing or a pass fails."""
+    if not shutil.which("rocprofv3"):
+        return None
+    import sqlite3
+    import tempfile
+    out = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    if window:
+        env["APK_MSM_WINDOW"] = str(window)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="apk_pmc_", dir="/tmp")
+        try:
+            subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable,
+                            os.path.join(ROOT, "tools", "prof_msm.py"), str(log_n), "4", "0", curve], cwd="/tmp", env=env, capture_output=True,
+                           timeout=timeout_s, check=True)
+            dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("_results.db")]
+            db = sqlite3.connect(dbs[0])
+            tot, launches = 0.0, set()
+            for name, did, cname, val in db.execute("select kernel_name, dispatch_id, counter_name, value from counters_collection"):
+                if "msm_accumulate_kernel" in name and cname == counter:
+                    tot += val
+                    launches.add(did)
+            out[counter] = (tot, len(launches))
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    n_msm = 12                                     # prof_msm.py: 4 single MSMs + 8 VK commitments (two batches of 4)
+    pairs = n_msm * (1 << log_n)
+    fetch_kb, nl = out["FETCH_SIZE"]
+    write_kb, _ = out["WRITE_SIZE"]
+    bytes_total = 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0
+    return {"hbm_bytes_per_pair": bytes_total / pairs, "launches": nl, "fetch_kb": fetch_kb, "write_kb": write_kb}
+
+
+# ---------------------------------------------------------------------------------------------------- modes
+def main(argv=None) -> None:
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if maybe_self_launch(args, argv):
+        return
+    if args.mode == "launcher-selftest":
+        return launcher_selftest(args)
+    rk = Ranks(args, "nccl")
+    from algoplonk_amd import ecc
+    cv = ecc.BN254 if args.curve == "bn254" else ecc.BLS12_381
+    if args.mode == "msm-sharded":
+        return bench_sharded_msm(args, cv, rk)
+    return bench_prove(args, cv, rk)
+
+
+def launcher_selftest(args) -> None:
+    rk = Ranks(args, "gloo")
+    state = {"n": 0}
+
+    def step():
+        state["n"] += 1
+
+    elapsed = rk.timed(step, args.steps, args.warmup)
+    assert state["n"] == args.steps + args.warmup
+    if rk.rank == 0:
+        print(json.dumps({"metric": "launcher-selftest", "value": 0.0, "unit": "none", "n_gpus": rk.world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 6), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none: no-op step, NOT a measurement",
+                          "config": {"workload": "launcher self-test", "backend": rk.backend, "world_size": rk.world}}), flush=True)
+    rk.close()
+
+
+def window_bits(args) -> int:
+    return args.msm_window or (16 if args.log_n >= 21 else min(15, max(8, args.log_n - 2)))
+
+
+def roofline_from_stats(args, cv, st, pmc):
+    pair_bytes = 32 + 2 * cv.fp_bytes  # SURVEY.md §8d: 96 B/pair BN254, 128 B/pair BLS12-381
+    acc_avg_ms = st.msm_accumulate_ms / max(st.msm_accumulate_launches, 1)
+    pairs_per_launch = st.msm_pairs / max(st.msm_accumulate_launches, 1)
+    achieved = pairs_per_launch * pair_bytes / (acc_avg_ms * 1e-3) / 1e9 if acc_avg_ms > 0 else 0.0
+    roofline = {
+        # the contract's HBM yardstick (algorithmic bytes / time / 8 TB/s) - but the kernel's real ceiling is integer-VALU
+        # issue (DESIGN.md section 5), reported beside it as `valu`
+        "bound": "valu", "kernel": "msm_accumulate_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+        "traffic": int(pmc["hbm_bytes_per_pair"] * pairs_per_launch) if pmc else None,
+        "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py invocation (%d launches), %.0f B per pair"
+                           % (pmc["launches"], pmc["hbm_bytes_per_pair"])) if pmc else None,
+        "avg_launch_ms": round(acc_avg_ms, 4), "pairs_per_launch": round(pairs_per_launch, 1),
+        "algorithmic_bytes_per_pair": pair_bytes,
+    }
+    if acc_avg_ms > 0:
+        c = window_bits(args)
+        windows = (cv.r.bit_length() + 1 + c - 1) // c
+        adds_per_s = pairs_per_launch * windows / (acc_avg_ms * 1e-3)
+        roofline["valu"] = {"bucket_additions_per_s": round(adds_per_s / 1e9, 3), "unit": "G additions/s", "windows": windows}
+        if pmc:
+            roofline["hbm_traffic_frac"] = round(pmc["hbm_bytes_per_pair"] * pairs_per_launch / (acc_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    return roofline
+
+
+def bench_prove(args, cv, rk) -> None:
+    from algoplonk_amd import _lib, frontend, plonk, setup, workloads
     from algoplonk_amd._lib import lib, check
 
-    cv = ecc.BN254 if args.curve == "bn254" else ecc.BLS12_381
-    seed = 0xA190 if cv is ecc.BN254 else 0xA191
-    if args.mode == "msm-sharded":
-        return bench_sharded_msm(args, cv, rank, local_rank, world, torch, dist)
+    seed = {("bn254", 0): 0xA190, ("bls12_381", 0): 0xA191}.get((args.curve, args.bsb22), 0xA193)
     t0 = time.time()
-    wl = workloads.random_circuit(cv, args.log_n, seed)
-    n = wl.ccs.domain_size()
-    srs = setup.unsafe_srs(cv, n, wl.tau, device=local_rank)
-    pk, vk = plonk.Setup(wl.ccs, srs, device=local_rank, msm_window=args.msm_window, slots=args.inflight)
-    L, R, O = frontend.wire_columns(wl.ccs, wl.solution)
-    host = [cv.fr_vector(v) for v in (L, R, O)]
-    dptr = []
-    for b in host:
+    pi2_host = None
+    if args.bsb22:
+        ccs, witness, blinding, tau = workloads.random_circuit_bsb22(cv, args.log_n, seed, nb_commitments=args.bsb22)
+        name = "%s random circuit, 2^%d constraints, %d BSB22 commitment(s)" % (cv.name, args.log_n, args.bsb22)
+    else:
+        wl = workloads.random_circuit(cv, args.log_n, seed)
+        ccs, witness, blinding, tau, name = wl.ccs, wl.witness, wl.blinding, wl.tau, wl.name
+    n = ccs.domain_size()
+    srs = setup.unsafe_srs(cv, n, tau, device=rk.local_rank, lagrange=bool(args.bsb22))
+    pk, vk = plonk.Setup(ccs, srs, device=rk.local_rank, msm_window=args.msm_window, slots=args.inflight)
+    if args.bsb22:
+        solution, pi2_host = plonk.solve_with_commitments(ccs, pk, witness, hiding=[(0xA193 + k, 0x3910A + k) for k in range(args.bsb22)])
+    else:
+        solution = wl.solution
+    L, R, O = frontend.wire_columns(ccs, solution)
+
+    def resident(vec):
+        b = cv.fr_vector(vec)
         p = C.c_void_p()
         check(lib.apk_device_alloc(pk.ctx, len(b), C.byref(p)))
         check(lib.apk_device_upload(pk.ctx, p, b, len(b)))
-        dptr.append(p)
-    pub = cv.fr_vector(wl.witness.public)
-    bl = cv.fr_vector(wl.blinding)
+        return p
+
+    dptr = [resident(v) for v in (L, R, O)]
+    d_pi2 = None
+    if pi2_host:
+        ptrs = [resident(col) for col in pi2_host]
+        d_pi2 = (C.c_void_p * len(ptrs))(*ptrs)
+    pub = cv.fr_vector(witness.public)
+    bl = cv.fr_vector(blinding)
     setup_s = time.time() - t0
 
     proofs = [_lib.Proof() for _ in range(args.inflight)]
     errors = []
 
     def one(i):
-        rc = lib.apk_prove_device(pk.ctx, dptr[0], dptr[1], dptr[2], pub, bl, None, C.byref(proofs[i]))
+        rc = lib.apk_prove_device(pk.ctx, dptr[0], dptr[1], dptr[2], pub, bl, d_pi2, C.byref(proofs[i]))
         if rc != 0:
             errors.append((rc, lib.apk_last_error()))
 
@@ -105,27 +343,10 @@ def main() -> None:
         for t in ts:
             t.join()
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t1
+    elapsed = rk.timed(step, args.steps, args.warmup)
     if errors:
         raise SystemExit("apk_prove failed: %r" % (errors[0],))
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    total_proofs = args.steps * args.inflight * world
+    total_proofs = args.steps * args.inflight * rk.world
     value = total_proofs / elapsed
 
     # ---- single-proof latency + live HIP-event timing of the dominant kernel (own pass, after the timed region)
@@ -138,72 +359,51 @@ def main() -> None:
     lat_ms = (time.perf_counter() - lat0) / nlat * 1e3
     st = pk.stats(reset=True)
     pk.enable_stats(False)
-    pair_bytes = 32 + 2 * cv.fp_bytes  # 96 B/pair BN254, 128 B/pair BLS12-381
-    acc_avg_ms = st.msm_accumulate_ms / max(st.msm_accumulate_launches, 1)
-    pairs_per_launch = st.msm_pairs / max(st.msm_accumulate_launches, 1)
-    achieved = pairs_per_launch * pair_bytes / (acc_avg_ms * 1e-3) / 1e9 if acc_avg_ms > 0 else 0.0
-    # HBM bytes per launch from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
-    # corrected as MI355X_MICROARCH.md prescribes; profiles/r01_pmc_msm_accumulate.json): bytes per pair x pairs
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_msm_accumulate.json")))
-        if cv is ecc.BN254 and args.log_n == 17:
-            traffic = int(pmc["hbm_bytes_per_pair"] * pairs_per_launch)
-    except Exception:
-        traffic = None
-    roofline = {
-        "bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-        "avg_launch_ms": round(acc_avg_ms, 4), "pairs_per_launch": round(pairs_per_launch, 1),
-        "algorithmic_bytes_per_pair": pair_bytes,
-    }
-    # The HBM fraction above is what the contract asks for; the kernel's real ceiling is VALU issue.
-    # BN254 only: 2335 VALU instructions (1467 v_mad_u64_u32) per mixed addition in the build's assembly = 9.6 k issue cycles
-    # per wave at the measured per-instruction costs -> SIMDs * clock / 9.6 k * 64 lanes additions/s if no SIMD ever stalled.
-    if cv is ecc.BN254 and acc_avg_ms > 0:
-        c = args.msm_window or (16 if args.log_n >= 21 else min(15, max(8, args.log_n - 2)))
-        windows = (254 + 1 + c - 1) // c
-        adds_per_s = pairs_per_launch * windows / (acc_avg_ms * 1e-3)
-        issue_bound = 1024 * 2.4e9 / 9600.0 * 64
-        roofline["valu"] = {"mixed_additions_per_s": round(adds_per_s / 1e9, 3), "issue_bound": round(issue_bound / 1e9, 3),
-                            "unit": "G additions/s", "frac": round(adds_per_s / issue_bound, 4)}
 
     # ---- MSM-only throughput (second half of BASELINE.json's metric): one 2^log_n MSM, scalars resident in HBM
     out_pt = C.create_string_buffer(2 * cv.fp_bytes)
     for _ in range(3):
         check(lib.apk_msm_g1_device(pk.ctx, 0, dptr[0], n, out_pt))
-    torch.cuda.synchronize()
+    rk.torch.cuda.synchronize()
     reps = 20
     m0 = time.perf_counter()
     for _ in range(reps):
         check(lib.apk_msm_g1_device(pk.ctx, 0, dptr[0], n, out_pt))
-    torch.cuda.synchronize()
+    rk.torch.cuda.synchronize()
     msm_s = (time.perf_counter() - m0) / reps
     msm_mscalar = n / msm_s / 1e6
 
+    pmc = None
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        try:
-            from bench_cpu import cpu_baseline_prove
-            cpu_baseline = cpu_baseline_prove(wl, srs, args.cpu_baseline_seconds)
-        except Exception as e:  # the baseline is reported, never required for the GPU number
-            cpu_baseline = {"value": None, "unit": "proofs/sec", "cores": 0, "kind": "port", "sample": "unavailable: %s" % e}
+    if rk.rank == 0 and rk.world == 1:
+        if not args.no_pmc and not args.bsb22:
+            pmc = pmc_traffic(args.curve, args.log_n, args.msm_window)
+        if not args.no_cpu_baseline and not args.bsb22:
+            probe = go_probe()
+            cpu_baseline = gnark_cpu_baseline(probe, args.curve, args.log_n, args.cpu_baseline_seconds)
+            if cpu_baseline is None:
+                try:
+                    from bench_cpu import cpu_baseline_prove
+                    cpu_baseline = cpu_baseline_prove(wl, srs, args.cpu_baseline_seconds)
+                except Exception as e:  # the baseline is reported, never required for the GPU number
+                    cpu_baseline = {"value": None, "unit": "proofs/sec", "cores": 0, "kind": "port", "sample": "unavailable: %s" % e}
+            cpu_baseline["go_probe"] = probe
+    roofline = roofline_from_stats(args, cv, st, pmc)
 
-    gpu_proof_sha = None
-    if rank == 0:
+    if rk.rank == 0:
         import hashlib
         from algoplonk_amd import MarshalProof
         gpu_proof_sha = hashlib.sha256(MarshalProof(plonk.Proof(cv, proofs[0]))).hexdigest()[:16]
         if cpu_baseline and cpu_baseline.get("proof_sha256_prefix"):
             cpu_baseline["matches_gpu_proof"] = cpu_baseline["proof_sha256_prefix"] == gpu_proof_sha
-    if rank == 0:
         line = {
-            "metric": "proofs/sec", "value": round(value, 4), "unit": "proofs/sec", "n_gpus": world, "steps": args.steps,
+            "metric": "proofs/sec", "value": round(value, 4), "unit": "proofs/sec", "n_gpus": rk.world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (Montgomery Fr/Fp)" if cv is ecc.BN254 else "u32x8 Fr / u32x12 Fp (Montgomery)",
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (Montgomery Fr/Fp)" if cv.name == "bn254" else "u32x8 Fr / u32x12 Fp (Montgomery)",
             "data": "synthetic",
-            "config": {"workload": wl.name, "log_n": args.log_n, "curve": cv.name, "proofs_per_step": args.inflight,
-                       "srs": "synthetic tau=SHA256(seed)", "parallelism": "replicas x%d" % world},
+            "config": {"workload": name, "log_n": args.log_n, "curve": cv.name, "proofs_per_step": args.inflight,
+                       "srs": "synthetic tau=SHA256(seed)", "parallelism": "replicas x%d" % rk.world, "world_size": rk.world,
+                       "backend": "nccl (RCCL)" if rk.world > 1 else "single process"},
             "proof_latency_ms": round(lat_ms, 3), "msm_mscalar_per_s": round(msm_mscalar, 3),
             "msm_ms": round(msm_s * 1e3, 4), "setup_s": round(setup_s, 2),
             "msm_batch_avg_ms": round(st.msm_total_ms / max(st.msm_batches, 1), 4),
@@ -211,60 +411,66 @@ def main() -> None:
             "proof_sha256_prefix": gpu_proof_sha, "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    rk.close()
 
 
-def bench_sharded_msm(args, cv, rank, local_rank, world, torch, dist):
+def bench_sharded_msm(args, cv, rk) -> None:
     """BASELINE.json configs[3]: one 2^log_n MSM (seed 0xA192, uniform scalars, SRS-shaped points) sharded by index range:
     every rank keeps the windowed tables of its slice resident, computes a full partial sum, then ONE all-gather of a
     64/96-byte point per rank + world-1 host point additions (algoplonk_amd/parallel.py).  Strong scaling."""
-    from algoplonk_amd import parallel, setup, workloads
+    from algoplonk_amd import parallel, plonk, setup, workloads
+    from algoplonk_amd import _lib
     from algoplonk_amd._lib import lib, check
 
     n = 1 << args.log_n
     g = workloads.SplitMix64(0xA192)
     tau = workloads.tau_from_seed(0xA192, cv.r)
-    srs = setup.unsafe_srs(cv, n, tau, device=local_rank)
+    srs = setup.unsafe_srs(cv, n, tau, device=rk.local_rank)
     scalars = cv.fr_vector([g.fr(cv.r) for _ in range(n)])
-    sm = parallel.ShardedMsm(cv, srs.g1[: n * 2 * cv.fp_bytes], device=local_rank, rank=rank, world=world, msm_window=args.msm_window)
+    bases = srs.g1[: n * 2 * cv.fp_bytes]
+    sm = parallel.ShardedMsm(cv, bases, device=rk.local_rank, rank=rk.rank, world=rk.world, msm_window=args.msm_window)
     mine = scalars[sm.lo * 32: sm.hi * 32]
     d = C.c_void_p()
     check(lib.apk_device_alloc(sm._ctx, len(mine), C.byref(d)))
     check(lib.apk_device_upload(sm._ctx, d, mine, len(mine)))
     out = C.create_string_buffer(2 * cv.fp_bytes)
+    res = [b""]
 
     def step():
         check(lib.apk_msm_g1_device(sm._ctx, 0, d, sm.hi - sm.lo, out))
-        return parallel.gather_and_add(cv, out.raw) if world > 1 else out.raw
+        res[0] = parallel.gather_and_add(cv, out.raw) if rk.world > 1 else out.raw
 
-    for _ in range(args.warmup):
-        res = step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t1
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if rank == 0:
+    elapsed = rk.timed(step, args.steps, args.warmup)
+    # dominant kernel of this rank's share, HIP events on its stream
+    check(lib.apk_stats_enable(sm._ctx, 1))
+    st = _lib.Stats()
+    check(lib.apk_stats_read(sm._ctx, C.byref(st), 1))
+    for _ in range(5):
+        check(lib.apk_msm_g1_device(sm._ctx, 0, d, sm.hi - sm.lo, out))
+    check(lib.apk_stats_read(sm._ctx, C.byref(st), 1))
+    check(lib.apk_stats_enable(sm._ctx, 0))
+    pmc = None
+    cpu_baseline = None
+    if rk.rank == 0 and rk.world == 1:
+        if not args.no_pmc:
+            pmc = pmc_traffic(args.curve, args.log_n, args.msm_window)
+        if not args.no_cpu_baseline:
+            from bench_cpu import cpu_baseline_msm
+            cpu_baseline = cpu_baseline_msm(cv, bases, scalars, n, args.cpu_baseline_seconds)
+            cpu_baseline["go_probe"] = go_probe()
+            cpu_baseline["matches_gpu_result"] = cpu_baseline.pop("result") == res[0]
+    if rk.rank == 0:
         import hashlib
         print(json.dumps({
-            "metric": "MSM Mscalar/s", "value": round(n * args.steps / elapsed / 1e6, 3), "unit": "Mscalar/s", "n_gpus": world,
+            "metric": "MSM Mscalar/s", "value": round(n * args.steps / elapsed / 1e6, 3), "unit": "Mscalar/s", "n_gpus": rk.world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u29x9 Fp (BN254) / u28x14 Fp (BLS12-381) unsaturated Montgomery",
             "data": "synthetic", "config": {"workload": "%s single MSM 2^%d sharded by index range" % (cv.name, args.log_n),
-                                            "parallelism": "index-range x%d + all-gather of %d-byte points" % (world, 2 * cv.fp_bytes)},
-            "result_sha256_prefix": hashlib.sha256(res).hexdigest()[:16]}), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+                                            "parallelism": "index-range x%d + all-gather of %d-byte points" % (rk.world, 2 * cv.fp_bytes),
+                                            "world_size": rk.world, "backend": "nccl (RCCL)" if rk.world > 1 else "single process"},
+            "result_sha256_prefix": hashlib.sha256(res[0]).hexdigest()[:16],
+            "roofline": roofline_from_stats(args, cv, st, pmc), "cpu_baseline": cpu_baseline}), flush=True)
+    rk.close()
 
 
 if __name__ == "__main__":

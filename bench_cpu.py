@@ -32,3 +32,26 @@ def cpu_baseline_prove(wl, srs, budget_s: float = 20.0, threads: int = 0):
     return {"value": round(done / el, 5), "unit": "proofs/sec", "cores": cores, "kind": "port",
             "sample": "%d proof(s) of the same %s in %.1f s, oracle/apk_oracle.c with %d pthreads" % (done, wl.name, el, cores),
             "proof_sha256_prefix": __import__("hashlib").sha256(blob).hexdigest()[:16]}
+
+
+def cpu_baseline_msm(cv, bases: bytes, scalars: bytes, n: int, budget_s: float = 20.0, threads: int = 0):
+    """MSM-only baseline for bench.py --mode msm-sharded: the C oracle's Pippenger (orc_msm) over the same
+    points and scalars on this box's host cores."""
+    import ctypes as C
+    from oracle import c_oracle
+
+    lib = c_oracle.load()
+    cores = threads or (os.cpu_count() or 1)
+    out = C.create_string_buffer(2 * cv.fp_bytes)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        rc = lib.orc_msm(cv.abi, bases, scalars, n, cores, out)
+        if rc != 0:
+            raise RuntimeError("C oracle MSM returned %d" % rc)
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or el + el / done > 1.5 * budget_s:
+            break
+    return {"value": round(done * n / el / 1e6, 4), "unit": "Mscalar/s", "cores": cores, "kind": "port",
+            "sample": "%d MSM(s) of 2^%d pairs in %.1f s, oracle/apk_oracle.c Pippenger with %d pthreads" % (done, n.bit_length() - 1, el, cores),
+            "result": out.raw}

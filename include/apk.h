@@ -170,6 +170,9 @@ int apk_hash_fr(int curve, const void* g1_affine, void* out_fr);
  * mixed addition / the plain one; 14 = lazy full additions and doublings ending at 4p+6q. */
 int apk_host_fe_op(int curve, int field, int op, const void* a, const void* b, void* out);
 int apk_host_g1_op(int curve, int op, const void* p, const void* q, void* out);
+/* out = sum of `count` G1 affine points (host; 0 points give infinity): the local half of a sharded MSM's one exchange
+ * step - the all-gathered per-rank partial sums are added with this call (algoplonk_amd/parallel.py). */
+int apk_g1_sum(int curve, const void* points, uint64_t count, void* out);
 
 /* ---- device memory helpers for callers that keep inputs resident (bench, batched proofs) ------------------ */
 int apk_device_alloc(apk_ctx* ctx, size_t bytes, void** d_ptr);

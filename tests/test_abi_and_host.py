@@ -179,6 +179,19 @@ def test_compile_rejects_what_the_reference_rejects():
     assert ap_setup.TestOnlySetup(ecc.BN254) == ap_setup.Name.TestOnlyBN254
 
 
+def test_setup_name_values_are_the_reference_iota_order():
+    """setup/setup.go:30-36: an integer setup id carried over from the Go side must name the same setup."""
+    N = ap_setup.Name
+    assert [int(N.PerpetualPowersOfTauBN254), int(N.EthereumKzgCeremonyBLS12381), int(N.DuskBLS12381), int(N.TestOnlyBN254),
+            int(N.TestOnlyBLS12381)] == [0, 1, 2, 3, 4]
+    for i, (curve, trusted, path) in enumerate([(ecc.BN254, True, "PerpetualPowersOfTauBN254"),
+                                                 (ecc.BLS12_381, True, "EethereumKzgCeremonyBLS12_381"),
+                                                 (ecc.BLS12_381, True, "DuskBLS12_381"), (ecc.BN254, False, "test_only"),
+                                                 (ecc.BLS12_381, False, "test_only")]):
+        s, ok = ap_setup.Get(i)                       # setup/setup.go:49-75
+        assert ok and s.Curve is curve and s.Trusted is trusted and s.NamePath == path
+
+
 def test_frontend_trace_matches_oracle_trace():
     from oracle import circuits as ocircuits
 

@@ -36,16 +36,20 @@ def _worker(rank, world, port, q):
             pts = [ov.mul(ov.g1, pow(tau, i, cv.r)) for i in range(n)]
             scalars = [g.fr(cv.r) for _ in range(n)]
 
-            def local(mine: bytes, lo: int, cv=cv, ov=ov, pts=pts):
-                sc = cv.fr_vector_decode(mine)
-                return cv.g1_to_bytes(ov.msm_naive(pts[lo: lo + len(sc)], sc))
+            class OracleShard(parallel.ShardedMsm):
+                """The product class with its per-rank GPU MSM swapped for the oracle's (no GPU in this tier)."""
+                def _open(self, my_bases, device, msm_window):
+                    self._pts = cv.g1_vector_decode(my_bases)
 
-            sm = parallel.ShardedMsm(cv, cv.g1_vector(pts), device=0, rank=rank, world=world, local_msm=local)
+                def local_partial(self, mine, cv=cv, ov=ov):
+                    return cv.g1_to_bytes(ov.msm_naive(self._pts, cv.fr_vector_decode(mine)))
+
+            sm = OracleShard(cv, cv.g1_vector(pts), device=0, rank=rank, world=world)
             assert (sm.lo, sm.hi) == parallel.my_share(n, rank, world)
             got = cv.g1_from_bytes(sm.run(cv.fr_vector(scalars)))
             assert got == ov.mul(ov.g1, oplonk.poly_eval(scalars, tau, cv.r)), "sharded MSM != full MSM"
             # degenerate: a rank with an empty share contributes the point at infinity
-            sm2 = parallel.ShardedMsm(cv, cv.g1_vector(pts[:1]), device=0, rank=rank, world=world, local_msm=local)
+            sm2 = OracleShard(cv, cv.g1_vector(pts[:1]), device=0, rank=rank, world=world)
             assert cv.g1_from_bytes(sm2.run(cv.fr_vector(scalars[:1]))) == ov.mul(pts[0], scalars[0])
         # proof sharding: shares tile [0, total) without gaps
         lo, hi = parallel.my_share(11, rank, world)

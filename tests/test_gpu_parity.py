@@ -218,6 +218,17 @@ def test_full_size_proof_is_accepted_by_the_transcribed_verifier(gpu, cname, log
     ovk_pairing = dataclasses.replace(ovk, tau=None, g2=(pr.G2_GEN, pr.g2_mul(pr.G2_GEN, wl.tau)))
     assert oplonk.verify(ovk_pairing, blob, pib)
     assert not oplonk.verify(ovk_pairing, bytes(bad), pib)
+    # byte for byte against the oracle's plain-C prover on the same inputs (BN254 2^17 = the headline config)
+    from oracle import c_oracle
+    tr = frontend.build_trace(wl.ccs)
+    L, R, O = frontend.wire_columns(wl.ccs, wl.solution)
+    rc, cblob, cch = c_oracle.prove(c_oracle.load(), cv.abi, n, wl.ccs.GetNbPublicVariables(), srs.g1,
+                                    [cv.fr_vector(x) for x in (tr.ql, tr.qr, tr.qm, tr.qo, tr.qk)], tr.perm, cv.fr_vector(L),
+                                    cv.fr_vector(R), cv.fr_vector(O), cv.fr_vector(wl.witness.public), cv.fr_vector(wl.blinding),
+                                    threads=os.cpu_count() or 1)
+    assert rc == 0 and blob == cblob
+    ch = proof.challenges
+    assert [ch[k] for k in ("gamma", "beta", "alpha", "zeta", "gamma_kzg")] == cch
     # MSM linearity at full size: msm(a) + msm(b) == msm(a + b)
     a = wl.solution[: n]; b = wl.solution[1: n + 1]
     assert ov.add(pk.msm(a), pk.msm(b)) == pk.msm([(x + y) % cv.r for x, y in zip(a, b)])
@@ -437,19 +448,80 @@ def test_bsb22_at_scale_is_accepted_by_the_transcribed_verifier(gpu, cname, log_
     pk.close()
 
 
-def test_largest_size_bls12_381_2p21_proof_verifies(gpu):
-    """BASELINE.json configs[4] size on one GPU (BLS12-381, n = 2^21, 64 MiB per polynomial, 3.2 GB of windowed tables):
-    the proof is checked by the transcribed verifier, whose cost does not depend on n."""
+def test_largest_size_bls12_381_2p21_with_bsb22_proof_verifies(gpu):
+    """BASELINE.json configs[4] AS STATED, on one GPU: BLS12-381, n = 2^21 (64 MiB per polynomial, 2 x 3.2 GB of windowed
+    tables: canonical + Lagrange SRS) WITH one BSB22 commitment (committed column: 16 wires + 2 hiding entries out of 2^21).
+    The proof is checked by the transcribed verifier, whose cost does not depend on n, including the hash_fr /
+    L_{nbPublic+cci}(zeta) public-input term (templateLogicSigBLS12_381.go twin of templateLogicSigBN254.go:187-193)."""
     from algoplonk_amd import workloads
     cv, ov = CURVES["bls12-381"]
-    wl = workloads.random_circuit(cv, 21, 0xA193)
-    n = wl.ccs.domain_size()
-    srs = ap_setup.unsafe_srs(cv, n, wl.tau, device=gpu)
-    pk, vk = ap_plonk.Setup(wl.ccs, srs, device=gpu)
-    proof = ap_plonk.Prove(wl.ccs, pk, wl.witness, wl.blinding)
-    blob, pib = MarshalProof(proof), MarshalPublicInputs(wl.witness)
+    ccs, w, bl, tau = workloads.random_circuit_bsb22(cv, 21, 0xA193)
+    n = ccs.domain_size()
+    assert n == 1 << 21 and len(ccs.commitments) == 1
+    srs = ap_setup.unsafe_srs(cv, n, tau, device=gpu, lagrange=True)
+    pk, vk = ap_plonk.Setup(ccs, srs, device=gpu)
+    proof = ap_plonk.Prove(ccs, pk, w, bl, hiding=[(0xA193, 0x3910A)])
+    blob, pib = MarshalProof(proof), MarshalPublicInputs(w)
     ovk = oracle_vk_from_product(ov, vk)
-    assert len(blob) == 1056 and oplonk.verify(ovk, blob, pib)
+    assert len(blob) == 1056 + 32 + 96 and oplonk.verify(ovk, blob, pib)     # bsb22_test.go:97-101
+    assert proof.Bsb22Commitments[0] is not None
     bad = bytearray(blob); bad[900] ^= 1
     assert not oplonk.verify(ovk, bytes(bad), pib)
+    bad = bytearray(blob); bad[-1] ^= 1            # the BSB22 commitment point
+    assert not oplonk.verify(ovk, bytes(bad), pib)
+    bad = bytearray(pib); bad[-1] ^= 1             # testutils/verifier_integration_test.go:188-228: flipped public input
+    assert not oplonk.verify(ovk, blob, bytes(bad))
     pk.close()
+
+
+def test_public_api_pythagorean_compile_verify_export(gpu, tmp_path):
+    """BASELINE.json configs[0] through the HIP path and the PUBLIC API: the reference's examples/basic workload
+    (/root/reference/examples/basic/logicsigVerifier/main.go:30-52: a^2 + b^2 == c^2, assignment 3, 4, 5) run as
+    Compile (algoplonk.go:37-59) -> CompiledCircuit.Verify (algoplonk.go:79-98: prove + verify) ->
+    ExportProofAndPublicInputs (algoplonk.go:103-132), on BN254 with the TestOnly setup.  The
+    exported 768-byte blob must equal the oracle prover's for the same tau / blinding, and the 64-byte public-input file
+    the oracle's marshalling."""
+    from algoplonk_amd import Compile
+
+    class Pyth(frontend.Circuit):
+        A = frontend.Public(); B = frontend.Public(); C = frontend.Secret()
+
+        def define(self, api):
+            api.AssertIsEqual(api.Add(api.Mul(self.A, self.A), api.Mul(self.B, self.B)), api.Mul(self.C, self.C))
+
+    for cname, name in (("bn254", ap_setup.Name.TestOnlyBN254), ("bls12-381", ap_setup.Name.TestOnlyBLS12381)):
+        cv, ov = CURVES[cname]
+        seed = 0x5EED0000 + int(name)
+        cc = Compile(Pyth(), cv, name, device=gpu, seed=seed)
+        assert cc.Vk.Size == 8 and cc.Vk.NbPublicVariables == 2
+        a = Pyth(); a.A, a.B, a.C = 3, 4, 5
+        bl = blinding(cv, 0xB1)
+        seen = []
+
+        def transcribed(vk, blob, pib):
+            seen.append((blob, pib))
+            return oplonk.verify(oracle_vk_from_product(ov, vk), blob, pib)
+
+        vp = cc.Verify(a, blinding=bl, verifier=transcribed)
+        assert len(seen) == 1
+        pf, pif = str(tmp_path / ("proof_%s.bin" % cname)), str(tmp_path / ("pi_%s.bin" % cname))
+        vp.ExportProofAndPublicInputs(pf, pif)
+        blob, pib = open(pf, "rb").read(), open(pif, "rb").read()
+        assert (blob, pib) == seen[0]
+        assert len(blob) == (768 if cv is ecc.BN254 else 1056) and len(pib) == 64
+        assert pib == (3).to_bytes(32, "big") + (4).to_bytes(32, "big")
+        # the oracle prover on the same circuit / SRS / witness / blinding
+        tau = int.from_bytes(seed.to_bytes(48, "big"), "big") % cv.r
+        oc = oracle_circuit_from_ccs(ov, cc.Ccs)
+        opk = oplonk.setup(oc, oplonk.synthetic_srs(ov, 8, tau, materialize=False))
+        sol = frontend.solve(cc.Ccs, frontend.NewWitness(a, cv.r))
+        L, R, O = oplonk.solve_lro(oc, sol)
+        want = oplonk.marshal_proof(ov, oplonk.prove(opk, L, R, O, [3, 4], bl))
+        assert blob == want
+        # the built-in verifier (algoplonk.go:93 runs plonk.Verify unconditionally) accepts it too, and a wrong assignment
+        # never yields a VerifiedProof (algoplonk.go:90-92)
+        cc.Verify(a, blinding=bl)
+        wrong = Pyth(); wrong.A, wrong.B, wrong.C = 3, 4, 6
+        with pytest.raises(RuntimeError, match="error creating Plonk proof"):
+            cc.Verify(wrong, blinding=bl)
+        cc.Pk.close()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Small driver for profiler runs: one context at BN254 2^log_n, then a few single MSMs and proofs.
-usage: python tools/prof_msm.py [log_n] [msms] [proofs]"""
+usage: python tools/prof_msm.py [log_n] [msms] [proofs] [bn254|bls12_381]"""
 import ctypes as C
 import os
 import sys
@@ -12,8 +12,8 @@ from algoplonk_amd._lib import lib, check
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 17
 n_msm = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 n_proofs = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-cv = ecc.BN254
-wl = workloads.random_circuit(cv, log_n, 0xA190)
+cv = ecc.BLS12_381 if len(sys.argv) > 4 and sys.argv[4] == "bls12_381" else ecc.BN254
+wl = workloads.random_circuit(cv, log_n, 0xA190 if cv is ecc.BN254 else 0xA191)
 n = wl.ccs.domain_size()
 srs = setup.unsafe_srs(cv, n, wl.tau)
 pk, vk = plonk.Setup(wl.ccs, srs)
@@ -25,7 +25,7 @@ for v in (L, R, O):
     check(lib.apk_device_alloc(pk.ctx, len(b), C.byref(p)))
     check(lib.apk_device_upload(pk.ctx, p, b, len(b)))
     d.append(p)
-out = C.create_string_buffer(64)
+out = C.create_string_buffer(2 * cv.fp_bytes)
 for _ in range(n_msm):
     check(lib.apk_msm_g1_device(pk.ctx, 0, d[0], n, out))
 pr = _lib.Proof()
