@@ -14,8 +14,10 @@ LIB_PATH = os.path.join(_HERE, "libapk.so")
 APK_BN254 = 0
 APK_BLS12_381 = 1
 APK_OK = 0
-APK_ERR_ARG, APK_ERR_HIP, APK_ERR_STATE, APK_ERR_WITNESS = 1, 2, 3, 4
+APK_ERR_ARG, APK_ERR_HIP, APK_ERR_STATE, APK_ERR_WITNESS, APK_ERR_VERIFY = 1, 2, 3, 4, 5
+ABI_VERSION = 2
 G1_MAX = 96
+G2_MAX = 192
 MAX_COMMITMENTS = 2
 NB_BLINDING = 9
 
@@ -23,7 +25,7 @@ NB_BLINDING = 9
 SYMBOLS = [
     "apk_last_error", "apk_abi_version", "apk_device_count", "apk_g1_bytes", "apk_fp_bytes",
     "apk_ctx_create", "apk_ctx_destroy", "apk_msm_ctx_create", "apk_ctx_get_vk", "apk_msm_g1", "apk_msm_g1_device", "apk_ntt",
-    "apk_prove", "apk_prove_device", "apk_g1_mul_batch", "apk_g1_decompress", "apk_g1_to_lagrange", "apk_marshal_proof", "apk_marshal_public_inputs",
+    "apk_prove", "apk_prove_device", "apk_verify", "apk_g2_decompress", "apk_g2_mul_generator", "apk_g1_mul_batch", "apk_g1_decompress", "apk_g1_to_lagrange", "apk_marshal_proof", "apk_marshal_public_inputs",
     "apk_fe_from_be", "apk_fe_to_be", "apk_hash_fr", "apk_host_fe_op", "apk_host_g1_op", "apk_g1_sum",
     "apk_device_alloc", "apk_device_free", "apk_device_upload", "apk_device_download",
     "apk_stats_enable", "apk_stats_read",
@@ -66,6 +68,16 @@ class Proof(C.Structure):
     ]
 
 
+class VerifyingKey(C.Structure):
+    _fields_ = [
+        ("curve", C.c_int), ("n", C.c_uint64), ("nb_public", C.c_uint32), ("nb_commitments", C.c_uint32),
+        ("ql", C.c_uint8 * G1_MAX), ("qr", C.c_uint8 * G1_MAX), ("qm", C.c_uint8 * G1_MAX), ("qo", C.c_uint8 * G1_MAX),
+        ("qk", C.c_uint8 * G1_MAX), ("s", (C.c_uint8 * G1_MAX) * 3), ("qcp", (C.c_uint8 * G1_MAX) * MAX_COMMITMENTS),
+        ("commitment_constraint_index", C.c_uint32 * MAX_COMMITMENTS), ("g1", C.c_uint8 * G1_MAX),
+        ("g2", (C.c_uint8 * G2_MAX) * 2),
+    ]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("msm_accumulate_ms", C.c_double), ("msm_accumulate_launches", C.c_uint64), ("msm_pairs", C.c_uint64),
@@ -95,6 +107,9 @@ def _load() -> C.CDLL:
     lib.apk_ntt.argtypes = [vp, i32, i32, i32, vp]
     lib.apk_prove.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(Proof)]
     lib.apk_prove_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(Proof)]
+    lib.apk_verify.argtypes = [C.POINTER(VerifyingKey), C.POINTER(Proof), vp]
+    lib.apk_g2_decompress.argtypes = [i32, vp, vp]
+    lib.apk_g2_mul_generator.argtypes = [i32, vp, vp]
     lib.apk_g1_mul_batch.argtypes = [i32, i32, vp, vp, u64, vp]
     lib.apk_g1_decompress.argtypes = [i32, i32, vp, u64, vp]
     lib.apk_g1_to_lagrange.argtypes = [i32, i32, vp, u64, vp]

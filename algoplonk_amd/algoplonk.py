@@ -6,8 +6,9 @@
     MarshalProof / MarshalPublicInputs                                helper.go:13-24, 91-110
 
 Out of scope here: WritePuyaPyVerifier and the AVM tooling.  `plonk.Verify` (algoplonk.go:93) is
-gnark's pairing verifier on the Go side; the Python mirror takes an optional `verifier` callable instead so the
-test-suite can plug in the verifier it transcribed from the reference's templates.
+gnark's pairing verifier on the Go side; here it is `algoplonk_amd.plonk.Verify` -> libapk's host-side apk_verify, and
+it ALWAYS runs: a `VerifiedProof` is never handed out unverified.  The optional `verifier` callable runs in addition
+(the test-suite plugs in the verifier it transcribed from the reference's templates).
 """
 from __future__ import annotations
 
@@ -38,10 +39,13 @@ class CompiledCircuit:
             proof = plonk.Prove(self.Ccs, self.Pk, witness, blinding)
         except Exception as e:
             raise RuntimeError("error creating Plonk proof: %s" % e)
-        vp = VerifiedProof(proof, witness)
+        try:
+            plonk.Verify(proof, self.Vk, witness.Public())                     # algoplonk.go:93
+        except Exception as e:
+            raise RuntimeError("error verifying Plonk proof: %s" % e)
         if verifier is not None and not verifier(self.Vk, MarshalProof(proof), MarshalPublicInputs(witness)):
-            raise RuntimeError("error verifying Plonk proof")
-        return vp
+            raise RuntimeError("error verifying Plonk proof: rejected by the caller's verifier")
+        return VerifiedProof(proof, witness)
 
 
 @dataclass

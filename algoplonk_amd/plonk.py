@@ -33,7 +33,32 @@ class VerifyingKey:
     Qcp: List[ecc.Point]
     CommitmentConstraintIndexes: List[int]
     KzgG1: ecc.Point
-    tau: Optional[int] = None   # TestOnly setups: stands in for Kzg.G2 = ([1]G2, [tau]G2)
+    tau: Optional[int] = None   # TestOnly setups only: the toxic value (lets tests use the known-tau shortcut)
+    KzgG2: Optional[bytes] = None   # Kzg.G2 = ([1]G2, [tau]G2), gnark in-memory G2Affine bytes
+
+    def raw(self) -> "_lib.VerifyingKey":
+        """The C-ABI form apk_verify takes (include/apk.h apk_verifying_key)."""
+        cv = self.curve
+        if not self.KzgG2:
+            raise ValueError("verifying key carries no G2 points")
+        v = _lib.VerifyingKey()
+        v.curve, v.n, v.nb_public, v.nb_commitments = cv.abi, self.Size, self.NbPublicVariables, len(self.Qcp)
+
+        def put(slot, P):
+            b = cv.g1_to_bytes(P)
+            C.memmove(slot, b, len(b))
+
+        for name, P in (("ql", self.Ql), ("qr", self.Qr), ("qm", self.Qm), ("qo", self.Qo), ("qk", self.Qk), ("g1", self.KzgG1)):
+            put(getattr(v, name), P)
+        for j in range(3):
+            put(v.s[j], self.S[j])
+        for k, P in enumerate(self.Qcp):
+            put(v.qcp[k], P)
+            v.commitment_constraint_index[k] = self.CommitmentConstraintIndexes[k]
+        w = 4 * cv.fp_bytes
+        for j in range(2):
+            C.memmove(v.g2[j], self.KzgG2[j * w: (j + 1) * w], w)
+        return v
 
 
 class ProvingKey:
@@ -156,8 +181,24 @@ def Setup(ccs: frontend.ConstraintSystem, srs: SRS, device: int = 0, msm_window:
         NbPublicVariables=ccs.GetNbPublicVariables(), Ql=P(raw.ql), Qr=P(raw.qr), Qm=P(raw.qm), Qo=P(raw.qo), Qk=P(raw.qk),
         S=[P(raw.s[i]) for i in range(3)], Qcp=[P(raw.qcp[k]) for k in range(nbc)],
         CommitmentConstraintIndexes=[ccs.commitments[k][1] for k in range(nbc)],
-        KzgG1=cv.g1_from_bytes(srs.g1[: 2 * cv.fp_bytes]), tau=srs.tau)
+        KzgG1=cv.g1_from_bytes(srs.g1[: 2 * cv.fp_bytes]), tau=srs.tau, KzgG2=srs.g2)
     return pk, vk
+
+
+class VerificationError(RuntimeError):
+    pass
+
+
+def Verify(proof: "Proof", vk: VerifyingKey, public_witness: frontend.Witness) -> None:
+    """plonk.Verify(proof, vk, publicWitness) (/root/reference/algoplonk.go:93): raises VerificationError when the proof is
+    rejected.  Host-side (apk_verify: transcript, linearised commitment, one two-pair pairing check) - no GPU work."""
+    cv = vk.curve
+    pub = cv.fr_vector(public_witness.Public().public)
+    raw_vk = vk.raw()
+    rc = lib.apk_verify(C.byref(raw_vk), C.byref(proof.raw), pub)
+    if rc == _lib.APK_ERR_VERIFY:
+        raise VerificationError((lib.apk_last_error() or b"").decode())
+    check(rc)
 
 
 def solve_with_commitments(ccs: frontend.ConstraintSystem, pk: ProvingKey, witness: frontend.Witness, hiding=None):

@@ -78,7 +78,8 @@ class SRS:
     n: int
     g1: bytes
     g1_lagrange: Optional[bytes]
-    tau: Optional[int] = None   # TestOnly setups only (stands in for the G2 side of the verifying key)
+    tau: Optional[int] = None   # TestOnly setups only: the toxic value (never known for a trusted setup)
+    g2: Optional[bytes] = None  # kzg.VerifyingKey.G2 = ([1]G2, [tau]G2), gnark in-memory G2Affine (X.A0 || X.A1 || Y.A0 || Y.A1 each)
 
 
 def _mul_base_batch(curve: ecc.ID, scalars: List[int], device: int) -> bytes:
@@ -115,7 +116,31 @@ def unsafe_srs(curve: ecc.ID, n: int, tau: int, device: int = 0, lagrange: bool 
             sc[i] = ws[i] * zn % r * (inv * pref[i] % r) % r
             inv = inv * den[i] % r
         lag = _mul_base_batch(curve, sc, device)
-    return SRS(curve, n, g1, lag, tau)
+    return SRS(curve, n, g1, lag, tau, g2_from_tau(curve, tau))
+
+
+def g2_from_tau(curve: ecc.ID, tau: int) -> bytes:
+    """([1]G2, [tau]G2) for a TestOnly SRS (host: apk_g2_mul_generator)."""
+    out = b""
+    for k in (1, tau):
+        buf = C.create_string_buffer(4 * curve.fp_bytes)
+        check(lib.apk_g2_mul_generator(curve.abi, curve.fr_vector([k]), buf))
+        out += buf.raw
+    return out
+
+
+def g2_from_vk_bin(curve: ecc.ID, vk: bytes) -> bytes:
+    """The two G2 points of a trusted setup's vk.bin = G2[0] || G2[1] || G1[0], all compressed (writer
+    order setup/DuskBLS12_381/audit.go:155-179), decompressed on the host (apk_g2_decompress)."""
+    w = 2 * curve.fp_bytes
+    if len(vk) != 2 * w + curve.fp_bytes:
+        raise ValueError("vk.bin: expected %d bytes, found %d" % (2 * w + curve.fp_bytes, len(vk)))
+    out = b""
+    for j in range(2):
+        buf = C.create_string_buffer(4 * curve.fp_bytes)
+        check(lib.apk_g2_decompress(curve.abi, vk[j * w: (j + 1) * w], buf))
+        out += buf.raw
+    return out
 
 
 def _sqrt_fp(a: int, p: int) -> Optional[int]:
@@ -189,7 +214,10 @@ def trusted_srs(setup: Setup, n: int, device: int = 0, lagrange: bool = False, r
     if not root:
         raise FileNotFoundError("trusted setup files are not bundled: set APK_TRUSTED_SETUP_DIR")
     cv = setup.Curve
-    g1b, _vk = load_trusted_setup_bytes(os.path.join(root, setup.NamePath), n + 3, cv.fp_bytes)
+    g1b, vk = load_trusted_setup_bytes(os.path.join(root, setup.NamePath), n + 3, cv.fp_bytes)
     g1 = decompress_g1_batch(cv, g1b[4:], device)
     lag = to_lagrange_g1(cv, g1[: n * 2 * cv.fp_bytes], device) if lagrange else None   # G1[:len-3] (setup.go:124,138)
-    return SRS(cv, n, g1, lag, None)
+    g2 = g2_from_vk_bin(cv, vk)                                                          # srs.Vk.ReadFrom (setup.go:174,190)
+    if decompress_g1_batch(cv, vk[-cv.fp_bytes:], device) != g1[: 2 * cv.fp_bytes]:
+        raise ValueError("vk.bin: Vk.G1 differs from pk.bin's first point")               # setup/trusted_setup_test.go:127-129
+    return SRS(cv, n, g1, lag, None, g2)

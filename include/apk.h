@@ -15,6 +15,13 @@
  *
  * There is NO CPU fallback: every compute entry point fails with APK_ERR_HIP when no gfx950 device is
  * usable.  The oracle under oracle/ is test infrastructure and is never linked into this library.
+ *
+ * Runtime environment: a context runs up to 16 proofs concurrently, one HIP stream each.  ROCm maps streams onto
+ * GPU_MAX_HW_QUEUES hardware queues (default 4), read ONCE when the HIP runtime initialises; with 4 the streams serialise
+ * (-20 % proofs/s measured).  The library therefore sets GPU_MAX_HW_QUEUES=24 when it is loaded, unless the variable is
+ * already set.  A host process that initialises HIP BEFORE loading libapk (another GPU library, torch ...) must export
+ * GPU_MAX_HW_QUEUES=24 itself before its first HIP call - the cgo shim of INTEGRATION.md loads libapk at program start, so
+ * a plain AlgoPlonk process needs nothing.
  */
 #ifndef APK_H
 #define APK_H
@@ -26,7 +33,7 @@
 extern "C" {
 #endif
 
-#define APK_ABI_VERSION 1
+#define APK_ABI_VERSION 2
 
 /* curve ids: the two curves the AVM supports (algoplonk.go:39-41) */
 #define APK_BN254 0
@@ -37,9 +44,11 @@ extern "C" {
 #define APK_ERR_HIP 2      /* HIP runtime failure, including "no device" */
 #define APK_ERR_STATE 3    /* call not valid for this context (e.g. Lagrange MSM without a Lagrange SRS) */
 #define APK_ERR_WITNESS 4  /* the witness does not satisfy the circuit (quotient not a polynomial) */
+#define APK_ERR_VERIFY 5   /* apk_verify: the proof does not verify against the key and public inputs */
 
 #define APK_FR_BYTES 32
 #define APK_G1_MAX_BYTES 96       /* BLS12-381 affine; BN254 uses the first 64 bytes of a slot */
+#define APK_G2_MAX_BYTES 192      /* G2 affine, gnark in-memory: X.A0 || X.A1 || Y.A0 || Y.A1; BN254 uses the first 128 bytes */
 #define APK_MAX_COMMITMENTS 2     /* BSB22 commitments per circuit (reference documents 0/1/2: README.md:27-30) */
 #define APK_NB_BLINDING 9         /* bl0,bl1, br0,br1, bo0,bo1, bz0,bz1,bz2 */
 
@@ -135,6 +144,32 @@ int apk_prove(apk_ctx* ctx, const void* L, const void* R, const void* O, const v
 /* Variant with L,R,O already resident in device memory (n Fr each). */
 int apk_prove_device(apk_ctx* ctx, const void* d_L, const void* d_R, const void* d_O, const void* public_inputs,
                      const void* blinding, const void* const* d_pi2, apk_proof* out);
+
+/* ---- the verifier: the host-side mirror of plonk.Verify(proof, vk, publicWitness) (algoplonk.go:93) --------------------
+ * (*CompiledCircuit).Verify runs the prover AND gnark's verifier before it hands out a VerifiedProof (algoplonk.go:79-98).
+ * A Go integration keeps calling gnark's plonk.Verify on the returned *Proof; hosts without gnark (algoplonk_amd's Python
+ * mirror of the API) call apk_verify.  Host only, no GPU: transcript, ~25 G1 scalar multiplications, one two-pair pairing
+ * check.  The statement checked is the one the reference's generated AVM verifiers check
+ * (verifier/templateLogicSigBN254.go:110-356).  Returns APK_OK, APK_ERR_VERIFY (proof rejected) or APK_ERR_ARG (bad key). */
+typedef struct {
+    int curve;
+    uint64_t n;                /* VK Size */
+    uint32_t nb_public;        /* VK NbPublicVariables */
+    uint32_t nb_commitments;
+    uint8_t ql[APK_G1_MAX_BYTES], qr[APK_G1_MAX_BYTES], qm[APK_G1_MAX_BYTES], qo[APK_G1_MAX_BYTES], qk[APK_G1_MAX_BYTES];
+    uint8_t s[3][APK_G1_MAX_BYTES];
+    uint8_t qcp[APK_MAX_COMMITMENTS][APK_G1_MAX_BYTES];
+    uint32_t commitment_constraint_index[APK_MAX_COMMITMENTS];
+    uint8_t g1[APK_G1_MAX_BYTES];        /* VK Kzg.G1 = SRS G1[0] */
+    uint8_t g2[2][APK_G2_MAX_BYTES];     /* VK Kzg.G2 = ([1]G2, [tau]G2), gnark in-memory G2Affine */
+} apk_verifying_key;
+int apk_verify(const apk_verifying_key* vk, const apk_proof* proof, const void* public_inputs);
+/* G2 points for apk_verifying_key.g2 (host only).  apk_g2_decompress: one compressed G2 exactly as it sits in the
+ * reference's vk.bin files (64 | 96 bytes, X.A1 || X.A0 big-endian with gnark's flag bits) -> in-memory form.
+ * apk_g2_mul_generator: [scalar]G2 - the G2 side of a TestOnly SRS whose tau is known (unsafekzg, setup/setup.go:102-108);
+ * scalar = one Fr in Montgomery form. */
+int apk_g2_decompress(int curve, const uint8_t* compressed, void* out);
+int apk_g2_mul_generator(int curve, const void* scalar_fr, void* out);
 
 /* ---- test-only SRS generation: the device half of gnark's test/unsafekzg.NewSRS (setup/setup.go:102-108) ---
  * out[i] = scalars[i] * base.  Host buffers; scalars Fr Montgomery; base/out G1 affine.  The caller supplies
