@@ -22,6 +22,7 @@
 #include "kernels_ntt.h"
 #include "kernels_poly.h"
 #include "kernels_setup.h"
+#include "host_msm.h"
 #include "sha256.h"
 
 namespace apk {
@@ -1121,6 +1122,8 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         const int iz = ea.count;
         ea.f[iz] = ptr<Fr>(s.cz); ea.len[iz] = n + 3; ea.pw[iz] = ptr<Fr>(s.pw_zw); ea.count++;
         CHK(eval_many(s, ea, ptr<Fr>(s.pw_z), hfr));
+        // the opening quotient of Z at omega*zeta does not wait for anything the host derives from the evaluations
+        CHK(kzg_quotient(s, ptr<Fr>(s.cz), n + 3, ptr<Fr>(s.pw_zw), ptr<Fr>(s.pw_zwi), z0, ptr<Fr>(s.q2)));
         CHK(sync_results(s));
         for (int i = 0; i < ea.count; i++) ev[i] = hfr[i];
     }
@@ -1128,39 +1131,60 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     const Fr zshift = ev[5 + nb_commit_];
     // coefficients of the linearised polynomial (templateLogicSigBN254.go:195-201,231-254)
     const Fr zn_m1 = Fr::pow_u64(zeta, n) - Fr::one();
-    const Fr lag0 = zn_m1 * n_inv_ * Fr::inv(zeta - Fr::one());
     const Fr alpha2 = alpha * alpha;
+    // L_i(zeta) = omega^i (zeta^n - 1) / (n (zeta - omega^i)) for the rows the prover wrote into Qk (public inputs, commitment
+    // hashes) and for row 0: one shared inversion
+    std::vector<Fr> lag_w, lag_den;
+    {
+        std::vector<uint32_t> rows = {0};
+        for (uint32_t i = 1; i < nb_public_; i++) rows.push_back(i);
+        for (uint32_t k = 0; k < nb_commit_; k++) rows.push_back(nb_public_ + cci_[k]);
+        Fr wi = Fr::one();
+        uint32_t at = 0;
+        for (uint32_t row : rows) {
+            if (row == at + 1) wi = wi * omega_; else if (row != at) wi = Fr::pow_u64(omega_, row);
+            at = row;
+            lag_w.push_back(wi);
+            lag_den.push_back(zeta - wi);
+        }
+        std::vector<Fr> pref(lag_den.size() + 1, Fr::one());
+        for (size_t i = 0; i < lag_den.size(); i++) pref[i + 1] = pref[i] * lag_den[i];
+        Fr inv = Fr::inv(pref.back());
+        const Fr scale = zn_m1 * n_inv_;
+        for (size_t i = lag_den.size(); i-- > 0;) {
+            const Fr di = inv * pref[i];
+            inv = inv * lag_den[i];
+            lag_w[i] = lag_w[i] * scale * di;        // = L_row(zeta)
+        }
+    }
+    const Fr lag0 = lag_w[0];
+    // lin(zeta) as the verifier derives it from the quotient identity (templateLogicSigBN254.go:203-218) - the
+    // identity holds exactly (the tail check above), so this IS the evaluation of the linearised polynomial
+    Fr pi_z = Fr::zero();   // lag_w = [L_0, L_1 .. L_{nbPublic-1}, L_{nbPublic+cci_0} ..](zeta)
+    for (uint32_t i = 0; i < nb_public_; i++) pi_z = pi_z + pubv[i] * lag_w[i];
+    for (uint32_t k = 0; k < nb_commit_; k++) pi_z = pi_z + cval[k] * lag_w[(nb_public_ ? nb_public_ : 1) + k];
+    const Fr lin_z = Fr::neg(pi_z + alpha * zshift * (lz + beta * s1z + gamma) * (rz + beta * s2z + gamma) * (oz + gamma) - alpha2 * lag0);
     const Fr c_s3 = alpha * beta * zshift * (lz + beta * s1z + gamma) * (rz + beta * s2z + gamma);
     const Fr c_z = alpha2 * lag0 - alpha * (lz + beta * zeta + gamma) * (rz + beta_u * zeta + gamma) * (oz + beta_u2 * zeta + gamma);
     const Fr zn2 = Fr::pow_u64(zeta, n + 2);
+    const Fr mz = Fr::neg(zn_m1);
+    // terms of the linearised polynomial: the polynomial (device), its commitment (host), its coefficient
+    struct LinTerm { const Fr* poly; uint32_t len; Aff com; Fr coef; };
+    std::vector<LinTerm> lin_terms = {
+        {ptr<Fr>(ql_c_), n, vk_pts_[0], lz}, {ptr<Fr>(qr_c_), n, vk_pts_[1], rz}, {ptr<Fr>(qm_c_), n, vk_pts_[2], lz * rz},
+        {ptr<Fr>(qo_c_), n, vk_pts_[3], oz}, {ptr<Fr>(qk_c_), n, vk_pts_[4], Fr::one()}, {ptr<Fr>(s_c_[2]), n, vk_pts_[7], c_s3},
+        {ptr<Fr>(s.cz), n + 3, zcom, c_z}, {ptr<Fr>(s.hcan), n + 2, hcom[0], mz},
+        {ptr<Fr>(s.hcan) + (n + 2), n + 2, hcom[1], mz * zn2}, {ptr<Fr>(s.hcan) + 2 * (size_t)(n + 2), n + 2, hcom[2], mz * zn2 * zn2}};
+    for (uint32_t k = 0; k < nb_commit_; k++) lin_terms.push_back({ptr<Fr>(s.pi2_can[k]), n, bsb[k], ev[5 + k]});
+    // [lin] = sum coef_i * [poly_i]: the group element kzg.Commit(lin) would give, taken from commitments already in hand
+    // (host_msm.h) instead of a tenth size-n MSM
+    Aff lin_com;
     {
-        LinCombArgs<FRP> lc{};
-        int c = 0;
-        auto push = [&](const Fr* f, uint32_t len, const Fr& coef) { lc.f[c] = f; lc.len[c] = len; lc.coef[c] = coef; c++; };
-        push(ptr<Fr>(ql_c_), n, lz); push(ptr<Fr>(qr_c_), n, rz); push(ptr<Fr>(qm_c_), n, lz * rz); push(ptr<Fr>(qo_c_), n, oz);
-        push(ptr<Fr>(qk_c_), n, Fr::one()); push(ptr<Fr>(s_c_[2]), n, c_s3); push(ptr<Fr>(s.cz), n + 3, c_z);
-        const Fr mz = Fr::neg(zn_m1);
-        push(ptr<Fr>(s.hcan), n + 2, mz); push(ptr<Fr>(s.hcan) + (n + 2), n + 2, mz * zn2); push(ptr<Fr>(s.hcan) + 2 * (size_t)(n + 2), n + 2, mz * zn2 * zn2);
-        for (uint32_t k = 0; k < nb_commit_; k++) push(ptr<Fr>(s.pi2_can[k]), n, ev[5 + k]);
-        lc.count = c; lc.out_len = n + 3;
-        lincomb_kernel<FRP><<<cdiv(n + 3, POLY_THREADS), POLY_THREADS, 0, st>>>(lc, ptr<Fr>(s.lin)); KCHK();
+        Aff lp[HOST_MSM_MAX];
+        Fr lk[HOST_MSM_MAX];
+        for (size_t i = 0; i < lin_terms.size(); i++) { lp[i] = lin_terms[i].com; lk[i] = lin_terms[i].coef; }
+        lin_com = host_lincomb<FRP, FPP>(lp, lk, (int)lin_terms.size());
     }
-    // opening of Z at omega*zeta (kzg.Open [UPSTREAM]) and the commitment + value of lin
-    CHK(kzg_quotient(s, ptr<Fr>(s.cz), n + 3, ptr<Fr>(s.pw_zw), ptr<Fr>(s.pw_zwi), z0, ptr<Fr>(s.q2)));
-    {
-        MsmBatchArgs a{};
-        a.batch = 2;
-        a.scalars[0] = s.lin.p; a.len[0] = n + 3; a.offset[0] = 0;
-        a.scalars[1] = s.q2.p; a.len[1] = n + 2; a.offset[1] = 0;
-        CHK(run_msm(s, tab_can_, a, hp));
-        EvalArgs<FRP> ea{};
-        ea.f[0] = ptr<Fr>(s.lin); ea.len[0] = n + 3; ea.count = 1;
-        CHK(eval_many(s, ea, ptr<Fr>(s.pw_z), hfr));
-    }
-    CHK(sync_results(s));
-    const Aff lin_com = hp[0], zshift_h = hp[1];
-    const Fr lin_z = hfr[0];
-    store_pt(out->zshift_h, zshift_h);
     memcpy(out->zshift_value, &zshift, sizeof(Fr));
     Fr claimed[6 + APK_MAX_COMMITMENTS] = {lin_z, lz, rz, oz, s1z, s2z};
     for (uint32_t k = 0; k < nb_commit_; k++) claimed[6 + k] = ev[5 + k];
@@ -1182,21 +1206,28 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     }
     const Fr gk = fr_from_be(gk_raw);
     {
+        // folded = lin + gk l + gk^2 r + gk^3 o + gk^4 S1 + gk^5 S2 + gk^(6+k) Qcp_k, one fused linear combination over the
+        // constituents of lin (the linearised polynomial itself is never materialised)
         LinCombArgs<FRP> lc{};
         int c = 0;
-        Fr acc = Fr::one();
+        for (const LinTerm& t : lin_terms) { lc.f[c] = t.poly; lc.len[c] = t.len; lc.coef[c] = t.coef; c++; }
+        Fr acc = gk;
         auto push = [&](const Fr* f, uint32_t len) { lc.f[c] = f; lc.len[c] = len; lc.coef[c] = acc; c++; acc = acc * gk; };
-        push(ptr<Fr>(s.lin), n + 3); push(ptr<Fr>(s.cl), n + 2); push(ptr<Fr>(s.cr), n + 2); push(ptr<Fr>(s.co), n + 2);
+        push(ptr<Fr>(s.cl), n + 2); push(ptr<Fr>(s.cr), n + 2); push(ptr<Fr>(s.co), n + 2);
         push(ptr<Fr>(s_c_[0]), n); push(ptr<Fr>(s_c_[1]), n);
         for (uint32_t k = 0; k < nb_commit_; k++) push(ptr<Fr>(qcp_c_[k]), n);
         lc.count = c; lc.out_len = n + 3;
         lincomb_kernel<FRP><<<cdiv(n + 3, POLY_THREADS), POLY_THREADS, 0, st>>>(lc, ptr<Fr>(s.folded)); KCHK();
         CHK(kzg_quotient(s, ptr<Fr>(s.folded), n + 3, ptr<Fr>(s.pw_z), ptr<Fr>(s.pw_zi), z0, ptr<Fr>(s.q1)));
+        // both opening proofs in one batch: W_zeta (batched opening) and W_omega*zeta (kzg.Open of Z [UPSTREAM])
         MsmBatchArgs a{};
-        a.batch = 1; a.scalars[0] = s.q1.p; a.len[0] = n + 2; a.offset[0] = 0;
+        a.batch = 2;
+        a.scalars[0] = s.q1.p; a.len[0] = n + 2; a.offset[0] = 0;
+        a.scalars[1] = s.q2.p; a.len[1] = n + 2; a.offset[1] = 0;
         CHK(run_msm(s, tab_can_, a, hp));
     }
     CHK(sync_results(s));
+    store_pt(out->zshift_h, hp[1]);
     store_pt(out->batched_h, hp[0]);
     memcpy(out->gamma, &gamma, sizeof(Fr)); memcpy(out->beta, &beta, sizeof(Fr)); memcpy(out->alpha, &alpha, sizeof(Fr));
     memcpy(out->zeta, &zeta, sizeof(Fr)); memcpy(out->gamma_kzg, &gk, sizeof(Fr));

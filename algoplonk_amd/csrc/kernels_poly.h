@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(POLY_THREADS) eval_final_kernel(const Fe<FR>* 
 }
 
 // ---- out[i] = sum_k coef[k] * f_k[i]  (linearised polynomial, folded opening polynomial) -------------------
-constexpr int LC_MAX = 14;
+constexpr int LC_MAX = 20;   // folded opening polynomial: 11 + k terms of the linearised polynomial, 5 + k folded ones (k <= 2)
 template <class FR>
 struct LinCombArgs {
     const Fe<FR>* f[LC_MAX];
@@ -371,7 +371,6 @@ __global__ void __launch_bounds__(POLY_THREADS) div_finish_kernel(const Fe<FR>* 
     q[j] = suffix[j + 1] * zinv_pw[j + 1];
 }
 
-// z == 0 fallback: q[j] = f[j+1]
 // The quotient is a polynomial of degree < 3(n+2) iff the witness satisfies the circuit: OR-reduce ALL the words of the
 // coefficients above it (h[3(n+2) .. 4n)).  A non-zero word stamps the proof's epoch into *flag (atomicMax: no zeroing between
 // proofs, nothing is written in the normal case); the host compares the flag with the epoch after the stream sync.
@@ -385,6 +384,7 @@ __global__ void __launch_bounds__(256) tail_nonzero_kernel(const uint4* __restri
     if (__ballot(acc != 0) != 0 && (threadIdx.x & 63) == 0) atomicMax(flag, epoch);
 }
 
+// z == 0 fallback: q[j] = f[j+1]
 template <class FR>
 __global__ void shift_down_kernel(const Fe<FR>* __restrict__ f, uint32_t len, Fe<FR>* __restrict__ q) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
