@@ -18,6 +18,7 @@
 package main
 
 import (
+	"bytes"
 	"crypto/rand"
 	"crypto/sha256"
 	"encoding/binary"
@@ -183,6 +184,13 @@ func main() {
 	domain.FFT(evals, fft.DIF)
 	fft.BitReverse(evals) // == vec
 
+	// gnark's own serialisations (what utils.SerializeCompiledCircuit wraps, utils/utils.go:97-122): pins algoplonk_amd/serialize.py
+	var vkBuf, ccsBuf bytes.Buffer
+	_, err = vk.WriteTo(&vkBuf)
+	must(err)
+	_, err = ccs.WriteTo(&ccsBuf)
+	must(err)
+
 	pubVec := pub.Vector().(fr.Vector)
 	claimed := proof.BatchedProof.ClaimedValues
 	out := map[string]interface{}{
@@ -206,6 +214,7 @@ func main() {
 			"s": []string{g1(&vk.S[0]), g1(&vk.S[1]), g1(&vk.S[2])},
 			"size_inv": frs([]fr.Element{vk.SizeInv}), "generator": frs([]fr.Element{vk.Generator}), "coset_shift": frs([]fr.Element{vk.CosetShift}),
 		},
+		"vk_write_to": hex.EncodeToString(vkBuf.Bytes()), "ccs_write_to_len": ccsBuf.Len(), "ecc_id": uint16(ecc.BN254),
 		"primitives": map[string]interface{}{
 			"msm_scalars": frs(canon), "msm_commit": g1(&commit), "ntt_in": frs(canon), "ntt_out": frs(evals),
 		},
