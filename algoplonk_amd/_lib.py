@@ -24,7 +24,7 @@ NB_BLINDING = 9
 # every symbol include/apk.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
     "apk_last_error", "apk_abi_version", "apk_device_count", "apk_g1_bytes", "apk_fp_bytes",
-    "apk_ctx_create", "apk_ctx_destroy", "apk_msm_ctx_create", "apk_ctx_get_vk", "apk_msm_g1", "apk_msm_g1_device", "apk_ntt",
+    "apk_ctx_create", "apk_ctx_destroy", "apk_msm_ctx_create", "apk_ctx_get_vk", "apk_msm_g1", "apk_msm_g1_device", "apk_msm_g1_batch_device", "apk_ctx_set_commit_hook", "apk_device_copy", "apk_ntt",
     "apk_prove", "apk_prove_device", "apk_verify", "apk_g2_decompress", "apk_g2_mul_generator", "apk_g1_mul_batch", "apk_g1_decompress", "apk_g1_to_lagrange", "apk_marshal_proof", "apk_marshal_public_inputs",
     "apk_fe_from_be", "apk_fe_to_be", "apk_hash_fr", "apk_host_fe_op", "apk_host_g1_op", "apk_g1_sum",
     "apk_device_alloc", "apk_device_free", "apk_device_upload", "apk_device_download",
@@ -86,6 +86,10 @@ class Stats(C.Structure):
     ]
 
 
+# int hook(void* user, int basis, uint32_t count, const void* const* d_scalars, const uint32_t* lens, void* out_points)
+COMMIT_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_void_p)
+
+
 def _load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -104,6 +108,9 @@ def _load() -> C.CDLL:
     lib.apk_ctx_get_vk.argtypes = [vp, C.POINTER(Vk)]
     lib.apk_msm_g1.argtypes = [vp, i32, vp, u64, vp]
     lib.apk_msm_g1_device.argtypes = [vp, i32, vp, u64, vp]
+    lib.apk_msm_g1_batch_device.argtypes = [vp, i32, C.c_uint32, vp, vp, vp, vp]
+    lib.apk_ctx_set_commit_hook.argtypes = [vp, COMMIT_HOOK, vp]
+    lib.apk_device_copy.argtypes = [vp, vp, vp, sz]
     lib.apk_ntt.argtypes = [vp, i32, i32, i32, vp]
     lib.apk_prove.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(Proof)]
     lib.apk_prove_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(Proof)]

@@ -337,6 +337,14 @@ int apk_msm_g1_device(apk_ctx* ctx, int basis, const void* sc, uint64_t len, voi
     NEED_CTX(); if (!sc || !out) { set_error("null argument"); return APK_ERR_ARG; }
     return ctx->be->msm(basis, sc, len, true, out);
 }
+int apk_msm_g1_batch_device(apk_ctx* ctx, int basis, uint32_t count, const void* const* d_scalars, const uint64_t* offsets,
+                            const uint64_t* lens, void* out) {
+    NEED_CTX();
+    if (!d_scalars || !offsets || !lens || !out) { set_error("null argument"); return APK_ERR_ARG; }
+    return ctx->be->msm_batch(basis, count, d_scalars, offsets, lens, out);
+}
+int apk_ctx_set_commit_hook(apk_ctx* ctx, apk_commit_hook hook, void* user) { NEED_CTX(); return ctx->be->set_commit_hook(hook, user); }
+int apk_device_copy(apk_ctx* ctx, void* d, const void* s, size_t b) { NEED_CTX(); return ctx->be->dev_copy(d, s, b); }
 int apk_ntt(apk_ctx* ctx, int which, int inverse, int coset, void* data) {
     NEED_CTX(); if (!data) { set_error("null data"); return APK_ERR_ARG; }
     return ctx->be->ntt(which, inverse, coset, data);

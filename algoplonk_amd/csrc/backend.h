@@ -21,6 +21,9 @@ struct Backend {
     virtual int init_msm_only(int device, const void* bases, uint64_t count, int msm_window) = 0;
     virtual int get_vk(apk_vk* out) = 0;
     virtual int msm(int basis, const void* scalars, uint64_t len, bool on_device, void* out) = 0;
+    virtual int msm_batch(int basis, uint32_t count, const void* const* d_scalars, const uint64_t* offsets, const uint64_t* lens, void* out) = 0;
+    virtual int set_commit_hook(apk_commit_hook fn, void* user) = 0;
+    virtual int dev_copy(void* d, const void* s, size_t bytes) = 0;
     virtual int ntt(int which, int inverse, int coset, void* data) = 0;
     virtual int prove(const void* L, const void* R, const void* O, bool on_device, const void* pub, const void* blinding,
                       const void* const* pi2, apk_proof* out) = 0;

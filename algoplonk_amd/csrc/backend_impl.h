@@ -136,6 +136,9 @@ class CurveBackend : public Backend {
         DevBuf counts, hist, offsets, unit_off, full_off, rem_rank, rem_list, scan_blk, sorted, partial, bucket_sum, rowcol, bit_partial, result, result_xyzz;
         void* h_pinned = nullptr;  // small pinned staging for results: [0,1024) affine, [1024,2048) XYZZ, [2048,4096) scalars
         uint32_t pending_pts = 0;  // MSM sums waiting in h_pinned for their affine conversion (sync_results)
+        bool hook_pending = false; // a commitment batch handed to the context's commit hook at the next sync_results()
+        int hook_basis = 0;
+        MsmBatchArgs hook_args{};
         DevBuf tail_flag;          // epoch of the last proof whose quotient had a non-zero tail (tail_nonzero_kernel)
         uint32_t epoch = 0;
     };
@@ -172,6 +175,9 @@ class CurveBackend : public Backend {
     std::vector<Slot*> slots_;
     std::mutex mu_;
     std::condition_variable cv_;
+    // intra-proof multi-GPU (apk_ctx_set_commit_hook): the prover's commitments go through the host's hook instead of this GPU
+    apk_commit_hook hook_ = nullptr;
+    void* hook_user_ = nullptr;
     // stats
     bool stats_on_ = false;
     uint32_t simds_ = 1024;  // SIMDs of the device (4 per CU); set at init
@@ -393,9 +399,31 @@ class CurveBackend : public Backend {
         return APK_OK;
     }
 
+    // A commitment batch of the prover.  Without a hook: run_msm on this GPU.  With one (the
+    // independent commitments of ONE proof dealt to several GPUs) the batch is parked and handed to the hook at the next
+    // sync_results(), after the stream has produced the scalar vectors - the launches queued in between (coset NTTs ...) run
+    // on this GPU while the other GPUs commit.
+    int commit(Slot& s, const MsmTables& T, int basis, const MsmBatchArgs& a, Aff* h_out) {
+        if (!hook_) return run_msm(s, T, a, h_out);
+        for (uint32_t b = 0; b < a.batch; b++)
+            if (a.offset[b] + a.len[b] > T.n_bases) { set_error("msm: %u scalars exceed the %u bases", a.len[b], T.n_bases); return APK_ERR_ARG; }
+        s.hook_pending = true; s.hook_basis = basis; s.hook_args = a;
+        return APK_OK;
+    }
+
     // stream sync + affine conversion of the MSM sums run_msm left in the pinned buffer (results land at h_pinned[0..])
     int sync_results(Slot& s) {
         HIPCHK(hipStreamSynchronize(s.stream));
+        if (s.hook_pending) {
+            s.hook_pending = false;
+            const MsmBatchArgs& a = s.hook_args;
+            uint8_t pts[MSM_MAX_BATCH * sizeof(Aff)];
+            const int rc = hook_(hook_user_, s.hook_basis, a.batch, a.scalars, a.len, pts);
+            if (rc != APK_OK) { set_error("commit hook failed with %d", rc); return rc == APK_ERR_ARG ? APK_ERR_ARG : APK_ERR_STATE; }
+            memcpy(s.h_pinned, pts, a.batch * sizeof(Aff));
+            s.pending_pts = 0;
+            return APK_OK;
+        }
         const Pt* g = reinterpret_cast<const Pt*>(reinterpret_cast<const uint8_t*>(s.h_pinned) + 1024);
         Aff* o = reinterpret_cast<Aff*>(s.h_pinned);
         for (uint32_t i = 0; i < s.pending_pts; i++) o[i] = g[i].to_affine();
@@ -693,6 +721,30 @@ class CurveBackend : public Backend {
         return APK_OK;
     }
 
+    // `count` partial MSMs in one batch: sum over scalars[b][0 .. len) * SRS[offset + i]; scalars in device memory
+    int msm_batch(int basis, uint32_t count, const void* const* d_scalars, const uint64_t* offsets, const uint64_t* lens, void* out) override {
+        HIPCHK(hipSetDevice(device_));
+        MsmTables& T = basis ? tab_lag_ : tab_can_;
+        if (!T.built) { set_error("context has no %s SRS", basis ? "Lagrange" : "canonical"); return APK_ERR_STATE; }
+        if (count == 0 || count > MSM_MAX_BATCH) { set_error("msm batch of %u (1..%d)", count, MSM_MAX_BATCH); return APK_ERR_ARG; }
+        SlotGuard g(this);
+        Slot& s = *g.s;
+        MsmBatchArgs a{};
+        a.batch = count;
+        for (uint32_t b = 0; b < count; b++) {
+            if (offsets[b] + lens[b] > T.n_bases || !d_scalars[b]) { set_error("msm batch: range [%llu, +%llu) outside the %u bases", (unsigned long long)offsets[b], (unsigned long long)lens[b], T.n_bases); return APK_ERR_ARG; }
+            a.scalars[b] = d_scalars[b]; a.len[b] = (uint32_t)lens[b]; a.offset[b] = (uint32_t)offsets[b];
+        }
+        CHK(run_msm(s, T, a, reinterpret_cast<Aff*>(s.h_pinned)));
+        HIPCHK(hipStreamSynchronize(s.stream));
+        const Pt* gsum = reinterpret_cast<const Pt*>(reinterpret_cast<const uint8_t*>(s.h_pinned) + 1024);
+        for (uint32_t b = 0; b < count; b++) { const Aff r = gsum[b].to_affine(); memcpy(reinterpret_cast<uint8_t*>(out) + b * sizeof(Aff), &r, sizeof r); }
+        s.pending_pts = 0;
+        return APK_OK;
+    }
+    int set_commit_hook(apk_commit_hook fn, void* user) override { hook_ = fn; hook_user_ = user; return APK_OK; }
+    int dev_copy(void* dd, const void* ss, size_t bytes) override { HIPCHK(hipSetDevice(device_)); HIPCHK(hipMemcpy(dd, ss, bytes, hipMemcpyDeviceToDevice)); return APK_OK; }
+
     int ntt(int which, int inverse, int coset, void* data) override {
         if (msm_only_) { set_error("MSM-only context has no NTT domain"); return APK_ERR_STATE; }
         HIPCHK(hipSetDevice(device_));
@@ -944,7 +996,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         HIPCHK(hipMemcpyAsync(s.pi2_lag[k].p, pi2[k], fn, kin, st));
         MsmBatchArgs a{};
         a.batch = 1; a.scalars[0] = s.pi2_lag[k].p; a.len[0] = n; a.offset[0] = 0;
-        CHK(run_msm(s, tab_lag_, a, hp));
+        CHK(commit(s, tab_lag_, 1, a, hp));
         CHK(inv_ntt_n(st, ptr<Fr>(s.pi2_lag[k]), ptr<Fr>(s.pi2_can[k])));
         CHK(coset_ntt_4n(st, ptr<Fr>(s.pi2_can[k]), n, ptr<Fr>(s.epi2[k])));
         CHK(sync_results(s));
@@ -969,7 +1021,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         MsmBatchArgs a{};
         a.batch = 3;
         for (int j = 0; j < 3; j++) { a.scalars[j] = canon[j]; a.len[j] = n + 2; a.offset[j] = 0; }
-        CHK(run_msm(s, tab_can_, a, hp));
+        CHK(commit(s, tab_can_, 0, a, hp));
     }
     // completed Qk: public inputs and commitment values written into the Lagrange column, then iNTT
     if (!qk_direct_) {
@@ -1034,7 +1086,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         blind_kernel<FRP><<<1, 64, 0, st>>>(ptr<Fr>(s.cz), n, b, 3); KCHK();
         MsmBatchArgs a{};
         a.batch = 1; a.scalars[0] = s.cz.p; a.len[0] = n + 3; a.offset[0] = 0;
-        CHK(run_msm(s, tab_can_, a, hp));
+        CHK(commit(s, tab_can_, 0, a, hp));
     }
     CHK(coset_ntt_4n(st, ptr<Fr>(s.cz), n + 3, ptr<Fr>(s.ez)));
     CHK(sync_results(s));
@@ -1081,7 +1133,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         MsmBatchArgs a{};
         a.batch = 3;
         for (int j = 0; j < 3; j++) { a.scalars[j] = ptr<Fr>(s.hcan) + (size_t)j * (n + 2); a.len[j] = n + 2; a.offset[j] = 0; }
-        CHK(run_msm(s, tab_can_, a, hp));
+        CHK(commit(s, tab_can_, 0, a, hp));
         // the quotient is a polynomial of degree < 3n+6 iff the witness satisfies the circuit: every coefficient of the tail
         // h[3(n+2) .. 4n) must vanish (OR-reduce on the device, one flag word back)
         s.epoch++;
@@ -1224,7 +1276,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         a.batch = 2;
         a.scalars[0] = s.q1.p; a.len[0] = n + 2; a.offset[0] = 0;
         a.scalars[1] = s.q2.p; a.len[1] = n + 2; a.offset[1] = 0;
-        CHK(run_msm(s, tab_can_, a, hp));
+        CHK(commit(s, tab_can_, 0, a, hp));
     }
     CHK(sync_results(s));
     store_pt(out->zshift_h, hp[1]);

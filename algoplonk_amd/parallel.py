@@ -2,6 +2,9 @@
 ROCm; "gloo" in the CPU tests).
 
 * independent proofs            -> `my_share`: a contiguous share per rank, no data-path collective (replicas only).
+* ONE proof on several GPUs      -> `SplitCommitter`: every commitment batch of the prover is dealt to the ranks by index
+  range of its flattened (scalar, point) pairs; the transcript and the polynomial arithmetic stay on rank 0 (SURVEY.md §8e
+  row 2: "independent commitments inside one proof").
 * ONE MSM sharded by index range -> `ShardedMsm`: rank r holds the windowed tables for bases [lo_r, hi_r) in its own
   HBM, computes a full partial MSM over its slice of the scalars, then ONE all-gather of world x (64|96)-byte affine
   points and world-1 point additions give the result on every rank.  A numeric all-reduce cannot add curve points,
@@ -11,7 +14,7 @@ ROCm; "gloo" in the CPU tests).
 from __future__ import annotations
 
 import ctypes as C
-from typing import Tuple
+from typing import List, Optional, Sequence, Tuple
 
 from . import ecc
 from ._lib import lib, check
@@ -89,3 +92,147 @@ class ShardedMsm:
         if self._ctx:
             lib.apk_ctx_destroy(self._ctx)
             self._ctx = C.c_void_p()
+
+
+# ---- intra-proof multi-GPU: the commitments of ONE proof dealt to the ranks -----------------------------
+def deal(lens: Sequence[int], rank: int, world: int):
+    """The (commitment, lo, hi) segments of rank `rank` when the sum(lens) (scalar, point) pairs of a commitment batch are
+    cut into `world` contiguous shares of the flattened pair list (sizes differ by at most one)."""
+    lo, hi = my_share(sum(lens), rank, world)
+    segs, base = [], 0
+    for k, n in enumerate(lens):
+        a, b = max(lo, base), min(hi, base + n)
+        if a < b:
+            segs.append((k, a - base, b - base))
+        base += n
+    return segs
+
+
+class SplitCommitter:
+    """One proof, several GPUs.  Every rank holds the circuit context (SRS tables resident: any rank can commit any index
+    range of any polynomial); rank 0 runs the prover (transcript, NTTs, quotient ...) and at each Fiat-Shamir sync point its
+    commit hook (include/apk.h apk_ctx_set_commit_hook) deals the batch's (scalar, point) pairs evenly:
+
+        leader : header broadcast (basis, lens)  ->  scatter of the scalar slices (one RCCL scatter: the slices leave rank 0
+                 on its 7 xGMI links in parallel; 2^21 x 32 B x 3 polynomials / 8 ranks = 24 MB per link)
+        all    : apk_msm_g1_batch_device over the dealt segments (<= 3 segments per rank)
+        all    : all-gather of count x (64|96)-byte partial sums; the leader adds them per commitment (apk_g1_sum)
+
+    Workers sit in serve() until the leader sends the stop header.  The only collectives are that broadcast, scatter and
+    all-gather; a numeric all-reduce cannot add curve points."""
+
+    STOP = -1
+
+    def __init__(self, curve: ecc.ID, ctx, rank: int, world: int, group=None, device: Optional[str] = None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.curve, self.ctx, self.rank, self.world, self.group = curve, ctx, rank, world, group
+        self.dev = device or ("cuda" if world > 1 and dist.get_backend(group) == "nccl" else ("cuda" if world == 1 and torch.cuda.is_available() else "cpu"))
+        self._hook = None
+        self.batches = 0
+
+    # -- what a rank does with its share: overridden in the CPU tests (no GPU there)
+    def local_commit(self, basis: int, chunk, segs, lens) -> bytes:
+        """Partial sums of this rank's segments: chunk = its scalar slices back to back (a uint8 tensor on this rank's GPU).
+        Returns len(lens) affine points, infinity where the rank holds no part of a commitment."""
+        cv = self.curve
+        nb = 2 * cv.fp_bytes
+        out = bytearray(len(lens) * nb)
+        if segs:
+            k = len(segs)
+            ptrs, offs, ls, at = (C.c_void_p * k)(), (C.c_uint64 * k)(), (C.c_uint64 * k)(), 0
+            for i, (_, lo, hi) in enumerate(segs):
+                ptrs[i], offs[i], ls[i] = chunk.data_ptr() + at, lo, hi - lo
+                at += (hi - lo) * 32
+            res = C.create_string_buffer(k * nb)
+            check(lib.apk_msm_g1_batch_device(self.ctx, basis, k, ptrs, offs, ls, res))
+            for i, (c, _, _) in enumerate(segs):
+                out[c * nb: (c + 1) * nb] = res.raw[i * nb: (i + 1) * nb]
+        return bytes(out)
+
+    def fill_chunks(self, staging, d_scalars, lens, chunk_bytes: int) -> None:
+        """Leader: copy every rank's slices out of the prover's vectors into that rank's row of the staging tensor."""
+        for r in range(self.world):
+            at = r * chunk_bytes
+            for k, lo, hi in deal(lens, r, self.world):
+                check(lib.apk_device_copy(self.ctx, staging.data_ptr() + at, d_scalars[k] + lo * 32, (hi - lo) * 32))
+                at += (hi - lo) * 32
+
+    def _round(self, basis: int, lens, d_scalars=None) -> Optional[List[bytes]]:
+        torch, dist, cv = self.torch, self.dist, self.curve
+        nb = 2 * cv.fp_bytes
+        total = sum(lens)
+        chunk_bytes = ((total + self.world - 1) // self.world) * 32
+        mine = torch.empty(chunk_bytes, dtype=torch.uint8, device=self.dev)
+        if self.rank == 0:
+            staging = torch.empty(self.world * chunk_bytes, dtype=torch.uint8, device=self.dev)
+            self.fill_chunks(staging, d_scalars, lens, chunk_bytes)
+            if self.world > 1:
+                dist.scatter(mine, [staging[r * chunk_bytes: (r + 1) * chunk_bytes] for r in range(self.world)], src=0, group=self.group)
+            else:
+                mine = staging
+        else:
+            dist.scatter(mine, None, src=0, group=self.group)
+        part = self.local_commit(basis, mine, deal(lens, self.rank, self.world), lens)
+        if self.world > 1:
+            allp = torch.empty(self.world * len(lens) * nb, dtype=torch.uint8, device=self.dev)
+            dist.all_gather_into_tensor(allp, torch.frombuffer(bytearray(part), dtype=torch.uint8).to(self.dev), group=self.group)
+            raw = allp.cpu().numpy().tobytes()
+        else:
+            raw = part
+        self.batches += 1
+        if self.rank != 0:
+            return None
+        k = len(lens)
+        return [g1_sum(cv, b"".join(raw[(r * k + c) * nb: (r * k + c + 1) * nb] for r in range(self.world))) for c in range(k)]
+
+    def _header(self, basis: int, lens) -> List[int]:
+        torch, dist = self.torch, self.dist
+        h = torch.zeros(8, dtype=torch.int64, device=self.dev)
+        if self.rank == 0:
+            h[0], h[1] = basis, len(lens)
+            for i, n in enumerate(lens):
+                h[2 + i] = n
+        if self.world > 1:
+            dist.broadcast(h, src=0, group=self.group)
+        return [int(x) for x in h.cpu().tolist()]
+
+    # -- leader
+    def commit(self, basis: int, d_scalars: Sequence[int], lens: Sequence[int]) -> List[bytes]:
+        self._header(basis, lens)
+        return self._round(basis, list(lens), list(d_scalars))
+
+    def install(self) -> None:
+        """Leader: route the context's commitments through this object (apk_ctx_set_commit_hook)."""
+        from . import _lib
+        nb = 2 * self.curve.fp_bytes
+
+        def hook(_user, basis, count, d_scalars, lens, out_points):
+            try:
+                pts = self.commit(basis, [d_scalars[i] for i in range(count)], [lens[i] for i in range(count)])
+                C.memmove(out_points, b"".join(pts), count * nb)
+                return 0
+            except Exception as e:  # never unwind through the C frames
+                import sys
+                print("SplitCommitter hook: %r" % (e,), file=sys.stderr)
+                return 3
+        self._hook = _lib.COMMIT_HOOK(hook)
+        check(lib.apk_ctx_set_commit_hook(self.ctx, self._hook, None))
+
+    def stop(self) -> None:
+        if self.rank == 0:
+            if self._hook is not None:
+                check(lib.apk_ctx_set_commit_hook(self.ctx, type(self._hook)(0), None))
+                self._hook = None
+            if self.world > 1:
+                self._header(self.STOP, [])
+
+    # -- workers
+    def serve(self) -> int:
+        """Rank != 0: take part in the leader's rounds until it stops; returns the number of batches served."""
+        while True:
+            h = self._header(0, [])
+            if h[0] == self.STOP:
+                return self.batches
+            self._round(h[0], h[2: 2 + h[1]])

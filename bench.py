@@ -18,6 +18,10 @@ Modes:
                      (BASELINE configs[1], and configs[4] with --curve bls12_381 --log-n 21 --bsb22 1);
   msm-sharded      : configs[3] - ONE 2^log_n MSM split by index range over the ranks, one all-gather of a 64/96-byte point
                      per rank + local point additions; strong scaling;
+  prove-split      : intra-proof multi-GPU: ONE proof at a time, its commitment batches dealt to the
+                     ranks by index range (algoplonk_amd/parallel.py::SplitCommitter: scatter of scalar slices, per-rank
+                     partial MSMs, all-gather of the partial sums), transcript on rank 0; strong scaling - meant for
+                     --curve bls12_381 --log-n 21;
   launcher-selftest: NOT a measurement - the launcher, rendezvous, barrier / MAX reduction and JSON plumbing with a no-op
                      step on gloo (CPU tier test of this file).
 
@@ -62,7 +66,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes behind roofline.traffic")
-    ap.add_argument("--mode", default="prove", choices=["prove", "msm-sharded", "launcher-selftest"])
+    ap.add_argument("--mode", default="prove", choices=["prove", "msm-sharded", "prove-split", "launcher-selftest"])
     return ap.parse_args(argv)
 
 
@@ -237,7 +241,71 @@ def main(argv=None) -> None:
     cv = ecc.BN254 if args.curve == "bn254" else ecc.BLS12_381
     if args.mode == "msm-sharded":
         return bench_sharded_msm(args, cv, rk)
+    if args.mode == "prove-split":
+        return bench_prove_split(args, cv, rk)
     return bench_prove(args, cv, rk)
+
+
+def bench_prove_split(args, cv, rk) -> None:
+    """One proof at a time on N GPUs: every rank holds the circuit context; rank 0 proves with its commitments routed through
+    SplitCommitter, the other ranks serve.  A step = one proof; value = proofs/s of the whole job (strong scaling)."""
+    import hashlib
+    from algoplonk_amd import _lib, frontend, parallel, plonk, setup, workloads, MarshalProof
+    from algoplonk_amd._lib import lib, check
+
+    seed = 0xA190 if args.curve == "bn254" else 0xA193
+    wl = workloads.random_circuit(cv, args.log_n, seed)
+    n = wl.ccs.domain_size()
+    srs = setup.unsafe_srs(cv, n, wl.tau, device=rk.local_rank)
+    pk, vk = plonk.Setup(wl.ccs, srs, device=rk.local_rank, msm_window=args.msm_window, slots=1)
+    sc = parallel.SplitCommitter(cv, pk.ctx, rk.rank, rk.world)
+    line = None
+    if rk.rank == 0:
+        L, R, O = frontend.wire_columns(wl.ccs, wl.solution)
+        dptr = []
+        for v in (L, R, O):
+            b = cv.fr_vector(v)
+            p = C.c_void_p()
+            check(lib.apk_device_alloc(pk.ctx, len(b), C.byref(p)))
+            check(lib.apk_device_upload(pk.ctx, p, b, len(b)))
+            dptr.append(p)
+        pub, bl = cv.fr_vector(wl.witness.public), cv.fr_vector(wl.blinding)
+        proof = _lib.Proof()
+
+        def step():
+            check(lib.apk_prove_device(pk.ctx, dptr[0], dptr[1], dptr[2], pub, bl, None, C.byref(proof)))
+
+        step()                                    # single-GPU reference proof (no hook) for the byte comparison
+        want = MarshalProof(plonk.Proof(cv, proof))
+        sc.install()
+        for _ in range(args.warmup):
+            step()
+        rk.torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        rk.torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t1
+        got = MarshalProof(plonk.Proof(cv, proof))
+        batches = sc.batches
+        sc.stop()
+        line = {
+            "metric": "proofs/sec", "value": round(args.steps / elapsed, 4), "unit": "proofs/sec", "n_gpus": rk.world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u32x8 Fr / u32x12 Fp (Montgomery)" if cv.name != "bn254" else "u32x8 (Montgomery Fr/Fp)", "data": "synthetic",
+            "config": {"workload": wl.name + ", one proof at a time", "log_n": args.log_n, "curve": cv.name,
+                       "parallelism": "commitment batches dealt by index range x%d (scatter + all-gather of partial sums), transcript on rank 0" % rk.world,
+                       "world_size": rk.world, "backend": "nccl (RCCL)" if rk.world > 1 else "single process"},
+            "commit_batches_per_proof": batches // (args.steps + args.warmup),
+            "proof_sha256_prefix": hashlib.sha256(got).hexdigest()[:16], "matches_single_gpu_proof": got == want,
+        }
+    else:
+        sc.serve()
+    # the contract's barrier + MAX over ranks: the leader's clock covers every rank's work (workers only serve its rounds)
+    rk.fence()
+    if rk.rank == 0:
+        print(json.dumps(line), flush=True)
+    rk.close()
 
 
 def launcher_selftest(args) -> None:

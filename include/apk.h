@@ -113,6 +113,11 @@ int apk_ctx_get_vk(apk_ctx* ctx, apk_vk* out);
 int apk_msm_g1(apk_ctx* ctx, int basis, const void* scalars, uint64_t len, void* out);
 /* same, scalars already resident in device memory (what bench.py times: inputs in HBM) */
 int apk_msm_g1_device(apk_ctx* ctx, int basis, const void* d_scalars, uint64_t len, void* out);
+/* `count` (<= 4) partial commitments in one launch sequence: out[b] = sum_{i < lens[b]} d_scalars[b][i] * SRS[offsets[b] + i].
+ * The building block of an MSM split by index range over GPUs that each hold the whole SRS (algoplonk_amd/parallel.py
+ * SplitCommitter): a rank commits the slices it was dealt, the partial sums are all-gathered and added (apk_g1_sum). */
+int apk_msm_g1_batch_device(apk_ctx* ctx, int basis, uint32_t count, const void* const* d_scalars, const uint64_t* offsets,
+                            const uint64_t* lens, void* out);
 /* fft.Domain.FFT / FFTInverse on the context's size-n (which=0) or size-4n (which=1) domain, natural order in
  * and out; coset != 0 evaluates on / interpolates from the coset CosetShift * <omega>.  data: host, in place. */
 int apk_ntt(apk_ctx* ctx, int which, int inverse, int coset, void* data);
@@ -144,6 +149,15 @@ int apk_prove(apk_ctx* ctx, const void* L, const void* R, const void* O, const v
 /* Variant with L,R,O already resident in device memory (n Fr each). */
 int apk_prove_device(apk_ctx* ctx, const void* d_L, const void* d_R, const void* d_O, const void* public_inputs,
                      const void* blinding, const void* const* d_pi2, apk_proof* out);
+
+/* Intra-proof multi-GPU.  With a hook installed, apk_prove* does not run its KZG commitments on
+ * the context's own GPU: at each Fiat-Shamir sync point it calls the hook with the batch's scalar vectors (device memory of
+ * this context, `lens[b]` Fr each, commitment b = sum d_scalars[b][i] * SRS_basis[i]) and expects `count` G1 affine points
+ * (apk_g1_bytes each) in out_points.  The hook deals the work to the other GPUs of the node (algoplonk_amd/parallel.py:
+ * scatter of scalar slices over RCCL, apk_msm_g1_batch_device on every rank, all-gather of the partial sums) while this GPU
+ * runs the launches the prover queued behind the batch.  Return APK_OK or an error code.  NULL removes the hook. */
+typedef int (*apk_commit_hook)(void* user, int basis, uint32_t count, const void* const* d_scalars, const uint32_t* lens, void* out_points);
+int apk_ctx_set_commit_hook(apk_ctx* ctx, apk_commit_hook hook, void* user);
 
 /* ---- the verifier: the host-side mirror of plonk.Verify(proof, vk, publicWitness) (algoplonk.go:93) --------------------
  * (*CompiledCircuit).Verify runs the prover AND gnark's verifier before it hands out a VerifiedProof (algoplonk.go:79-98).
@@ -214,6 +228,7 @@ int apk_device_alloc(apk_ctx* ctx, size_t bytes, void** d_ptr);
 int apk_device_free(apk_ctx* ctx, void* d_ptr);
 int apk_device_upload(apk_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 int apk_device_download(apk_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+int apk_device_copy(apk_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);   /* device to device, same GPU */
 
 /* ---- timing hooks used by bench.py: HIP-event time of the dominant kernel on the stream it runs on ------- */
 typedef struct {

@@ -75,6 +75,82 @@ def test_sharded_msm_and_shares_world2():
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
 
 
+def _split_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from algoplonk_amd import ecc, parallel
+    from oracle import curves as oc, plonk as oplonk
+    from oracle.prng import SplitMix64
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cv, ov = ecc.BLS12_381, oc.BLS12_381
+        tau, nbases = 0xABCDEF12345, 19
+        pts = [ov.mul(ov.g1, pow(tau, i, cv.r)) for i in range(nbases)]
+        g = SplitMix64(7)
+        vectors = [[g.fr(cv.r) for _ in range(m)] for m in (18, 18, 18, 19, 5)]
+        host = [cv.fr_vector(v) for v in vectors]
+
+        class OracleSplit(parallel.SplitCommitter):
+            """The product's scheduling (deal / header / scatter / all-gather / per-commitment sums) with the two GPU
+            touch points swapped: slices are cut from host bytes, the per-rank partial MSM is the oracle's."""
+            def fill_chunks(self, staging, d_scalars, lens, chunk_bytes):
+                for r in range(self.world):
+                    at = r * chunk_bytes
+                    for k, lo, hi in parallel.deal(lens, r, self.world):
+                        staging[at: at + (hi - lo) * 32] = torch.frombuffer(bytearray(host[d_scalars[k]][lo * 32: hi * 32]), dtype=torch.uint8)
+                        at += (hi - lo) * 32
+
+            def local_commit(self, basis, chunk, segs, lens):
+                raw, at, out = chunk.numpy().tobytes(), 0, [None] * len(lens)
+                for k, lo, hi in segs:
+                    sc = cv.fr_vector_decode(raw[at: at + (hi - lo) * 32])
+                    out[k] = ov.msm_naive(pts[lo:hi], sc)
+                    at += (hi - lo) * 32
+                return b"".join(cv.g1_to_bytes(P) for P in out)
+
+        sc = OracleSplit(cv, None, rank, world, device="cpu")
+        if rank == 0:
+            # a batch of three (round 1 / round 3 of the prover), a single commitment, a batch of two of unequal lengths
+            for batch in ([0, 1, 2], [3], [4, 3]):
+                lens = [len(vectors[i]) for i in batch]
+                got = sc.commit(0, batch, lens)
+                want = [ov.mul(ov.g1, oplonk.poly_eval(vectors[i], tau, cv.r)) for i in batch]
+                assert [cv.g1_from_bytes(b) for b in got] == want, batch
+            sc.stop()
+            assert sc.batches == 3
+        else:
+            assert sc.serve() == 3
+        # the deal tiles the flattened pair list: every pair exactly once, shares differ by at most one pair
+        for lens in ([18, 18, 18], [7], [5, 19], [1, 1, 1, 1]):
+            segs = [parallel.deal(lens, r, 3) for r in range(3)]
+            seen = sorted((k, i) for ss in segs for k, lo, hi in ss for i in range(lo, hi))
+            assert seen == [(k, i) for k, n in enumerate(lens) for i in range(n)]
+            sizes = [sum(hi - lo for _, lo, hi in ss) for ss in segs]
+            assert max(sizes) - min(sizes) <= 1
+        q.put((rank, "ok"))
+    except Exception as e:
+        import traceback
+        q.put((rank, "FAIL: %r %s" % (e, traceback.format_exc()[-600:])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_split_committer_schedule_world2():
+    """SURVEY.md section 8e row 2 (intra-proof multi-GPU): leader / worker protocol of SplitCommitter on two gloo ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=240) for _ in procs]
+    [p.join(timeout=60) for p in procs]
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
 def test_my_share_partitions():
     from algoplonk_amd.parallel import my_share
     for total in (0, 1, 7, 8, 131072):

@@ -525,3 +525,54 @@ def test_public_api_pythagorean_compile_verify_export(gpu, tmp_path):
         with pytest.raises(RuntimeError, match="error creating Plonk proof"):
             cc.Verify(wrong, blinding=bl)
         cc.Pk.close()
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12-381"])
+def test_commit_hook_and_ranged_batch_msm(gpu, cname):
+    """SURVEY.md section 8e row 2 on ONE GPU: (1) apk_msm_g1_batch_device = partial commitments over index ranges, against
+    the oracle; (2) a proof whose commitments all go through the context's commit hook (SplitCommitter, world = 1: the same
+    code path the ranks of a node run, minus the collectives) is byte-identical to the plain proof - with and without BSB22."""
+    from algoplonk_amd import parallel, workloads
+    cv, ov = CURVES[cname]
+    ccs, w, sol = random_chain_ccs(cv, 9, 0xA190 + 9)
+    pk, vk, opk, srs = _setup_pair(cv, ov, ccs, 31, gpu)
+    n, tau = ccs.domain_size(), srs.tau
+    g = SplitMix64(17)
+    sc = [g.fr(cv.r) for _ in range(n + 3)]
+    buf = cv.fr_vector(sc)
+    d = C.c_void_p()
+    check(lib.apk_device_alloc(pk.ctx, len(buf), C.byref(d)))
+    check(lib.apk_device_upload(pk.ctx, d, buf, len(buf)))
+    segs = [(0, 100), (100, n + 3), (37, 38)]
+    k = len(segs)
+    ptrs, offs, ls = (C.c_void_p * k)(), (C.c_uint64 * k)(), (C.c_uint64 * k)()
+    for i, (lo, hi) in enumerate(segs):
+        ptrs[i], offs[i], ls[i] = d.value + 32 * lo, lo, hi - lo
+    out = C.create_string_buffer(k * 2 * cv.fp_bytes)
+    check(lib.apk_msm_g1_batch_device(pk.ctx, 0, k, ptrs, offs, ls, out))
+    got = cv.g1_vector_decode(out.raw)
+    for (lo, hi), P in zip(segs, got):
+        assert P == ov.mul(ov.g1, sum(sc[i] * pow(tau, i, cv.r) for i in range(lo, hi)) % cv.r)
+    assert ov.add(got[0], got[1]) == pk.msm(sc)
+    offs[1] = n                                                        # range past the SRS: an error, not a wild read
+    assert lib.apk_msm_g1_batch_device(pk.ctx, 0, k, ptrs, offs, ls, out) == _lib.APK_ERR_ARG
+    check(lib.apk_device_free(pk.ctx, d))
+    # (2) the hook path
+    bl = blinding(cv, 5)
+    plain = MarshalProof(ap_plonk.Prove(ccs, pk, w, bl))
+    split = parallel.SplitCommitter(cv, pk.ctx, 0, 1)
+    split.install()
+    hooked = MarshalProof(ap_plonk.Prove(ccs, pk, w, bl))
+    assert split.batches == 4                                          # {L,R,O}, {Z}, {H1,H2,H3}, {W_zeta, W_omega*zeta}
+    split.stop()
+    assert hooked == plain and MarshalProof(ap_plonk.Prove(ccs, pk, w, bl)) == plain
+    pk.close()
+    ccs2, w2, bl2, tau2 = workloads.random_circuit_bsb22(cv, 8, 0xA193, nb_commitments=1, committed=4)
+    srs2 = ap_setup.unsafe_srs(cv, ccs2.domain_size(), tau2, device=gpu, lagrange=True)
+    pk2, vk2 = ap_plonk.Setup(ccs2, srs2, device=gpu)
+    plain2 = MarshalProof(ap_plonk.Prove(ccs2, pk2, w2, bl2, hiding=[(3, 4)]))
+    split2 = parallel.SplitCommitter(cv, pk2.ctx, 0, 1)
+    split2.install()
+    assert MarshalProof(ap_plonk.Prove(ccs2, pk2, w2, bl2, hiding=[(3, 4)])) == plain2 and split2.batches == 5
+    split2.stop()
+    pk2.close()
