@@ -399,6 +399,8 @@ class CurveBackend : public Backend {
         return APK_OK;
     }
 
+    static Slot*& hook_slot() { static thread_local Slot* p = nullptr; return p; }
+
     // A commitment batch of the prover.  Without a hook: run_msm on this GPU.  With one (the
     // independent commitments of ONE proof dealt to several GPUs) the batch is parked and handed to the hook at the next
     // sync_results(), after the stream has produced the scalar vectors - the launches queued in between (coset NTTs ...) run
@@ -418,7 +420,12 @@ class CurveBackend : public Backend {
             s.hook_pending = false;
             const MsmBatchArgs& a = s.hook_args;
             uint8_t pts[MSM_MAX_BATCH * sizeof(Aff)];
+            // the hook's own share of the batch comes back in through apk_msm_g1_batch_device on this thread: it runs on THIS
+            // slot (idle now: the stream was just synchronised and the parked batch never touched the MSM workspace) instead
+            // of waiting for a free one - with one slot it would wait for itself
+            hook_slot() = &s;
             const int rc = hook_(hook_user_, s.hook_basis, a.batch, a.scalars, a.len, pts);
+            hook_slot() = nullptr;
             if (rc != APK_OK) { set_error("commit hook failed with %d", rc); return rc == APK_ERR_ARG ? APK_ERR_ARG : APK_ERR_STATE; }
             memcpy(s.h_pinned, pts, a.batch * sizeof(Aff));
             s.pending_pts = 0;
@@ -727,11 +734,22 @@ class CurveBackend : public Backend {
         MsmTables& T = basis ? tab_lag_ : tab_can_;
         if (!T.built) { set_error("context has no %s SRS", basis ? "Lagrange" : "canonical"); return APK_ERR_STATE; }
         if (count == 0 || count > MSM_MAX_BATCH) { set_error("msm batch of %u (1..%d)", count, MSM_MAX_BATCH); return APK_ERR_ARG; }
-        SlotGuard g(this);
+        Slot* own = hook_slot();                       // called from inside this thread's commit hook: use the prover's slot
+        bool mine = false;
+        for (Slot* t : slots_) mine |= (t == own);
+        if (!mine) own = nullptr;
+        struct MaybeGuard { CurveBackend* b; Slot* s; bool owned; ~MaybeGuard() { if (owned) b->release(s); } };
+        MaybeGuard g{this, own ? own : acquire(), own == nullptr};
         Slot& s = *g.s;
         MsmBatchArgs a{};
         a.batch = count;
         for (uint32_t b = 0; b < count; b++) {
+            hipPointerAttribute_t at{};
+            if (d_scalars[b] && (hipPointerGetAttributes(&at, d_scalars[b]) != hipSuccess || at.type != hipMemoryTypeDevice)) {
+                (void)hipGetLastError();
+                set_error("msm batch: scalars[%u] is not device memory", b);
+                return APK_ERR_ARG;
+            }
             if (offsets[b] + lens[b] > T.n_bases || !d_scalars[b]) { set_error("msm batch: range [%llu, +%llu) outside the %u bases", (unsigned long long)offsets[b], (unsigned long long)lens[b], T.n_bases); return APK_ERR_ARG; }
             a.scalars[b] = d_scalars[b]; a.len[b] = (uint32_t)lens[b]; a.offset[b] = (uint32_t)offsets[b];
         }
@@ -743,7 +761,19 @@ class CurveBackend : public Backend {
         return APK_OK;
     }
     int set_commit_hook(apk_commit_hook fn, void* user) override { hook_ = fn; hook_user_ = user; return APK_OK; }
-    int dev_copy(void* dd, const void* ss, size_t bytes) override { HIPCHK(hipSetDevice(device_)); HIPCHK(hipMemcpy(dd, ss, bytes, hipMemcpyDeviceToDevice)); return APK_OK; }
+    // device-to-device copy that has COMPLETED when the call returns (hipMemcpy D2D returns early, and the proving streams are
+    // non-blocking streams: they do not order themselves behind the null stream)
+    int dev_copy(void* dd, const void* ss, size_t bytes) override {
+        HIPCHK(hipSetDevice(device_));
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, dd) != hipSuccess || at.type != hipMemoryTypeDevice) { (void)hipGetLastError(); set_error("apk_device_copy: destination is not device memory"); return APK_ERR_ARG; }
+        if (hipPointerGetAttributes(&at, ss) != hipSuccess || at.type != hipMemoryTypeDevice) { (void)hipGetLastError(); set_error("apk_device_copy: source is not device memory"); return APK_ERR_ARG; }
+        Slot* own = hook_slot();
+        hipStream_t st = own ? own->stream : nullptr;
+        HIPCHK(hipMemcpyAsync(dd, ss, bytes, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return APK_OK;
+    }
 
     int ntt(int which, int inverse, int coset, void* data) override {
         if (msm_only_) { set_error("MSM-only context has no NTT domain"); return APK_ERR_STATE; }

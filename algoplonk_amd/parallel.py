@@ -108,6 +108,26 @@ def deal(lens: Sequence[int], rank: int, world: int):
     return segs
 
 
+class _DeviceBytes:
+    """`n` bytes of this context's GPU memory with the one method SplitCommitter needs (data_ptr): the single-rank path
+    stays free of torch - its wheel bundles a ROCm runtime of its own, and the second HIP runtime to open the GPU in one
+    process does not see it, so torch may only be brought in where RCCL needs it (world > 1; bench.py initialises it first)."""
+
+    def __init__(self, ctx, n: int):
+        self.ctx, self.p = ctx, C.c_void_p()
+        check(lib.apk_device_alloc(ctx, max(n, 16), C.byref(self.p)))
+
+    def data_ptr(self) -> int:
+        return self.p.value
+
+    def __del__(self):
+        try:
+            if self.p:
+                lib.apk_device_free(self.ctx, self.p)
+        except Exception:
+            pass
+
+
 class SplitCommitter:
     """One proof, several GPUs.  Every rank holds the circuit context (SRS tables resident: any rank can commit any index
     range of any polynomial); rank 0 runs the prover (transcript, NTTs, quotient ...) and at each Fiat-Shamir sync point its
@@ -124,11 +144,19 @@ class SplitCommitter:
     STOP = -1
 
     def __init__(self, curve: ecc.ID, ctx, rank: int, world: int, group=None, device: Optional[str] = None):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
         self.curve, self.ctx, self.rank, self.world, self.group = curve, ctx, rank, world, group
-        self.dev = device or ("cuda" if world > 1 and dist.get_backend(group) == "nccl" else ("cuda" if world == 1 and torch.cuda.is_available() else "cpu"))
+        self.torch = self.dist = None
+        self.dev = device
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            self.torch, self.dist = torch, dist
+            # staging tensors live where the collectives run: the GPU (RCCL) - "cpu" only for the gloo tier tests, which replace
+            # both GPU touch points (fill_chunks / local_commit)
+            self.dev = device or ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
+            if self.dev == "cuda" and not torch.cuda.is_available():
+                raise RuntimeError("SplitCommitter: torch does not see the GPU - import torch and touch torch.cuda BEFORE libapk's "
+                                   "first HIP call (two HIP runtimes in one process: the second one finds no device)")
         self._hook = None
         self.batches = 0
 
@@ -164,23 +192,23 @@ class SplitCommitter:
         nb = 2 * cv.fp_bytes
         total = sum(lens)
         chunk_bytes = ((total + self.world - 1) // self.world) * 32
+        if self.world == 1:                        # no collective: the whole batch is this rank's share
+            staging = _DeviceBytes(self.ctx, chunk_bytes)
+            self.fill_chunks(staging, d_scalars, lens, chunk_bytes)
+            part = self.local_commit(basis, staging, deal(lens, 0, 1), lens)
+            self.batches += 1
+            return [g1_sum(cv, part[c * nb: (c + 1) * nb]) for c in range(len(lens))]
         mine = torch.empty(chunk_bytes, dtype=torch.uint8, device=self.dev)
         if self.rank == 0:
             staging = torch.empty(self.world * chunk_bytes, dtype=torch.uint8, device=self.dev)
             self.fill_chunks(staging, d_scalars, lens, chunk_bytes)
-            if self.world > 1:
-                dist.scatter(mine, [staging[r * chunk_bytes: (r + 1) * chunk_bytes] for r in range(self.world)], src=0, group=self.group)
-            else:
-                mine = staging
+            dist.scatter(mine, [staging[r * chunk_bytes: (r + 1) * chunk_bytes] for r in range(self.world)], src=0, group=self.group)
         else:
             dist.scatter(mine, None, src=0, group=self.group)
         part = self.local_commit(basis, mine, deal(lens, self.rank, self.world), lens)
-        if self.world > 1:
-            allp = torch.empty(self.world * len(lens) * nb, dtype=torch.uint8, device=self.dev)
-            dist.all_gather_into_tensor(allp, torch.frombuffer(bytearray(part), dtype=torch.uint8).to(self.dev), group=self.group)
-            raw = allp.cpu().numpy().tobytes()
-        else:
-            raw = part
+        allp = torch.empty(self.world * len(lens) * nb, dtype=torch.uint8, device=self.dev)
+        dist.all_gather_into_tensor(allp, torch.frombuffer(bytearray(part), dtype=torch.uint8).to(self.dev), group=self.group)
+        raw = allp.cpu().numpy().tobytes()
         self.batches += 1
         if self.rank != 0:
             return None
@@ -188,14 +216,15 @@ class SplitCommitter:
         return [g1_sum(cv, b"".join(raw[(r * k + c) * nb: (r * k + c + 1) * nb] for r in range(self.world))) for c in range(k)]
 
     def _header(self, basis: int, lens) -> List[int]:
+        if self.world == 1:
+            return [basis, len(lens)] + list(lens)
         torch, dist = self.torch, self.dist
         h = torch.zeros(8, dtype=torch.int64, device=self.dev)
         if self.rank == 0:
             h[0], h[1] = basis, len(lens)
             for i, n in enumerate(lens):
                 h[2 + i] = n
-        if self.world > 1:
-            dist.broadcast(h, src=0, group=self.group)
+        dist.broadcast(h, src=0, group=self.group)
         return [int(x) for x in h.cpu().tolist()]
 
     # -- leader
