@@ -133,7 +133,7 @@ class CurveBackend : public Backend {
         DevBuf scratch_in;  // upload staging for primitives
         DevBuf ntt_wide;    // NTT_MAX_BATCH transforms of 4n unsaturated-limb elements: the NTT's inter-pass form
         // MSM workspace
-        DevBuf counts, hist, offsets, unit_off, full_off, rem_rank, rem_list, scan_blk, sorted, partial, bucket_sum, rowcol, bit_partial, result, result_xyzz;
+        DevBuf counts, hist, offsets, unit_off, full_off, rem_rank, rem_list, scan_blk, sorted, partial, bucket_sum, rowcol, bit_partial, result, result_xyzz, done_count;
         void* h_pinned = nullptr;  // small pinned staging for results: [0,1024) affine, [1024,2048) XYZZ, [2048,4096) scalars
         uint32_t pending_pts = 0;  // MSM sums waiting in h_pinned for their affine conversion (sync_results)
         bool hook_pending = false; // a commitment batch handed to the context's commit hook at the next sync_results()
@@ -342,11 +342,12 @@ class CurveBackend : public Backend {
             const uint64_t upb = (entries / unit) / total_buckets + 1;  // unit partials per bucket (estimate)
             while ((1u << lanes_log) < MSM_COMBINE_LANES && (upb >> lanes_log) > 5) lanes_log++;
         }
-        msm_combine_kernel<FPP><<<cdiv((uint64_t)total_buckets << lanes_log, 256), 256, 0, st>>>(
-            ptr<PtU>(s.partial), ptr<uint32_t>(s.unit_off), total_buckets, lanes_log, ptr<PtU>(s.bucket_sum));
-        KCHK();
-        msm_combine_heavy_kernel<FPP><<<256, 256, 0, st>>>(ptr<PtU>(s.partial), ptr<uint32_t>(s.unit_off), total_buckets, ptr<PtU>(s.bucket_sum));
-        KCHK();
+        {   // light and heavy merge in one launch (the heavy blocks return at once when no bucket is skewed)
+            const uint32_t normal_blocks = cdiv((uint64_t)total_buckets << lanes_log, 256);
+            msm_combine_kernel<FPP><<<normal_blocks + MSM_HEAVY_BLOCKS, 256, 0, st>>>(
+                ptr<PtU>(s.partial), ptr<uint32_t>(s.unit_off), total_buckets, lanes_log, normal_blocks, ptr<PtU>(s.bucket_sum));
+            KCHK();
+        }
         // sum_k k*B_k: row/column sums of the bucket array, bit-wise weighted sums of those, final scaling + affine
         const int m_bits = c_ - 1, cols_log = m_bits - m_bits / 2;
         const uint32_t rows = 1u << (m_bits / 2), cols = 1u << cols_log;
@@ -368,18 +369,27 @@ class CurveBackend : public Backend {
         else
             msm_rowcol_kernel<FPP><<<dim3(rows + cols, a.batch), 256, 0, st>>>(ptr<PtU>(s.bucket_sum), NB_, rows, cols, ptr<PtU>(s.rowcol));
         KCHK();
-        if (quad & 2)
-            msm_bitsum_quad_kernel<FPP><<<dim3(nbits, 2, a.batch), 4 * lt, lt * sizeof(PtU), st>>>(ptr<PtU>(s.rowcol), rows, cols, ptr<PtU>(s.bit_partial));
-        else
-            msm_bitsum_kernel<FPP><<<dim3(nbits, 2, a.batch), 256, 0, st>>>(ptr<PtU>(s.rowcol), rows, cols, ptr<PtU>(s.bit_partial));
-        KCHK();
         // the sums leave the device in XYZZ form: the one field inversion of the affine conversion takes a lone GPU lane
         // ~100 us and the host a few; sync_results() finishes them into h_out (= the slot's pinned buffer)
-        if (quad & 4)
-            msm_final_quad_kernel<FPP><<<a.batch, 256, 0, st>>>(ptr<PtU>(s.bit_partial), nbits, cols_log, nullptr, ptr<Pt>(s.result_xyzz));
-        else
-            msm_final_kernel<FPP><<<a.batch, 64, 0, st>>>(ptr<PtU>(s.bit_partial), nbits, cols_log, nullptr, ptr<Pt>(s.result_xyzz));
-        KCHK();
+        if ((quad & 6) == 6) {
+            // bit sums + final scaling in ONE launch (the last workgroup to finish an MSM's bit sums runs its final phase)
+            const uint32_t threads = 4 * lt > 256 ? 4 * lt : 256;
+            const size_t lds = (size_t)(lt > 64 ? lt : 64) * sizeof(PtU);
+            msm_bitsum_final_quad_kernel<FPP><<<dim3(nbits, 2, a.batch), threads, lds, st>>>(
+                ptr<PtU>(s.rowcol), rows, cols, lt, ptr<PtU>(s.bit_partial), ptr<uint32_t>(s.done_count), cols_log, ptr<Pt>(s.result_xyzz));
+            KCHK();
+        } else {
+            if (quad & 2)
+                msm_bitsum_quad_kernel<FPP><<<dim3(nbits, 2, a.batch), 4 * lt, lt * sizeof(PtU), st>>>(ptr<PtU>(s.rowcol), rows, cols, ptr<PtU>(s.bit_partial));
+            else
+                msm_bitsum_kernel<FPP><<<dim3(nbits, 2, a.batch), 256, 0, st>>>(ptr<PtU>(s.rowcol), rows, cols, ptr<PtU>(s.bit_partial));
+            KCHK();
+            if (quad & 4)
+                msm_final_quad_kernel<FPP><<<a.batch, 256, 0, st>>>(ptr<PtU>(s.bit_partial), nbits, cols_log, nullptr, ptr<Pt>(s.result_xyzz));
+            else
+                msm_final_kernel<FPP><<<a.batch, 64, 0, st>>>(ptr<PtU>(s.bit_partial), nbits, cols_log, nullptr, ptr<Pt>(s.result_xyzz));
+            KCHK();
+        }
         if (stats_on_) HIPCHK(hipEventRecord(s.ev1, st));
         (void)h_out;
         HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(s.h_pinned) + 1024, s.result_xyzz.p, a.batch * sizeof(Pt), hipMemcpyDeviceToHost, st));
@@ -490,6 +500,8 @@ class CurveBackend : public Backend {
         CHK(s.bit_partial.alloc((size_t)batch * 2 * 32 * sizeof(PtU)));
         CHK(s.result.alloc(MSM_MAX_BATCH * sizeof(Aff)));
         CHK(s.result_xyzz.alloc(MSM_MAX_BATCH * sizeof(Pt)));
+        CHK(s.done_count.alloc(MSM_MAX_BATCH * sizeof(uint32_t)));
+        HIPCHK(hipMemset(s.done_count.p, 0, MSM_MAX_BATCH * sizeof(uint32_t)));
         return APK_OK;
     }
 

@@ -301,13 +301,25 @@ __device__ __forceinline__ PT shfl_down_point(const PT& p, int delta, int width)
     return r;
 }
 
-// merge a bucket's unit partials: MSM_COMBINE_LANES lanes per bucket, strided sums + shuffle tree
+// merge a bucket's unit partials: MSM_COMBINE_LANES lanes per bucket, strided sums + shuffle tree.
+// ONE launch does both cases: blocks [0, normal_blocks) run this light path, the MSM_HEAVY_BLOCKS blocks behind them the
+// whole-workgroup merge of skewed buckets (msm_combine_heavy_body below).
+constexpr uint32_t MSM_HEAVY_BLOCKS = 128;
+template <class FP>
+__device__ __forceinline__ void msm_combine_heavy_body(const XYZZ<FP, FeU<FP>>* __restrict__ partial, const uint32_t* __restrict__ unit_off,
+                                                       uint32_t total_buckets, XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum, uint32_t blk, uint32_t nblk);
+
 template <class FP>
 __global__ void __launch_bounds__(256) msm_combine_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ partial,
                                                           const uint32_t* __restrict__ unit_off, uint32_t total_buckets,
                                                           int lanes_log,  // lanes per bucket = 2^lanes_log <= MSM_COMBINE_LANES
+                                                          uint32_t normal_blocks,
                                                           XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum) {
     using PT = XYZZ<FP, FeU<FP>>;
+    if (blockIdx.x >= normal_blocks) {   // block-uniform
+        msm_combine_heavy_body<FP>(partial, unit_off, total_buckets, bucket_sum, blockIdx.x - normal_blocks, gridDim.x - normal_blocks);
+        return;
+    }
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t LANES = 1u << lanes_log;
     const uint32_t k = gid >> lanes_log;
@@ -334,14 +346,13 @@ __global__ void __launch_bounds__(256) msm_combine_kernel(const XYZZ<FP, FeU<FP>
 // of partials.  Each of the (few) blocks scans a slice of the bucket list and only does work for heavy buckets, so the launch
 // costs microseconds when there are none (uniform scalars never produce one).
 template <class FP>
-__global__ void __launch_bounds__(256) msm_combine_heavy_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ partial,
-                                                                const uint32_t* __restrict__ unit_off, uint32_t total_buckets,
-                                                                XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum) {
+__device__ __forceinline__ void msm_combine_heavy_body(const XYZZ<FP, FeU<FP>>* __restrict__ partial, const uint32_t* __restrict__ unit_off,
+                                                       uint32_t total_buckets, XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum, uint32_t blk, uint32_t nblk) {
     using PT = XYZZ<FP, FeU<FP>>;
     __shared__ PT sm[256];
     const uint32_t t = threadIdx.x;
-    const uint32_t per = (total_buckets + gridDim.x - 1) / gridDim.x;
-    const uint32_t k0 = blockIdx.x * per, k1 = min(k0 + per, total_buckets);
+    const uint32_t per = (total_buckets + nblk - 1) / nblk;
+    const uint32_t k0 = blk * per, k1 = min(k0 + per, total_buckets);
     // the common case has no heavy bucket at all: every thread looks at its own buckets first (one round of loads instead of
     // a serial walk over the slice), and the block only walks the slice if somebody saw one
     bool any = false;
@@ -523,6 +534,35 @@ __global__ void __launch_bounds__(512) msm_rowcol_quad_kernel(const XYZZ<FP, FeU
     if (t == 0 && q == 0) rc[(size_t)m * (rows + cols) + x] = acc;
 }
 
+// final phase as a device function: 64 quads (which, bit) scale their bit-sum by 2^bit (rows part by COLS as well), LDS tree,
+// conversion back to gnark's radix.  Needs the first 256 threads of the block (threads beyond idle) and 64 PT of LDS.
+template <class FP>
+__device__ __forceinline__ void msm_final_quad_body(const XYZZ<FP, FeU<FP>>* __restrict__ bit_partial, uint32_t nbits, int cols_log, uint32_t m,
+                                                    XYZZ<FP, FeU<FP>>* sm, XYZZ<FP>* __restrict__ result_xyzz) {
+    using PT = XYZZ<FP, FeU<FP>>;
+    const uint32_t t = threadIdx.x >> 2;
+    const int q = threadIdx.x & 3;
+    const bool live = threadIdx.x < 256;
+    const uint32_t which = t >> 5, bit = t & 31;
+    PT acc = PT::inf();
+    int dbl = 0;
+    if (live && bit < nbits) {
+        acc = bit_partial[((size_t)m * 2 + which) * 32 + bit];
+        dbl = (int)bit + (which == 0 ? cols_log : 0);
+    }
+    const int max_dbl = (int)nbits - 1 + cols_log;
+    for (int i = 0; i < max_dbl; i++) {
+        if (i < dbl && !acc.is_inf()) acc = PT::dbl_quad_general(acc, q);
+    }
+    if (live && q == 0) sm[t] = acc;
+    __syncthreads();
+    for (uint32_t d = 32; d >= 1; d >>= 1) {
+        if (live && t < d) { PT o = sm[t + d]; quad_tree_add(acc, o, q); if (q == 0) sm[t] = acc; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) result_xyzz[m] = to_fe_point<FP>(acc);   // back to gnark's Montgomery radix; affine conversion on the host
+}
+
 template <class FP>
 __global__ void __launch_bounds__(256) msm_final_quad_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ bit_partial, uint32_t nbits, int cols_log,
                                                              Affine<FP>* __restrict__ result, XYZZ<FP>* __restrict__ result_xyzz) {
@@ -553,6 +593,49 @@ __global__ void __launch_bounds__(256) msm_final_quad_kernel(const XYZZ<FP, FeU<
         if (result_xyzz) result_xyzz[m] = g;
         if (result) result[m] = g.to_affine();
     }
+}
+
+// Bit sums AND the final scaling in one launch: the workgroup that finishes the last of an MSM's 2 * nbits bit sums (an
+// agent-scope counter, reset by that workgroup for the next MSM) goes on to run the final phase - no spinning, so any number
+// of concurrent streams is safe.  `lt` logical threads (quads) do the bit sum; blockDim.x = max(4 * lt, 256); LDS holds
+// max(lt, 64) points.
+template <class FP>
+__global__ void __launch_bounds__(512) msm_bitsum_final_quad_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ rc, uint32_t rows, uint32_t cols,
+                                                                    uint32_t lt, XYZZ<FP, FeU<FP>>* __restrict__ bit_partial,
+                                                                    uint32_t* __restrict__ done_count, int cols_log,
+                                                                    XYZZ<FP>* __restrict__ result_xyzz) {
+    using PT = XYZZ<FP, FeU<FP>>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    PT* sm = reinterpret_cast<PT*>(smem_raw);
+    __shared__ uint32_t s_last;
+    const uint32_t bit = blockIdx.x, which = blockIdx.y, m = blockIdx.z, t = threadIdx.x >> 2, LT = lt;
+    const int q = threadIdx.x & 3;
+    const bool live = t < LT;
+    const PT* src = rc + (size_t)m * (rows + cols) + (which ? rows : 0);
+    const uint32_t count = which ? cols : rows;
+    PT acc = PT::inf();
+    if (live)
+        for (uint32_t i = t; i < count; i += LT) {
+            const uint32_t weight = which ? i + 1 : i;
+            if ((weight >> bit) & 1u) acc.add_lazy(src[i]);      // at most a couple per lane: the first is a copy
+        }
+    if (live && q == 0) sm[t] = acc;
+    __syncthreads();
+    for (uint32_t d = LT >> 1; d >= 1; d >>= 1) {
+        if (live && t < d) { PT o = sm[t + d]; quad_tree_add(acc, o, q); if (q == 0) sm[t] = acc; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        bit_partial[((size_t)m * 2 + which) * 32 + bit] = acc;
+        // release our bit sum, count it; the workgroup that sees the full count acquires everybody's
+        const uint32_t old = __hip_atomic_fetch_add(&done_count[m], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (old == 2 * gridDim.x - 1) ? 1u : 0u;
+        if (s_last) __hip_atomic_store(&done_count[m], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    msm_final_quad_body<FP>(bit_partial, gridDim.x, cols_log, m, sm, result_xyzz);
 }
 
 template <class FP>
