@@ -16,6 +16,7 @@
 // [UPSTREAM, not vendored; reached from /root/reference/algoplonk.go:89 via kzg.Commit].
 #pragma once
 #include "ff.h"
+#include "ffu_asm.h"
 
 template <class P>
 struct FeU {
@@ -121,6 +122,9 @@ struct FeU {
     // is below p + p*p/R' < 2p and is brought to [0, p) by one conditional subtraction (left out by mul_nr, see the
     // lazy forms below).
     APK_HD static FeU mul_nr(const FeU& a, const FeU& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (UMulAsm<P>::available) { FeU r; UMulAsm<P>::mul(r.l, a.l, b.l); return r; }   // one strict mad chain (ffu_asm.h)
+#endif
         uint32_t m[L];
         FeU r;
         uint64_t acc = 0;
@@ -150,6 +154,9 @@ struct FeU {
 
     // a*a/R': the off-diagonal partial products are taken once against 2a (L*(L+1)/2 mads instead of L*L)
     APK_HD static FeU sqr_nr(const FeU& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (UMulAsm<P>::available) { FeU r; UMulAsm<P>::sqr(r.l, a.l); return r; }
+#endif
         uint32_t m[L], d[L];
         FeU r;
 #pragma unroll

@@ -68,7 +68,7 @@ void run(const char* name, int waves_per_simd) {
 }
 
 int main() {
-    for (int w : {1, 4}) {
+    for (int w : {1, 2, 3, 4}) {
         run<0>("v_mad_u64_u32 x4 independent", w);
         run<1>("v_mad_u64_u32 dependent chain", w);
         run<2>("v_mov_b32", w);
