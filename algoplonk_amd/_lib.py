@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libapk.so")
+# APK_LIB: another build of the same ABI (A/B measurements: tools/ab_bench.sh); default = the in-tree build
+LIB_PATH = os.environ.get("APK_LIB") or os.path.join(_HERE, "libapk.so")
 
 APK_BN254 = 0
 APK_BLS12_381 = 1
