@@ -538,14 +538,19 @@ class CurveBackend : public Backend {
         return APK_OK;
     }
 
-    int choose_window(int requested, int log_size) {
+    int choose_window(int requested, int log_size, int slots = 1) {
         c_ = requested;
         if (c_ == 0) {
             c_ = env_int("APK_MSM_WINDOW", 0, 0, 16);
             if (c_ != 0 && c_ < 7) c_ = 7;
         }
-        // measured flat between log2(n)-4 and log2(n)-2 (tools/sweep.sh); 16 only pays from 2^21 up (128 KiB LDS histograms)
-        if (c_ == 0) { c_ = log_size - 2; if (c_ < 8) c_ = 8; if (c_ > 15) c_ = 15; if (log_size >= 21) c_ = 16; }
+        // measured flat between log2(n)-4 and log2(n)-2 (tools/sweep.sh).  c = 16 (128 KiB LDS histograms, 16 windows instead of
+        // 17) pays from 2^21 up on any context, and from 2^17 up on throughput contexts: at 2^17 with 16 slots +1.4 % proofs/s
+        // for +1.5 % latency (tools/ab_args.sh, same box, interleaved: 429 against 423 proofs/s; c = 14: 403)
+        if (c_ == 0) {
+            c_ = log_size - 2; if (c_ < 8) c_ = 8; if (c_ > 15) c_ = 15;
+            if (log_size >= 21 || (log_size >= 17 && slots > 2)) c_ = 16;
+        }
         if (c_ < 7 || c_ > 16) { set_error("msm_window %d out of [7,16]", c_); return APK_ERR_ARG; }
         W_ = (FRP::BITS + 1 + c_ - 1) / c_;
         NB_ = 1u << (c_ - 1);
@@ -622,7 +627,7 @@ class CurveBackend : public Backend {
             if ((uint64_t)nb_public_ + cci_[k] >= n_) { set_error("commitment_constraint_index[%u] = %u: row %llu is outside the domain (n = %u)", k, cci_[k], (unsigned long long)nb_public_ + cci_[k], n_); return APK_ERR_ARG; }
         }
         msm_bases_ = n_ + 3;
-        CHK(choose_window(d->msm_window, (int)log_n_));
+        CHK(choose_window(d->msm_window, (int)log_n_, d->slots));
         // domain constants on the host (gnark fft.NewDomain [UPSTREAM]; generator = VK Generator,
         // templateLogicSigBN254.go:57; shift = VK CosetShift :68)
         Fr root = root_of_unity();

@@ -326,7 +326,11 @@ def launcher_selftest(args) -> None:
 
 
 def window_bits(args) -> int:
-    return args.msm_window or (16 if args.log_n >= 21 else min(15, max(8, args.log_n - 2)))
+    """the library's default (backend_impl.h choose_window): 16 from 2^21 up, and from 2^17 up on contexts with more than 2 slots"""
+    if args.msm_window:
+        return args.msm_window
+    throughput = args.mode == "prove" and args.inflight > 2
+    return 16 if args.log_n >= 21 or (args.log_n >= 17 and throughput) else min(15, max(8, args.log_n - 2))
 
 
 def roofline_from_stats(args, cv, st, pmc):
@@ -445,7 +449,7 @@ def bench_prove(args, cv, rk) -> None:
     cpu_baseline = None
     if rk.rank == 0 and rk.world == 1:
         if not args.no_pmc and not args.bsb22:
-            pmc = pmc_traffic(args.curve, args.log_n, args.msm_window)
+            pmc = pmc_traffic(args.curve, args.log_n, window_bits(args))
         if not args.no_cpu_baseline and not args.bsb22:
             probe = go_probe()
             cpu_baseline = gnark_cpu_baseline(probe, args.curve, args.log_n, args.cpu_baseline_seconds)
@@ -521,7 +525,7 @@ def bench_sharded_msm(args, cv, rk) -> None:
     cpu_baseline = None
     if rk.rank == 0 and rk.world == 1:
         if not args.no_pmc:
-            pmc = pmc_traffic(args.curve, args.log_n, args.msm_window)
+            pmc = pmc_traffic(args.curve, args.log_n, window_bits(args))
         if not args.no_cpu_baseline:
             from bench_cpu import cpu_baseline_msm
             cpu_baseline = cpu_baseline_msm(cv, bases, scalars, n, args.cpu_baseline_seconds)

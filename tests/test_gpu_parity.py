@@ -576,3 +576,29 @@ def test_commit_hook_and_ranged_batch_msm(gpu, cname):
     assert MarshalProof(ap_plonk.Prove(ccs2, pk2, w2, bl2, hiding=[(3, 4)])) == plain2 and split2.batches == 5
     split2.stop()
     pk2.close()
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12-381"])
+@pytest.mark.parametrize("nb_public", [0, 1, 7, 40])
+def test_prove_with_few_and_many_public_inputs(gpu, cname, nb_public):
+    """Edge cases of the public-input handling: none, one (the reference's identity circuit, compile_test.go:13-20), more rows
+    than the quotient kernel's direct Qk completion takes (falls back to iNTT + coset NTT of the completed column), and
+    enough of them that PI(zeta) - the host-side sum behind lin(zeta) - has many Lagrange terms.  Byte-identical to the oracle."""
+    cv, ov = CURVES[cname]
+    ccs, w, sol = random_chain_ccs(cv, 6, 0xA190 + nb_public, nb_public=nb_public)
+    assert ccs.GetNbPublicVariables() == nb_public
+    pk, vk, opk, srs = _setup_pair(cv, ov, ccs, 77, gpu)
+    bl = blinding(cv, 3)
+    proof = ap_plonk.Prove(ccs, pk, w, bl)
+    blob, pib = MarshalProof(proof), MarshalPublicInputs(w)
+    oc = oracle_circuit_from_ccs(ov, ccs)
+    L, R, O = oplonk.solve_lro(oc, sol)
+    want = oplonk.marshal_proof(ov, oplonk.prove(opk, L, R, O, w.public, bl))
+    assert blob == want and len(pib) == 32 * nb_public
+    assert oplonk.verify(oracle_vk_from_product(ov, vk), blob, pib)
+    ap_plonk.Verify(proof, vk, w)                                      # the library's own verifier agrees
+    if nb_public:
+        bad = frontend.Witness(w.field, [(w.public[0] + 1) % cv.r] + w.public[1:], w.secret)
+        with pytest.raises(ap_plonk.VerificationError):
+            ap_plonk.Verify(proof, vk, bad)
+    pk.close()
