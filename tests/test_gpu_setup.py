@@ -129,3 +129,40 @@ def test_real_ethereum_srs_2p14_matches_c_oracle(gpu):
     check(lib.apk_msm_g1(ctx2, 0, cv.fr_vector(coeffs), n, out2))
     lib.apk_ctx_destroy(ctx2)
     assert out.raw == out2.raw and any(out.raw)
+
+
+def test_decompress_rejects_what_gnark_rejects(gpu):
+    """kzg SRS ReadFrom -> G1Affine.SetBytes [UPSTREAM] also checks subgroup membership and a clean infinity encoding
+    (ADVICE r01): a curve point outside G1 (BLS12-381 has a cofactor), an infinity flag with a payload, x >= p and a
+    non-residue x are all refused; the ceremony's own points and a clean infinity are accepted."""
+    cv, ov = CURVES["bls12-381"]
+    p = cv.p
+    x = 5
+    while True:                                   # a point of E(Fp) that is NOT in the order-r subgroup
+        rhs = (x * x * x + 4) % p
+        y = pow(rhs, (p + 1) // 4, p)
+        if y * y % p == rhs and ov.mul((x, y), cv.r) is not None:
+            break
+        x += 1
+    from algoplonk_amd import serialize as ser
+    good = ser.compress_g1(cv, ov.mul(ov.g1, 12345))
+    off_subgroup = ser.compress_g1(cv, (x, y))
+    inf_ok = ser.compress_g1(cv, None)
+    inf_payload = bytes([0xC0]) + bytes(46) + b"\x01"
+    too_big = bytes([0x9F]) + b"\xff" * 47                              # x >= p
+    x2 = 5
+    while pow((x2 ** 3 + 4) % p, (p - 1) // 2, p) == 1:
+        x2 += 1
+    not_on_curve = bytes([0x80 | (x2.to_bytes(48, "big")[0])]) + x2.to_bytes(48, "big")[1:]
+    out = C.create_string_buffer(2 * 96)
+    check(lib.apk_g1_decompress(cv.abi, gpu, good + inf_ok, 2, out))
+    assert cv.g1_vector_decode(out.raw) == [ov.mul(ov.g1, 12345), None]
+    for bad in (off_subgroup, inf_payload, too_big, not_on_curve):
+        assert lib.apk_g1_decompress(cv.abi, gpu, good + bad, 2, out) == _lib.APK_ERR_ARG, bad.hex()
+    # BN254 has cofactor 1: every curve point is in G1; flags 00 are not a compressed encoding
+    cb, ob = CURVES["bn254"]
+    okb = ser.compress_g1(cb, ob.mul(ob.g1, 777))
+    out = C.create_string_buffer(64)
+    check(lib.apk_g1_decompress(cb.abi, gpu, okb, 1, out))
+    assert cb.g1_from_bytes(out.raw) == ob.mul(ob.g1, 777)
+    assert lib.apk_g1_decompress(cb.abi, gpu, bytes([okb[0] & 0x3F]) + okb[1:], 1, out) == _lib.APK_ERR_ARG
