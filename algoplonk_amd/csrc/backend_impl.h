@@ -301,11 +301,13 @@ class CurveBackend : public Backend {
         if (stats_on_) HIPCHK(hipEventRecord(s.ev0, st));
         // counting sort by bucket: LDS-private histograms per scalar slice, column scan, bucket scan, scatter
         static const uint32_t slice = (uint32_t)env_int("APK_MSM_SLICE", 2048, 64, 1 << 20);  // scalars per sort workgroup
-        uint32_t G = cdiv(maxlen, slice ? slice : 2048u);
+        // packed 16-bit counters: a slice must stay below 2^16 entries per bucket even when every digit of every scalar agrees
+        const uint32_t slice_eff = NB_ >= MSM_PACKED_NB && slice > 3072u ? 3072u : slice;
+        uint32_t G = cdiv(maxlen, slice_eff ? slice_eff : 2048u);
         if (G < 1) G = 1;
         if (G > msm_G_max_) G = msm_G_max_;
         dim3 gd(G, a.batch);
-        const size_t lds = (size_t)NB_ * 4;
+        const size_t lds = digits_lds_bytes();
         static const int dth = env_int("APK_MSM_DIGITS_THREADS", MSM_DIGITS_THREADS, 64, MSM_DIGITS_THREADS) & ~63;   // whole waves, <= the launch bound
         msm_digits_kernel<FRP, false><<<gd, dth, lds, st>>>(a, win_, NB_, T.n_bases, G, ptr<uint32_t>(s.counts), nullptr, nullptr);
         KCHK();
@@ -538,10 +540,13 @@ class CurveBackend : public Backend {
         return APK_OK;
     }
 
+    // LDS of the sort kernels: 32-bit counters, or packed 16-bit pairs from 2^16 buckets (c = 17)
+    size_t digits_lds_bytes() const { return NB_ >= MSM_PACKED_NB ? (size_t)NB_ * 2 : (size_t)NB_ * 4; }
+
     int choose_window(int requested, int log_size, int slots = 1) {
         c_ = requested;
         if (c_ == 0) {
-            c_ = env_int("APK_MSM_WINDOW", 0, 0, 16);
+            c_ = env_int("APK_MSM_WINDOW", 0, 0, 17);
             if (c_ != 0 && c_ < 7) c_ = 7;
         }
         // measured flat between log2(n)-4 and log2(n)-2 (tools/sweep.sh).  c = 16 (128 KiB LDS histograms, 16 windows instead of
@@ -551,7 +556,9 @@ class CurveBackend : public Backend {
             c_ = log_size - 2; if (c_ < 8) c_ = 8; if (c_ > 15) c_ = 15;
             if (log_size >= 21 || (log_size >= 17 && slots > 2)) c_ = 16;
         }
-        if (c_ < 7 || c_ > 16) { set_error("msm_window %d out of [7,16]", c_); return APK_ERR_ARG; }
+        if (c_ < 7 || c_ > 17) { set_error("msm_window %d out of [7,17]", c_); return APK_ERR_ARG; }
+        // c = 17 counts in packed 16-bit halves: a sort slice (at most msm_G_max_ of them) must stay below 2^16 entries
+        if (c_ == 17 && (uint64_t)msm_bases_ > (uint64_t)msm_G_max_ * 3072u) { set_error("msm_window 17 supports at most %u bases", msm_G_max_ * 3072u); return APK_ERR_ARG; }
         W_ = (FRP::BITS + 1 + c_ - 1) / c_;
         NB_ = 1u << (c_ - 1);
         {   // spread the BITS+1 bits over W_ windows of width c_ or c_-1
@@ -587,9 +594,9 @@ class CurveBackend : public Backend {
         int lg = 0;
         while ((1ull << lg) < count) lg++;
         CHK(choose_window(msm_window, lg));
-        if ((size_t)NB_ * 4 > 65536) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, NB_ * 4));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NB_ * 4));
+        if (digits_lds_bytes() > 65536) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)digits_lds_bytes()));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)digits_lds_bytes()));
         }
         DevBuf srs;
         CHK(srs.alloc(count * sizeof(Aff)));
@@ -684,9 +691,9 @@ class CurveBackend : public Backend {
         }
         HIPCHK(hipDeviceSynchronize());
         srs.release();
-        if ((size_t)NB_ * 4 > 65536) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, NB_ * 4));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, NB_ * 4));
+        if (digits_lds_bytes() > 65536) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)digits_lds_bytes()));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)digits_lds_bytes()));
         }
         // proving slots
         int nslots = d->slots > 0 ? d->slots : 1;

@@ -55,6 +55,11 @@ struct MsmBatchArgs {
 //   SCATTER = false : counts[(b*G + g)*nb + k] = entries of slice g of msm b that fall into bucket k
 //   SCATTER = true  : LDS cursors start at offsets[b*nb+k] + (exclusive prefix of counts over g); every entry takes
 //                     the next slot of its bucket with an LDS atomic and is written to `sorted`
+// c = 17 (2^16 buckets) does not fit 32-bit counters into the 160 KB of LDS: from MSM_PACKED_NB buckets up two 16-bit counters
+// share a word (a slice holds <= 4096 scalars x 17 windows < 2^16 entries, so a half never overflows into its neighbour);
+// the scatter pass then keeps only the entry's RANK inside (slice, bucket) in LDS and adds the two bases - the bucket's global
+// offset and the slice's prefix inside the bucket - from global memory (both L2 resident).
+constexpr uint32_t MSM_PACKED_NB = 65536;
 constexpr int MSM_DIGITS_THREADS = 1024;  // per sort workgroup: the slice's LDS atomics and scattered stores are latency-bound
 template <class FR, bool SCATTER>
 __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_digits_kernel(MsmBatchArgs a, MsmWindows win, uint32_t nb, uint32_t n_max, uint32_t G,
@@ -66,7 +71,9 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_digits_kernel(MsmBatch
     uint32_t* lds = reinterpret_cast<uint32_t*>(smem_raw);
     const uint32_t g = blockIdx.x, b = blockIdx.y;
     uint32_t* row = counts + ((size_t)b * G + g) * nb;
-    for (uint32_t k = threadIdx.x; k < nb; k += blockDim.x) lds[k] = SCATTER ? offsets[b * nb + k] + row[k] : 0u;
+    const bool packed = nb >= MSM_PACKED_NB;   // uniform
+    if (packed) { for (uint32_t k = threadIdx.x; k < nb / 2; k += blockDim.x) lds[k] = 0u; }
+    else { for (uint32_t k = threadIdx.x; k < nb; k += blockDim.x) lds[k] = SCATTER ? offsets[b * nb + k] + row[k] : 0u; }
     __syncthreads();
     const uint32_t len = a.len[b];
     const uint32_t per = (len + G - 1) / G;
@@ -94,10 +101,18 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_digits_kernel(MsmBatch
                 if (d > half) { d = (1u << c) - d; neg = 1; carry = 1; }  // d in (half, 2^c] -> -(2^c - d)
                 else carry = 0;
                 if (d != 0) {  // d == 0 also covers the d == 2^c case (digit 0, carry 1)
-                    if (!SCATTER) {
-                        atomicAdd(&lds[d - 1], 1u);
+                    const uint32_t k = d - 1;
+                    if (packed) {
+                        const uint32_t sh = (k & 1u) * 16u;
+                        const uint32_t old = atomicAdd(&lds[k >> 1], 1u << sh);
+                        if (SCATTER) {
+                            const uint32_t pos = offsets[b * nb + k] + row[k] + ((old >> sh) & 0xffffu);
+                            sorted[pos] = ((uint32_t)j * n_max + base_idx) | (neg << 31);
+                        }
+                    } else if (!SCATTER) {
+                        atomicAdd(&lds[k], 1u);
                     } else {
-                        uint32_t pos = atomicAdd(&lds[d - 1], 1u);
+                        uint32_t pos = atomicAdd(&lds[k], 1u);
                         sorted[pos] = ((uint32_t)j * n_max + base_idx) | (neg << 31);
                     }
                 }
@@ -107,7 +122,8 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_digits_kernel(MsmBatch
     }
     if (!SCATTER) {
         __syncthreads();
-        for (uint32_t k = threadIdx.x; k < nb; k += blockDim.x) row[k] = lds[k];
+        if (packed) { for (uint32_t k = threadIdx.x; k < nb; k += blockDim.x) row[k] = (lds[k >> 1] >> ((k & 1u) * 16u)) & 0xffffu; }
+        else { for (uint32_t k = threadIdx.x; k < nb; k += blockDim.x) row[k] = lds[k]; }
     }
 }
 
@@ -147,7 +163,7 @@ __global__ void __launch_bounds__(256) msm_colscan_kernel(uint32_t* __restrict__
 // Three small launches (a single block took 58 us for 49 k buckets): 1024 counters per block -> block totals -> one block
 // scans the totals -> blocks add their base.
 constexpr int MSM_SCAN_BLOCK = 1024;
-constexpr int MSM_SCAN_MAX_BLOCKS = 128;   // MSM_MAX_BATCH * 2^15 buckets / MSM_SCAN_BLOCK
+constexpr int MSM_SCAN_MAX_BLOCKS = 256;   // MSM_MAX_BATCH * 2^16 buckets / MSM_SCAN_BLOCK
 
 template <int DUMMY>
 __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_local_kernel(const uint32_t* __restrict__ hist, uint32_t total, uint32_t unit,
@@ -190,20 +206,16 @@ __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_totals_kernel(uint32_
     __shared__ uint32_t s_unit[MSM_SCAN_BLOCK];
     __shared__ uint32_t s_full[MSM_SCAN_BLOCK];
     __shared__ uint32_t s_bintot[MSM_UNIT_MAX];
-    __shared__ uint32_t s_bins[MSM_SCAN_MAX_BLOCKS * MSM_UNIT_MAX];   // the per-block remainder histograms, scanned in LDS
+    __shared__ uint16_t s_bins[MSM_SCAN_MAX_BLOCKS * MSM_UNIT_MAX];   // per-block remainder histograms (<= 1024 each): 32 KB
     const uint32_t t = threadIdx.x;
     const uint32_t h = t < nblocks ? block_tot[t] : 0u, hu = t < nblocks ? block_tot[nblocks + t] : 0u,
                    hf = t < nblocks ? block_tot[2 * nblocks + t] : 0u;
     s_cnt[t] = h; s_unit[t] = hu; s_full[t] = hf;
-    for (uint32_t i = t; i < nblocks * MSM_UNIT_MAX; i += MSM_SCAN_BLOCK) s_bins[i] = block_bins[i];
+    for (uint32_t i = t; i < nblocks * MSM_UNIT_MAX; i += MSM_SCAN_BLOCK) s_bins[i] = (uint16_t)block_bins[i];
     __syncthreads();
-    if (t < MSM_UNIT_MAX) {   // per remainder length: exclusive prefix over the blocks
+    if (t < MSM_UNIT_MAX) {   // per remainder length: the total over the blocks
         uint32_t run = 0;
-        for (uint32_t blk = 0; blk < nblocks; blk++) {
-            const uint32_t v = s_bins[blk * MSM_UNIT_MAX + t];
-            s_bins[blk * MSM_UNIT_MAX + t] = run;
-            run += v;
-        }
+        for (uint32_t blk = 0; blk < nblocks; blk++) run += s_bins[blk * MSM_UNIT_MAX + t];
         s_bintot[t] = run;
     }
     __syncthreads();
@@ -216,14 +228,15 @@ __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_totals_kernel(uint32_
     }
     if (t < nblocks) { block_tot[t] = s_cnt[t] - h; block_tot[nblocks + t] = s_unit[t] - hu; block_tot[2 * nblocks + t] = s_full[t] - hf; }
     if (t == MSM_SCAN_BLOCK - 1) { offsets[total] = s_cnt[t]; unit_off[total] = s_unit[t]; full_off[total] = s_full[t]; }
-    __shared__ uint32_t s_base[MSM_UNIT_MAX];
-    if (t < MSM_UNIT_MAX) {   // longest remainders first
-        uint32_t base = 0;
-        for (uint32_t r = MSM_UNIT_MAX - 1; r > t; r--) base += s_bintot[r];
-        s_base[t] = base;
+    if (t < MSM_UNIT_MAX) {   // longest remainders first: base of length t, then the exclusive prefix over the blocks
+        uint32_t run = 0;
+        for (uint32_t r = MSM_UNIT_MAX - 1; r > t; r--) run += s_bintot[r];
+        for (uint32_t blk = 0; blk < nblocks; blk++) {
+            const uint32_t v = s_bins[blk * MSM_UNIT_MAX + t];
+            block_bins[blk * MSM_UNIT_MAX + t] = run;
+            run += v;
+        }
     }
-    __syncthreads();
-    for (uint32_t i = t; i < nblocks * MSM_UNIT_MAX; i += MSM_SCAN_BLOCK) block_bins[i] = s_bins[i] + s_base[i % MSM_UNIT_MAX];
 }
 
 template <int DUMMY>

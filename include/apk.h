@@ -84,7 +84,7 @@ typedef struct {
     const int64_t* perm;       /* 3n entries = gnark Trace.S */
     const void* qcp[APK_MAX_COMMITMENTS];               /* n Fr each */
     uint32_t commitment_constraint_index[APK_MAX_COMMITMENTS]; /* VK CommitmentConstraintIndexes */
-    int msm_window;            /* signed-digit window bits; 0 = choose from n */
+    int msm_window;            /* signed-digit window bits (7..17); 0 = choose from n and slots */
     int slots;                 /* concurrent proofs in flight on this context; 0 = 1; capped at 16 (more callers wait their turn) */
 } apk_circuit_desc;
 

@@ -153,7 +153,7 @@ def test_unsatisfied_witness_is_an_error_not_a_proof(gpu, cname):
     pk.close()
 
 
-@pytest.mark.parametrize("cname,window", [("bn254", 7), ("bn254", 9), ("bn254", 12), ("bn254", 16), ("bls12-381", 8), ("bls12-381", 13)])
+@pytest.mark.parametrize("cname,window", [("bn254", 7), ("bn254", 9), ("bn254", 12), ("bn254", 16), ("bn254", 17), ("bls12-381", 8), ("bls12-381", 13), ("bls12-381", 17)])
 def test_msm_window_sizes_and_skewed_scalars(gpu, cname, window):
     """Every window width gives the same group element; skewed inputs (all ones, two distinct values, tiny values)
     stress the bucket work-unit split (full units, sorted remainder units, heavy buckets)."""
@@ -166,6 +166,11 @@ def test_msm_window_sizes_and_skewed_scalars(gpu, cname, window):
              [g.below(1 << 16) for _ in range(n)], [0] * 5 + [g.fr(cv.r)], [1 << 253] * 3]
     for sc in cases:
         assert pk.msm(sc) == ov.mul(ov.g1, oplonk.poly_eval(sc, srs.tau, cv.r))
+    if window >= 16:   # a whole proof through the wide-window sort (c = 17: packed 16-bit LDS counters), batches of 3 included
+        bl = blinding(cv, 8)
+        oc = oracle_circuit_from_ccs(ov, ccs)
+        L, R, O = oplonk.solve_lro(oc, sol)
+        assert MarshalProof(ap_plonk.Prove(ccs, pk, w, bl)) == oplonk.marshal_proof(ov, oplonk.prove(opk, L, R, O, w.public, bl))
     pk.close()
 
 
