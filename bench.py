@@ -354,6 +354,13 @@ def roofline_from_stats(args, cv, st, pmc):
         windows = (cv.r.bit_length() + 1 + c - 1) // c
         adds_per_s = pairs_per_launch * windows / (acc_avg_ms * 1e-3)
         roofline["valu"] = {"bucket_additions_per_s": round(adds_per_s / 1e9, 3), "unit": "G additions/s", "windows": windows}
+        if cv.name == "bn254":
+            # the kernel's real ceiling: VALU issue.  2 012 VALU instructions per bucket addition and lane (SQ_INSTS_VALU over the
+            # additions of profiles/r02_pmc_msm_accumulate.json) at 2.03 ns per wave instruction and SIMD (tools/ubench/valu_rates.hip,
+            # v_mad_u64_u32 with 4 waves per SIMD) on 1024 SIMDs x 64 lanes
+            bound = 1024 * 64 / (2012 * 2.03e-9)
+            roofline["valu"].update({"issue_bound": round(bound / 1e9, 3), "frac": round(adds_per_s / bound, 4),
+                                     "basis": "2012 VALU instructions per addition (PMC) x 2.03 ns per wave instruction per SIMD (ubench)"})
         if pmc:
             roofline["hbm_traffic_frac"] = round(pmc["hbm_bytes_per_pair"] * pairs_per_launch / (acc_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     return roofline
