@@ -115,6 +115,12 @@ class CurveBackend : public Backend {
         uint32_t n_bases = 0;
         bool built = false;
     };
+    // APK_MSM_GRAPH=1: the launch sequence of an MSM batch (10 kernels + the result copy) is captured once per (slot, table,
+    // scalar vectors, lengths) into a hipGraph and replayed with one hipGraphLaunch.
+    struct GraphKey {
+        const void* table; MsmBatchArgs a;
+        bool operator==(const GraphKey& o) const { return table == o.table && memcmp(&a, &o.a, sizeof a) == 0; }
+    };
     struct Slot {
         hipStream_t stream = nullptr;
         hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
@@ -136,6 +142,7 @@ class CurveBackend : public Backend {
         DevBuf counts, hist, offsets, unit_off, full_off, rem_rank, rem_list, scan_blk, sorted, partial, bucket_sum, rowcol, bit_partial, result, result_xyzz, done_count;
         void* h_pinned = nullptr;  // small pinned staging for results: [0,1024) affine, [1024,2048) XYZZ, [2048,4096) scalars
         uint32_t pending_pts = 0;  // MSM sums waiting in h_pinned for their affine conversion (sync_results)
+        std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;   // APK_MSM_GRAPH
         bool hook_pending = false; // a commitment batch handed to the context's commit hook at the next sync_results()
         int hook_basis = 0;
         MsmBatchArgs hook_args{};
@@ -188,6 +195,7 @@ class CurveBackend : public Backend {
         (void)hipSetDevice(device_);
         for (Slot* s : slots_) {
             if (s->stream) (void)hipStreamSynchronize(s->stream);
+            for (auto& e : s->graphs) (void)hipGraphExecDestroy(e.second);
             if (s->ev0) (void)hipEventDestroy(s->ev0);
             if (s->ev1) (void)hipEventDestroy(s->ev1);
             if (s->ev2) (void)hipEventDestroy(s->ev2);
@@ -270,8 +278,31 @@ class CurveBackend : public Backend {
         return APK_OK;
     }
 
-    // results land in slot.result (device) and are copied to h_out (host, batch points) - caller syncs the stream
     int run_msm(Slot& s, const MsmTables& T, const MsmBatchArgs& a, Aff* h_out) {
+        static const int graphs = env_int("APK_MSM_GRAPH", 0, 0, 1);
+        if (!graphs || stats_on_) return run_msm_body(s, T, a, h_out);
+        GraphKey key{};
+        key.table = T.table.p; key.a = a;
+        for (uint32_t b = a.batch; b < MSM_MAX_BATCH; b++) { key.a.scalars[b] = nullptr; key.a.len[b] = 0; key.a.offset[b] = 0; }
+        for (auto& e : s.graphs)
+            if (e.first == key) { HIPCHK(hipGraphLaunch(e.second, s.stream)); s.pending_pts = a.batch; return APK_OK; }
+        hipGraph_t g = nullptr;
+        HIPCHK(hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal));
+        const int rc = run_msm_body(s, T, a, h_out);
+        const hipError_t e = hipStreamEndCapture(s.stream, &g);
+        if (rc != APK_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+        HIPCHK(e);
+        hipGraphExec_t exec = nullptr;
+        HIPCHK(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(g);
+        s.graphs.emplace_back(key, exec);
+        HIPCHK(hipGraphLaunch(exec, s.stream));
+        s.pending_pts = a.batch;
+        return APK_OK;
+    }
+
+    // results land in slot.result (device) and are copied to h_out (host, batch points) - caller syncs the stream
+    int run_msm_body(Slot& s, const MsmTables& T, const MsmBatchArgs& a, Aff* h_out) {
         hipStream_t st = s.stream;
         uint32_t maxlen = 0;
         uint64_t entries = 0;
