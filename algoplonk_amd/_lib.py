@@ -16,7 +16,7 @@ APK_BN254 = 0
 APK_BLS12_381 = 1
 APK_OK = 0
 APK_ERR_ARG, APK_ERR_HIP, APK_ERR_STATE, APK_ERR_WITNESS, APK_ERR_VERIFY = 1, 2, 3, 4, 5
-ABI_VERSION = 2
+ABI_VERSION = 3
 G1_MAX = 96
 G2_MAX = 192
 MAX_COMMITMENTS = 2
@@ -26,7 +26,7 @@ NB_BLINDING = 9
 SYMBOLS = [
     "apk_last_error", "apk_abi_version", "apk_device_count", "apk_g1_bytes", "apk_fp_bytes",
     "apk_ctx_create", "apk_ctx_destroy", "apk_msm_ctx_create", "apk_ctx_get_vk", "apk_msm_g1", "apk_msm_g1_device", "apk_msm_g1_batch_device", "apk_ctx_set_commit_hook", "apk_device_copy", "apk_ntt",
-    "apk_prove", "apk_prove_device", "apk_verify", "apk_g2_decompress", "apk_g2_mul_generator", "apk_g1_mul_batch", "apk_g1_decompress", "apk_g1_to_lagrange", "apk_marshal_proof", "apk_marshal_public_inputs",
+    "apk_prove", "apk_prove_device", "apk_verify", "apk_verify_ex", "apk_g2_decompress", "apk_g2_mul_generator", "apk_g1_mul_batch", "apk_g1_decompress", "apk_g1_to_lagrange", "apk_marshal_proof", "apk_marshal_public_inputs",
     "apk_fe_from_be", "apk_fe_to_be", "apk_hash_fr", "apk_host_fe_op", "apk_host_g1_op", "apk_g1_sum",
     "apk_device_alloc", "apk_device_free", "apk_device_upload", "apk_device_download",
     "apk_stats_enable", "apk_stats_read",
@@ -79,11 +79,19 @@ class VerifyingKey(C.Structure):
     ]
 
 
+class VerifyTrace(C.Structure):
+    _fields_ = [
+        ("gamma", C.c_uint8 * 32), ("beta", C.c_uint8 * 32), ("alpha", C.c_uint8 * 32), ("zeta", C.c_uint8 * 32),
+        ("pi", C.c_uint8 * 32), ("lin_at_zeta", C.c_uint8 * 32), ("gamma_kzg", C.c_uint8 * 32), ("folded_claim", C.c_uint8 * 32),
+        ("lin_commitment", C.c_uint8 * G1_MAX), ("folded_digest", C.c_uint8 * G1_MAX),
+    ]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("msm_accumulate_ms", C.c_double), ("msm_accumulate_launches", C.c_uint64), ("msm_pairs", C.c_uint64),
         ("msm_total_ms", C.c_double), ("msm_batches", C.c_uint64), ("ntt_ms", C.c_double), ("ntt_elements", C.c_uint64),
-        ("prove_ms", C.c_double), ("proofs", C.c_uint64),
+        ("prove_ms", C.c_double), ("proofs", C.c_uint64), ("round_ms", C.c_double * 4), ("host_lincomb_ms", C.c_double),
     ]
 
 
@@ -116,6 +124,7 @@ def _load() -> C.CDLL:
     lib.apk_prove.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(Proof)]
     lib.apk_prove_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.POINTER(Proof)]
     lib.apk_verify.argtypes = [C.POINTER(VerifyingKey), C.POINTER(Proof), vp]
+    lib.apk_verify_ex.argtypes = [C.POINTER(VerifyingKey), C.POINTER(Proof), vp, C.c_uint32, C.POINTER(VerifyTrace)]
     lib.apk_g2_decompress.argtypes = [i32, vp, vp]
     lib.apk_g2_mul_generator.argtypes = [i32, vp, vp]
     lib.apk_g1_mul_batch.argtypes = [i32, i32, vp, vp, u64, vp]

@@ -89,12 +89,13 @@ int host_fe_from_be(int curve, int field, const uint8_t* be, void* out) {
     return APK_ERR_ARG;
 }
 
-// gnark RawBytes(): X||Y big-endian, infinity -> 0x40 then zeros (helper.go:35-72; verifier/verifier.go:95-99)
+// gnark RawBytes(): X||Y big-endian; infinity -> 0x40 then zeros on BLS12-381 (helper.go:35-72; verifier/verifier.go:95-99),
+// all zeros on BN254 (the only encoding the BN254 template's ec ops take: templateLogicSigBN254.go:57-61)
 static void g1_raw(int curve, const uint8_t* slot, uint8_t* out) {
     const size_t fpb = apk_fp_bytes(curve);
     bool inf = true;
     for (size_t i = 0; i < 2 * fpb; i++) if (slot[i]) { inf = false; break; }
-    if (inf) { memset(out, 0, 2 * fpb); out[0] = 0x40; return; }
+    if (inf) { memset(out, 0, 2 * fpb); if (fpb == 48) out[0] = 0x40; return; }
     host_fe_to_be(curve, 1, slot, out);
     host_fe_to_be(curve, 1, slot + fpb, out + fpb);
 }

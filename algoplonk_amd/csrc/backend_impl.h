@@ -98,11 +98,14 @@ class CurveBackend : public Backend {
             p[0] = (uint8_t)(c.l[i] >> 24); p[1] = (uint8_t)(c.l[i] >> 16); p[2] = (uint8_t)(c.l[i] >> 8); p[3] = (uint8_t)c.l[i];
         }
     }
-    // gnark Marshal()/RawBytes(): X||Y big-endian; infinity = 0x40 then zeros (verifier/verifier.go:95-99)
+    // gnark Marshal()/RawBytes(): X||Y big-endian.  Infinity: BLS12-381 = 0x40 then zeros (verifier/verifier.go:95-99, the
+    // `_fs` constants of templateLogicSigBLS12_381.go:73-84); BN254 = all zeros - the BN254 template feeds ONE constant to the
+    // transcript and to the AVM's ec ops (templateLogicSigBN254.go:57-61,131-132), which take only the all-zero encoding: pinned by
+    // executing that template (tests/golden/template_verdicts.json, circuits whose [Qk] / [Qm] are the point at infinity).
     static void g1_raw_bytes(const Aff& p, uint8_t* out) {
         if (p.is_inf()) {
             memset(out, 0, 2 * FPB);
-            out[0] = 0x40;
+            if (FPB == 48) out[0] = 0x40;
             return;
         }
         fe_to_be<FPP>(p.x, out);
@@ -284,8 +287,13 @@ class CurveBackend : public Backend {
         GraphKey key{};
         key.table = T.table.p; key.a = a;
         for (uint32_t b = a.batch; b < MSM_MAX_BATCH; b++) { key.a.scalars[b] = nullptr; key.a.len[b] = 0; key.a.offset[b] = 0; }
-        for (auto& e : s.graphs)
-            if (e.first == key) { HIPCHK(hipGraphLaunch(e.second, s.stream)); s.pending_pts = a.batch; return APK_OK; }
+        for (size_t i = 0; i < s.graphs.size(); i++)
+            if (s.graphs[i].first == key) {
+                if (i) std::swap(s.graphs[i], s.graphs[0]);          // most recently used first
+                HIPCHK(hipGraphLaunch(s.graphs[0].second, s.stream));
+                s.pending_pts = a.batch;
+                return APK_OK;
+            }
         hipGraph_t g = nullptr;
         HIPCHK(hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal));
         const int rc = run_msm_body(s, T, a, h_out);
@@ -295,7 +303,16 @@ class CurveBackend : public Backend {
         hipGraphExec_t exec = nullptr;
         HIPCHK(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
         (void)hipGraphDestroy(g);
-        s.graphs.emplace_back(key, exec);
+        // bounded: the prover's own four batches hit the same keys every proof; callers with per-call staging pointers
+        // (apk_msm_g1_batch_device) would otherwise grow the list without limit.  The evicted exec may still be running on
+        // this slot's stream, so the stream is drained before it is destroyed.
+        constexpr size_t GRAPH_CACHE = 8;
+        if (s.graphs.size() >= GRAPH_CACHE) {
+            HIPCHK(hipStreamSynchronize(s.stream));
+            (void)hipGraphExecDestroy(s.graphs.back().second);
+            s.graphs.pop_back();
+        }
+        s.graphs.insert(s.graphs.begin(), std::make_pair(key, exec));
         HIPCHK(hipGraphLaunch(exec, s.stream));
         s.pending_pts = a.batch;
         return APK_OK;
@@ -307,7 +324,7 @@ class CurveBackend : public Backend {
         uint32_t maxlen = 0;
         uint64_t entries = 0;
         for (uint32_t b = 0; b < a.batch; b++) {
-            if (a.offset[b] + a.len[b] > T.n_bases) { set_error("msm: %u scalars exceed the %u bases", a.len[b], T.n_bases); return APK_ERR_ARG; }
+            if (a.len[b] > T.n_bases || a.offset[b] > T.n_bases - a.len[b]) { set_error("msm: %u scalars exceed the %u bases", a.len[b], T.n_bases); return APK_ERR_ARG; }
             if (a.len[b] > maxlen) maxlen = a.len[b];
             entries += (uint64_t)a.len[b] * W_;
         }
@@ -451,7 +468,7 @@ class CurveBackend : public Backend {
     int commit(Slot& s, const MsmTables& T, int basis, const MsmBatchArgs& a, Aff* h_out) {
         if (!hook_) return run_msm(s, T, a, h_out);
         for (uint32_t b = 0; b < a.batch; b++)
-            if (a.offset[b] + a.len[b] > T.n_bases) { set_error("msm: %u scalars exceed the %u bases", a.len[b], T.n_bases); return APK_ERR_ARG; }
+            if (a.len[b] > T.n_bases || a.offset[b] > T.n_bases - a.len[b]) { set_error("msm: %u scalars exceed the %u bases", a.len[b], T.n_bases); return APK_ERR_ARG; }
         s.hook_pending = true; s.hook_basis = basis; s.hook_args = a;
         return APK_OK;
     }
@@ -805,7 +822,7 @@ class CurveBackend : public Backend {
                 set_error("msm batch: scalars[%u] is not device memory", b);
                 return APK_ERR_ARG;
             }
-            if (offsets[b] + lens[b] > T.n_bases || !d_scalars[b]) { set_error("msm batch: range [%llu, +%llu) outside the %u bases", (unsigned long long)offsets[b], (unsigned long long)lens[b], T.n_bases); return APK_ERR_ARG; }
+            if (lens[b] > T.n_bases || offsets[b] > T.n_bases - lens[b] || !d_scalars[b]) {   /* no uint64 wrap-around */ set_error("msm batch: range [%llu, +%llu) outside the %u bases", (unsigned long long)offsets[b], (unsigned long long)lens[b], T.n_bases); return APK_ERR_ARG; }
             a.scalars[b] = d_scalars[b]; a.len[b] = (uint32_t)lens[b]; a.offset[b] = (uint32_t)offsets[b];
         }
         CHK(run_msm(s, T, a, reinterpret_cast<Aff*>(s.h_pinned)));
@@ -823,8 +840,10 @@ class CurveBackend : public Backend {
         hipPointerAttribute_t at{};
         if (hipPointerGetAttributes(&at, dd) != hipSuccess || at.type != hipMemoryTypeDevice) { (void)hipGetLastError(); set_error("apk_device_copy: destination is not device memory"); return APK_ERR_ARG; }
         if (hipPointerGetAttributes(&at, ss) != hipSuccess || at.type != hipMemoryTypeDevice) { (void)hipGetLastError(); set_error("apk_device_copy: source is not device memory"); return APK_ERR_ARG; }
-        Slot* own = hook_slot();
-        hipStream_t st = own ? own->stream : nullptr;
+        Slot* own = hook_slot();                       // the prover's stream only when the hook belongs to THIS context
+        bool mine = false;
+        for (Slot* t : slots_) mine |= (t == own);
+        hipStream_t st = mine ? own->stream : nullptr;
         HIPCHK(hipMemcpyAsync(dd, ss, bytes, hipMemcpyDeviceToDevice, st));
         HIPCHK(hipStreamSynchronize(st));
         return APK_OK;
@@ -1126,6 +1145,16 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     Aff lro[3] = {hp[0], hp[1], hp[2]};
     for (int j = 0; j < 3; j++) store_pt(out->lro[j], lro[j]);
 
+    double phase_ms[4] = {0, 0, 0, 0}, lincomb_ms = 0;   // R1..R4 of SURVEY.md section 3.3, host wall clock (stats only)
+    auto t_phase = t_start;
+    auto mark = [&](int r) {
+        if (!stats_on_) return;
+        const auto now = std::chrono::steady_clock::now();
+        phase_ms[r] = std::chrono::duration<double, std::milli>(now - t_phase).count();
+        t_phase = now;
+    };
+    mark(0);
+
     // ---------------- gamma, beta (templateLogicSigBN254.go:131-133) -----------------------------------------
     uint8_t vk_bytes[8 + APK_MAX_COMMITMENTS][2 * FPB];
     for (uint32_t i = 0; i < 8 + nb_commit_; i++) g1_raw_bytes(vk_pts_[i], vk_bytes[i]);
@@ -1177,6 +1206,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     CHK(sync_results(s));
     const Aff zcom = hp[0];
     store_pt(out->z, zcom);
+    mark(1);
     uint8_t z_bytes[2 * FPB];
     g1_raw_bytes(zcom, z_bytes);
     {
@@ -1233,6 +1263,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         return APK_ERR_WITNESS;
     }
     Aff hcom[3] = {hp[0], hp[1], hp[2]};
+    mark(2);
     uint8_t h_bytes[3][2 * FPB];
     for (int j = 0; j < 3; j++) { store_pt(out->h[j], hcom[j]); g1_raw_bytes(hcom[j], h_bytes[j]); }
     hash_challenge("zeta", alpha_raw, {h_bytes[0], h_bytes[1], h_bytes[2]}, {2 * FPB, 2 * FPB, 2 * FPB}, zeta_raw);
@@ -1320,7 +1351,9 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         Aff lp[HOST_MSM_MAX];
         Fr lk[HOST_MSM_MAX];
         for (size_t i = 0; i < lin_terms.size(); i++) { lp[i] = lin_terms[i].com; lk[i] = lin_terms[i].coef; }
+        const auto t_lc = std::chrono::steady_clock::now();
         lin_com = host_lincomb<FRP, FPP>(lp, lk, (int)lin_terms.size());
+        if (stats_on_) lincomb_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lc).count();
     }
     memcpy(out->zshift_value, &zshift, sizeof(Fr));
     Fr claimed[6 + APK_MAX_COMMITMENTS] = {lin_z, lz, rz, oz, s1z, s2z};
@@ -1368,11 +1401,14 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     store_pt(out->batched_h, hp[0]);
     memcpy(out->gamma, &gamma, sizeof(Fr)); memcpy(out->beta, &beta, sizeof(Fr)); memcpy(out->alpha, &alpha, sizeof(Fr));
     memcpy(out->zeta, &zeta, sizeof(Fr)); memcpy(out->gamma_kzg, &gk, sizeof(Fr));
+    mark(3);
     if (stats_on_) {
         double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
         std::lock_guard<std::mutex> g(stats_mu_);
         stats_.prove_ms += ms;
         stats_.proofs += 1;
+        for (int r = 0; r < 4; r++) stats_.round_ms[r] += phase_ms[r];
+        stats_.host_lincomb_ms += lincomb_ms;
     }
     return APK_OK;
 }

@@ -295,7 +295,7 @@ struct HostVerifier {
         }
     }
     static void g1_raw(const Aff& p, uint8_t* out) {
-        if (p.is_inf()) { memset(out, 0, 2 * FPB); out[0] = 0x40; return; }
+        if (p.is_inf()) { memset(out, 0, 2 * FPB); if (FPB == 48) out[0] = 0x40; return; }   // BN254: all zeros (see backend_impl.h g1_raw_bytes)
         fe_to_be<FPP>(p.x, out);
         fe_to_be<FPP>(p.y, out + FPB);
     }
@@ -349,7 +349,28 @@ struct HostVerifier {
         return fr_from_be(b1) * Fr::to_mont(t) + fr_from_be(lo);
     }
 
-    static int verify(const apk_verifying_key* vk, const apk_proof* pr, const void* public_inputs) {
+    // [r]P == infinity.  BN254's G1 has cofactor 1; BLS12-381's has not (gnark's SetBytes rejects such points, the AVM's
+    // pairing_check fails on them).
+    static bool g1_in_subgroup(const Aff& p) {
+        if (FPB != 48 || p.is_inf()) return true;
+        Pt acc = Pt::inf();
+        bool started = false;
+        const Fr q = Fr::modulus();
+        for (int w = Fr::N - 1; w >= 0; w--)
+            for (int b = 31; b >= 0; b--) {
+                if (started) acc = Pt::dbl(acc);
+                if ((q.l[w] >> b) & 1u) { acc.madd(p); started = true; }
+            }
+        return acc.to_affine().is_inf();
+    }
+    static void put_fr(uint8_t* out, const Fr& v) { fe_to_be<FRP>(v, out); }
+    static void put_pt(uint8_t* out, const Aff& p) {   // what the AVM's ec ops return: X || Y big-endian, all zero for infinity
+        memset(out, 0, APK_G1_MAX_BYTES);
+        if (!p.is_inf()) { fe_to_be<FPP>(p.x, out); fe_to_be<FPP>(p.y, out + FPB); }
+    }
+
+    static int verify(const apk_verifying_key* vk, const apk_proof* pr, const void* public_inputs, apk_verify_trace* tr) {
+        if (tr) memset(tr, 0, sizeof *tr);
         if (vk->n < 2 || (vk->n & (vk->n - 1)) || vk->n > (1ull << 30)) { set_error("verifying key: n must be a power of two"); return APK_ERR_ARG; }
         const uint32_t k = vk->nb_commitments;
         if (k > APK_MAX_COMMITMENTS || pr->nb_commitments != k || pr->curve != (uint32_t)CURVE_ID) {
@@ -381,6 +402,7 @@ struct HostVerifier {
         std::vector<Aff> pts = {L, R, O, Z, H1, H2, H3, Wz, Wzw};
         for (uint32_t i = 0; i < k; i++) { Qcp[i] = load_pt(vk->qcp[i]); Bsb[i] = load_pt(pr->bsb22[i]); pts.push_back(Bsb[i]); }
         for (const Aff& p : pts) if (!g1_on_curve(p)) { set_error("proof point is not on the curve"); return APK_ERR_VERIFY; }
+        for (const Aff& p : pts) if (!g1_in_subgroup(p)) { set_error("proof point is not in the prime-order subgroup"); return APK_ERR_VERIFY; }
         const Fr l_z = load_fr(pr->claimed_values[1]), r_z = load_fr(pr->claimed_values[2]), o_z = load_fr(pr->claimed_values[3]);
         const Fr s1_z = load_fr(pr->claimed_values[4]), s2_z = load_fr(pr->claimed_values[5]), zw_z = load_fr(pr->zshift_value);
         Fr qcp_z[APK_MAX_COMMITMENTS];
@@ -404,6 +426,7 @@ struct HostVerifier {
         { Transcript t("alpha"); t.bytes(beta_raw, 32); for (uint32_t i = 0; i < k; i++) t.point(Bsb[i]); t.point(Z); t.done(alpha_raw); }
         { Transcript t("zeta"); t.bytes(alpha_raw, 32); t.point(H1); t.point(H2); t.point(H3); t.done(zeta_raw); }
         const Fr gamma = fr_from_be(gamma_raw), beta = fr_from_be(beta_raw), alpha = fr_from_be(alpha_raw), zeta = fr_from_be(zeta_raw);
+        if (tr) { put_fr(tr->gamma, gamma); put_fr(tr->beta, beta); put_fr(tr->alpha, alpha); put_fr(tr->zeta, zeta); }
 
         // ---- PI(zeta) = sum pub_i L_i(zeta) + sum hash_fr([pi2_k]) L_{nbPub + cci_k}(zeta),  L_i(X) = w^i (X^n - 1) / (n (X - w^i))
         const Fr one = Fr::one();
@@ -426,6 +449,7 @@ struct HostVerifier {
         const Fr alpha2 = alpha * alpha;
         const Fr perm_z = alpha * zw_z * (l_z + beta * s1_z + gamma) * (r_z + beta * s2_z + gamma) * (o_z + gamma);
         const Fr lin_z = Fr::neg(pi + perm_z - alpha2 * lag0);
+        if (tr) { put_fr(tr->pi, pi); put_fr(tr->lin_at_zeta, lin_z); }
 
         // ---- [lin] (App. E "lin(X)")
         const Fr c_s3 = alpha * beta * zw_z * (l_z + beta * s1_z + gamma) * (r_z + beta * s2_z + gamma);
@@ -439,6 +463,7 @@ struct HostVerifier {
         lin.add(smul(S3, c_s3)); lin.add(smul(Z, c_z));
         lin.add(smul(H1, mzh)); lin.add(smul(H2, mzh * zn2)); lin.add(smul(H3, mzh * zn2 * zn2));
         const Aff lin_com = lin.to_affine();
+        if (tr) put_pt(tr->lin_commitment, lin_com);
 
         // ---- gamma' and the folded opening at zeta (:280-321)
         uint8_t gk_raw[32];
@@ -453,12 +478,14 @@ struct HostVerifier {
             t.done(gk_raw);
         }
         const Fr gk = fr_from_be(gk_raw);
+        if (tr) put_fr(tr->gamma_kzg, gk);
         Pt F = Pt::from_affine(lin_com);
         Fr c = lin_z, g = gk;
         const Aff fold_pts[5] = {L, R, O, S1, S2};
         const Fr fold_vals[5] = {l_z, r_z, o_z, s1_z, s2_z};
         for (int i = 0; i < 5; i++) { F.add(smul(fold_pts[i], g)); c = c + g * fold_vals[i]; g = g * gk; }
         for (uint32_t i = 0; i < k; i++) { F.add(smul(Qcp[i], g)); c = c + g * qcp_z[i]; g = g * gk; }
+        if (tr) { put_pt(tr->folded_digest, F.to_affine()); put_fr(tr->folded_claim, c); }
 
         // ---- batch the two openings with verifier-side randomness r' (any value unpredictable to the prover: a hash of
         // everything above; :322-345), then e(F - c G1 + zeta W_z + r' (Z - Zw G1 + w zeta W_zw), G2_0) e(-(W_z + r' W_zw), G2_1) = 1
@@ -487,6 +514,8 @@ struct HostVerifier {
             memcpy(&g2[j].y, vk->g2[j] + 2 * FPB, sizeof(g2[j].y));
             g2[j].inf = g2[j].x.is_zero() && g2[j].y.is_zero();
             if (g2[j].inf || !g2[j].on_curve()) { set_error("verifying key: Kzg.G2[%d] is not a point of the twist", j); return APK_ERR_ARG; }
+            // the twists have large cofactors and the ate Miller loop is a pairing only on the order-r subgroup
+            if (!G2::template mul<FRP>(g2[j], Fr::modulus()).inf) { set_error("verifying key: Kzg.G2[%d] is not in the prime-order subgroup", j); return APK_ERR_ARG; }
         }
         if (!pairing_check2<FPP, PP>(A.to_affine(), g2[0], B.to_affine(), g2[1])) {
             set_error("plonk verification failed: pairing check");

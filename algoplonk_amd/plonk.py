@@ -193,9 +193,12 @@ def Verify(proof: "Proof", vk: VerifyingKey, public_witness: frontend.Witness) -
     """plonk.Verify(proof, vk, publicWitness) (/root/reference/algoplonk.go:93): raises VerificationError when the proof is
     rejected.  Host-side (apk_verify: transcript, linearised commitment, one two-pair pairing check) - no GPU work."""
     cv = vk.curve
-    pub = cv.fr_vector(public_witness.Public().public)
+    public = public_witness.Public().public
+    if len(public) != vk.NbPublicVariables:       # gnark: "invalid witness size, got %d, expected %d (public)"
+        raise VerificationError("invalid witness size, got %d, expected %d (public)" % (len(public), vk.NbPublicVariables))
+    pub = cv.fr_vector(public)
     raw_vk = vk.raw()
-    rc = lib.apk_verify(C.byref(raw_vk), C.byref(proof.raw), pub)
+    rc = lib.apk_verify_ex(C.byref(raw_vk), C.byref(proof.raw), pub, len(public), None)
     if rc == _lib.APK_ERR_VERIFY:
         raise VerificationError((lib.apk_last_error() or b"").decode())
     check(rc)

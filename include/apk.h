@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define APK_ABI_VERSION 2
+#define APK_ABI_VERSION 3
 
 /* curve ids: the two curves the AVM supports (algoplonk.go:39-41) */
 #define APK_BN254 0
@@ -177,7 +177,22 @@ typedef struct {
     uint8_t g1[APK_G1_MAX_BYTES];        /* VK Kzg.G1 = SRS G1[0] */
     uint8_t g2[2][APK_G2_MAX_BYTES];     /* VK Kzg.G2 = ([1]G2, [tau]G2), gnark in-memory G2Affine */
 } apk_verifying_key;
-int apk_verify(const apk_verifying_key* vk, const apk_proof* proof, const void* public_inputs);
+int apk_verify(const apk_verifying_key* vk, const apk_proof* proof, const void* public_inputs);   /* public_inputs: vk->nb_public Fr */
+/* Same check with (a) the length of the public witness stated by the caller - gnark's plonk.Verify rejects
+ * len(publicWitness) != vk.NbPublicVariables, and so does this call (APK_ERR_VERIFY) instead of reading vk->nb_public values
+ * from a shorter buffer - and (b) optionally the intermediate values of the verification under the names the reference's
+ * AVM template gives them (verifier/templateLogicSigBN254.go:137-140 gamma/beta/alpha/zeta, :181-193 PI, :218
+ * linearized_poly_at_z, :256-278 lin_poly_com, :281-287 the folding challenge, :289-320 digest/claims before the two openings are
+ * batched).  Scalars canonical big-endian; points X || Y big-endian as the AVM's ec ops return them (all zero = infinity).
+ * tests/test_template_pin.py compares them with the values the executed template produced (tests/golden/template_verdicts.json).
+ * Fields behind the point of rejection stay zero. */
+typedef struct {
+    uint8_t gamma[APK_FR_BYTES], beta[APK_FR_BYTES], alpha[APK_FR_BYTES], zeta[APK_FR_BYTES];
+    uint8_t pi[APK_FR_BYTES], lin_at_zeta[APK_FR_BYTES], gamma_kzg[APK_FR_BYTES], folded_claim[APK_FR_BYTES];
+    uint8_t lin_commitment[APK_G1_MAX_BYTES], folded_digest[APK_G1_MAX_BYTES];
+} apk_verify_trace;
+int apk_verify_ex(const apk_verifying_key* vk, const apk_proof* proof, const void* public_inputs, uint32_t nb_public_inputs,
+                  apk_verify_trace* trace /* may be NULL */);
 /* G2 points for apk_verifying_key.g2 (host only).  apk_g2_decompress: one compressed G2 exactly as it sits in the
  * reference's vk.bin files (64 | 96 bytes, X.A1 || X.A0 big-endian with gnark's flag bits) -> in-memory form.
  * apk_g2_mul_generator: [scalar]G2 - the G2 side of a TestOnly SRS whose tau is known (unsafekzg, setup/setup.go:102-108);
@@ -241,6 +256,12 @@ typedef struct {
     uint64_t ntt_elements;     /* elements transformed (sum of sizes) */
     double prove_ms;           /* wall time inside apk_prove* */
     uint64_t proofs;
+    /* host wall clock per round of the prover, summed over `proofs` (the rounds of SURVEY.md section 3.3: R1 = wire polynomials,
+     * BSB22 commitments, [L][R][O]; R2 = grand product, [Z]; R3 = quotient, [H1..3]; R4 = evaluations, [lin], the two
+     * openings).  Each includes the Fiat-Shamir hashing that follows it.  host_lincomb_ms = the part of R4 spent in the
+     * host-side combination of commitments that replaces the MSM of the linearised polynomial. */
+    double round_ms[4];
+    double host_lincomb_ms;
 } apk_stats;
 int apk_stats_enable(apk_ctx* ctx, int enable); /* enabling inserts hipEvents around the kernels above */
 int apk_stats_read(apk_ctx* ctx, apk_stats* out, int reset);

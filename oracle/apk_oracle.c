@@ -191,11 +191,12 @@ static void fr_from_be_reduce(const fr_field* F, fr_t* out, const uint8_t* be) {
     while (f4_geq(&a, &F->mod)) f4_sub_raw(&a, &a, &F->mod);
     f4_to_mont(F, out, &a);
 }
-/* gnark RawBytes(): X||Y big-endian, infinity = 0x40 then zeros (verifier/verifier.go:95-99) */
+/* gnark RawBytes(): X||Y big-endian; infinity = 0x40 then zeros on BLS12-381 (verifier/verifier.go:95-99), all zeros on BN254
+ * (templateLogicSigBN254.go:57-61,131-132: one constant for the transcript and the ec ops; pinned by tests/golden/template_verdicts.json) */
 static void g1_raw(int curve, const void* aff, uint8_t* out) {
     if (curve == 0) {
         const bn_aff* p = (const bn_aff*)aff;
-        if (bn_aff_is_inf(p)) { memset(out, 0, 64); out[0] = 0x40; return; }
+        if (bn_aff_is_inf(p)) { memset(out, 0, 64); return; }
         f4_t c;
         f4_from_mont(&FP_BN, &c, &p->x); for (int i = 0; i < 4; i++) for (int b = 0; b < 8; b++) out[31 - (8 * i + b)] = (uint8_t)(c.l[i] >> (8 * b));
         f4_from_mont(&FP_BN, &c, &p->y); for (int i = 0; i < 4; i++) for (int b = 0; b < 8; b++) out[63 - (8 * i + b)] = (uint8_t)(c.l[i] >> (8 * b));

@@ -148,11 +148,15 @@ class Curve:
 
     # ---- encodings -------------------------------------------------------------------------
     def raw_bytes(self, P: Point) -> bytes:
-        """gnark `RawBytes()` / `Marshal()`: X || Y big-endian, infinity = 0x40 then zeros
-        (helper.go:35-72 uses RawBytes for BLS12-381; verifier/verifier.go:95-99 documents 0x40)."""
+        """gnark `RawBytes()` / `Marshal()`: X || Y big-endian.  Infinity: BLS12-381 = 0x40 then zeros
+        (helper.go:35-72 uses RawBytes; verifier/verifier.go:95-99 documents 0x40 and keeps it for the
+        transcript through `hexEncoded`, :102-105); BN254 = all zeros: its template has no `_fs` constants,
+        the bytes that are hashed are the bytes the AVM's ec ops decode (templateLogicSigBN254.go:57-61,
+        131-132), and those accept only the all-zero encoding.  Pinned by the executed template
+        (tests/golden/template_verdicts.json: pythagorean has [Qk] = infinity, identity has [Qm] = infinity)."""
         n = self.fp_bytes
         if P is None:
-            return bytes([0x40]) + bytes(2 * n - 1)
+            return bytes([0x40 if n == 48 else 0x00]) + bytes(2 * n - 1)
         return P[0].to_bytes(n, "big") + P[1].to_bytes(n, "big")
 
     def from_raw_bytes(self, b: bytes) -> Point:

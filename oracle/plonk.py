@@ -585,7 +585,11 @@ def prove(pk: ProvingKey, L: Sequence[int], R: Sequence[int], O: Sequence[int],
 # ------------------------------------------------------------------------------------------------
 
 
-def verify(vk: VerifyingKey, proof: bytes, public_inputs: bytes) -> bool:
+def verify(vk: VerifyingKey, proof: bytes, public_inputs: bytes, trace_out: Optional[dict] = None) -> bool:
+    """`trace_out`, when given, receives the intermediates the template computes under the template's own names
+    (gamma, beta, alpha, zeta, PI, linearized_poly_at_z, lin_poly_com, folded_h, digest, claims, quotient) so that
+    tests/test_template_pin.py can hold every step - not only the verdict - to the executed reference template."""
+    T = trace_out if trace_out is not None else {}
     cv = vk.curve
     q = cv.r
     fpb = cv.fp_bytes
@@ -647,6 +651,7 @@ def verify(vk: VerifyingKey, proof: bytes, public_inputs: bytes) -> bool:
                                    + fs(GRAND_PRODUCT)).digest()
         zeta_pre = hashlib.sha256(b"zeta" + alpha_pre + fs(H_0) + fs(H_1) + fs(H_2)).digest()
         gamma, beta, alpha, zeta = (I(x) % q for x in (gamma_pre, beta_pre, alpha_pre, zeta_pre))
+        T.update(gamma=gamma, beta=beta, alpha=alpha, zeta=zeta)
 
         n = vk.size
         # :142-146
@@ -680,6 +685,7 @@ def verify(vk: VerifyingKey, proof: bytes, public_inputs: bytes) -> bool:
         s1 = s1 * s2 % q * o % q * alpha % q * zwz % q
         s1 = (s1 + PI + q - alpha2Lagrange) % q
         linearized_poly_at_z = (q - s1) % q
+        T.update(PI=PI, linearized_poly_at_z=linearized_poly_at_z)
         # :220-229 folded H
         zn2 = pow(zeta, n + 2, q)
         folded_h = cv.mul(P(H_2), zn2)
@@ -687,6 +693,7 @@ def verify(vk: VerifyingKey, proof: bytes, public_inputs: bytes) -> bool:
         folded_h = cv.mul(folded_h, zn2)
         folded_h = cv.add(folded_h, P(H_0))
         folded_h = cv.neg(cv.mul(folded_h, Zz))
+        T["folded_h"] = rb_ec(cv, folded_h)
         # :231-254
         uu = zwz * beta % q
         v = (s1z * beta + lz + gamma) % q
@@ -710,6 +717,7 @@ def verify(vk: VerifyingKey, proof: bytes, public_inputs: bytes) -> bool:
         lin = cv.add(lin, cv.mul(vk.s[2], s1))
         lin = cv.add(lin, cv.mul(P(GRAND_PRODUCT), s2))
         lin = cv.add(lin, folded_h)
+        T["lin_poly_com"] = rb_ec(cv, lin)
         # :280-287
         r_pre = hashlib.sha256(
             b"gamma" + fr_bytes(zeta) + rb_ec(cv, lin) + fs(L_COM) + fs(R_COM) + fs(O_COM)
@@ -718,6 +726,7 @@ def verify(vk: VerifyingKey, proof: bytes, public_inputs: bytes) -> bool:
             + b"".join(QCP_AT_Z) + GRAND_PRODUCT_AT_Z_OMEGA).digest()
         rr = I(r_pre) % q
         r_acc = rr
+        T["gamma_kzg"] = rr
         # :289-320 fold
         digest = lin
         claims = linearized_poly_at_z
@@ -729,6 +738,7 @@ def verify(vk: VerifyingKey, proof: bytes, public_inputs: bytes) -> bool:
             digest = cv.add(digest, cv.mul(vk.qcp[i], r_acc))
             claims = (claims + I(QCP_AT_Z[i]) * r_acc) % q
             r_acc = r_acc * rr % q
+        T.update(folded_digest=rb_ec(cv, digest), folded_claims=claims)
         # :322-345 batch the two openings with verifier-side randomness
         r_pre = hashlib.sha256(rb_ec(cv, digest) + BATCH_OPENING_AT_Z + fs(GRAND_PRODUCT)
                                + OPENING_AT_Z_OMEGA + fr_bytes(zeta) + fr_bytes(rr)).digest()
@@ -742,6 +752,7 @@ def verify(vk: VerifyingKey, proof: bytes, public_inputs: bytes) -> bool:
         zeta_omega = zeta * vk.generator % q
         points_quotient = cv.add(points_quotient, cv.mul(P(OPENING_AT_Z_OMEGA), rv * zeta_omega % q))
         digest = cv.add(digest, points_quotient)
+        T.update(digest=rb_ec(cv, digest), claims=claims, quotient=rb_ec(cv, cv.neg(quotient)))
         # :346-355  e(digest, G2_0) * e(-quotient, G2_1) == 1   <=>   digest == tau * quotient
         if vk.g2 is not None:
             # the reference's own final line: ec.pairing_check(EC.BLS12_381g1, digest + invert(quotient), g2)

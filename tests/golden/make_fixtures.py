@@ -71,10 +71,6 @@ def proof_vectors():
               open(os.path.join(HERE, "proof_vectors.json"), "w"), indent=1)
 
 
-if __name__ == "__main__":
-    trusted_setup_fixtures()
-    ethereum_srs_prefix()
-    proof_vectors()
 
 
 def ethereum_srs_prefix():
@@ -87,3 +83,9 @@ def ethereum_srs_prefix():
         o.write(f.read(4 + 16387 * 48))
     with open(os.path.join(src, "vk.bin"), "rb") as f, open(os.path.join(d, "vk.bin"), "wb") as o:
         o.write(f.read())
+
+
+if __name__ == "__main__":
+    trusted_setup_fixtures()
+    ethereum_srs_prefix()
+    proof_vectors()
