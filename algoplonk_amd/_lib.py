@@ -30,6 +30,10 @@ SYMBOLS = [
     "apk_fe_from_be", "apk_fe_to_be", "apk_hash_fr", "apk_host_fe_op", "apk_host_g1_op", "apk_g1_sum",
     "apk_device_alloc", "apk_device_free", "apk_device_upload", "apk_device_download",
     "apk_stats_enable", "apk_stats_read",
+    "apk_ctx_set_wire_hook", "apk_coset_ntt_device",
+    "apk_comm_create", "apk_comm_destroy", "apk_comm_rank", "apk_comm_world", "apk_comm_barrier", "apk_comm_max_f64", "apk_comm_bind",
+    "apk_comm_transport", "apk_msm_g1_sharded", "apk_comm_split_begin", "apk_comm_split_end", "apk_comm_serve", "apk_comm_set_compute",
+    "apk_comm_commit", "apk_comm_wires",
 ]
 
 
@@ -99,6 +103,22 @@ class Stats(C.Structure):
 COMMIT_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_void_p)
 
 
+# int hook(void* user, uint32_t count, const void* const* d_canonical, const uint32_t* lens, void* const* d_evals)
+WIRE_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p))
+
+# apk_compute: the GPU touch points of the communicator's schedules (test seam, include/apk.h)
+CP_MSM = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p)
+CP_COSET = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+CP_ALLOC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p))
+CP_RELEASE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+CP_COPY = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+
+
+class Compute(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("msm_batch", CP_MSM), ("coset_ntt", CP_COSET), ("alloc", CP_ALLOC), ("release", CP_RELEASE),
+                ("copy", CP_COPY), ("g1_bytes", C.c_size_t), ("n", C.c_uint64)]
+
+
 def _load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -144,6 +164,23 @@ def _load() -> C.CDLL:
     lib.apk_device_download.argtypes = [vp, vp, vp, sz]
     lib.apk_stats_enable.argtypes = [vp, i32]
     lib.apk_stats_read.argtypes = [vp, C.POINTER(Stats), i32]
+    lib.apk_ctx_set_wire_hook.argtypes = [vp, WIRE_HOOK, vp]
+    lib.apk_coset_ntt_device.argtypes = [vp, vp, u64, vp]
+    lib.apk_comm_create.argtypes = [i32, i32, C.c_char_p, i32, C.POINTER(vp)]
+    lib.apk_comm_destroy.argtypes = [vp]; lib.apk_comm_destroy.restype = None
+    lib.apk_comm_rank.argtypes = [vp]
+    lib.apk_comm_world.argtypes = [vp]
+    lib.apk_comm_barrier.argtypes = [vp]
+    lib.apk_comm_max_f64.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.apk_comm_bind.argtypes = [vp, vp]
+    lib.apk_comm_transport.argtypes = [vp]; lib.apk_comm_transport.restype = C.c_char_p
+    lib.apk_msm_g1_sharded.argtypes = [vp, vp, u64, vp]
+    lib.apk_comm_split_begin.argtypes = [vp]
+    lib.apk_comm_split_end.argtypes = [vp]
+    lib.apk_comm_serve.argtypes = [vp, C.POINTER(u64)]
+    lib.apk_comm_set_compute.argtypes = [vp, C.POINTER(Compute)]
+    lib.apk_comm_commit.argtypes = [vp, i32, C.c_uint32, vp, vp, vp]
+    lib.apk_comm_wires.argtypes = [vp, C.c_uint32, vp, vp, vp]
     return lib
 
 

@@ -24,6 +24,10 @@ struct Backend {
     virtual int msm_batch(int basis, uint32_t count, const void* const* d_scalars, const uint64_t* offsets, const uint64_t* lens, void* out) = 0;
     virtual int set_commit_hook(apk_commit_hook fn, void* user) = 0;
     virtual int dev_copy(void* d, const void* s, size_t bytes) = 0;
+    virtual int set_wire_hook(apk_wire_hook fn, void* user) = 0;
+    virtual int device_ordinal() = 0;
+    virtual uint64_t domain_size() = 0;   // n; 0 on an MSM-only context
+    virtual int coset_ntt_dev(const void* d_in, uint64_t len, void* d_out) = 0;
     virtual int ntt(int which, int inverse, int coset, void* data) = 0;
     virtual int prove(const void* L, const void* R, const void* O, bool on_device, const void* pub, const void* blinding,
                       const void* const* pi2, apk_proof* out) = 0;

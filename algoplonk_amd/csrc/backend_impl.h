@@ -188,6 +188,8 @@ class CurveBackend : public Backend {
     // intra-proof multi-GPU (apk_ctx_set_commit_hook): the prover's commitments go through the host's hook instead of this GPU
     apk_commit_hook hook_ = nullptr;
     void* hook_user_ = nullptr;
+    apk_wire_hook wire_hook_ = nullptr;
+    void* wire_hook_user_ = nullptr;
     // stats
     bool stats_on_ = false;
     uint32_t simds_ = 1024;  // SIMDs of the device (4 per CU); set at init
@@ -833,6 +835,25 @@ class CurveBackend : public Backend {
         return APK_OK;
     }
     int set_commit_hook(apk_commit_hook fn, void* user) override { hook_ = fn; hook_user_ = user; return APK_OK; }
+    int set_wire_hook(apk_wire_hook fn, void* user) override { wire_hook_ = fn; wire_hook_user_ = user; return APK_OK; }
+    int device_ordinal() override { return device_; }
+    uint64_t domain_size() override { return msm_only_ ? 0 : n_; }
+    // 4n coset evaluations of a canonical polynomial, device memory in and out; COMPLETE when the call returns.  Inside a hook of
+    // this context it runs on the prover's own stream (see msm_batch), otherwise on a free slot.
+    int coset_ntt_dev(const void* d_in, uint64_t len, void* d_out) override {
+        if (msm_only_) { set_error("MSM-only context has no NTT domain"); return APK_ERR_STATE; }
+        if (!d_in || !d_out || len == 0 || len > n4_) { set_error("coset ntt: 1..4n coefficients"); return APK_ERR_ARG; }
+        HIPCHK(hipSetDevice(device_));
+        Slot* own = hook_slot();
+        bool mine = false;
+        for (Slot* t : slots_) mine |= (t == own);
+        if (!mine) own = nullptr;
+        struct MaybeGuard { CurveBackend* b; Slot* s; bool owned; ~MaybeGuard() { if (owned) b->release(s); } };
+        MaybeGuard g{this, own ? own : acquire(), own == nullptr};
+        CHK(coset_ntt_4n(g.s->stream, reinterpret_cast<const Fr*>(d_in), (uint32_t)len, reinterpret_cast<Fr*>(d_out)));
+        HIPCHK(hipStreamSynchronize(g.s->stream));
+        return APK_OK;
+    }
     // device-to-device copy that has COMPLETED when the call returns (hipMemcpy D2D returns early, and the proving streams are
     // non-blocking streams: they do not order themselves behind the null stream)
     int dev_copy(void* dd, const void* ss, size_t bytes) override {
@@ -1139,7 +1160,19 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     {
         Fr* ev[3] = {ptr<Fr>(s.el), ptr<Fr>(s.er), ptr<Fr>(s.eo)};
         const uint32_t lens[3] = {n + 2, n + 2, n + 2};
-        CHK(run_ntt_batch(st, 1, false, 3, canon, ev, lens, n4_, ptr<Fr>(coset_pre_), nullptr, nullptr));
+        if (wire_hook_) {
+            // per-wire transforms dealt to other GPUs (csrc/comm.cpp): the hook returns with the three
+            // evaluation vectors complete in this context's memory
+            HIPCHK(hipStreamSynchronize(st));
+            const void* cin[3] = {canon[0], canon[1], canon[2]};
+            void* eout[3] = {ev[0], ev[1], ev[2]};
+            hook_slot() = &s;
+            const int rc = wire_hook_(wire_hook_user_, 3, cin, lens, eout);
+            hook_slot() = nullptr;
+            if (rc != APK_OK) { set_error("wire hook failed with %d", rc); return rc == APK_ERR_ARG ? APK_ERR_ARG : APK_ERR_STATE; }
+        } else {
+            CHK(run_ntt_batch(st, 1, false, 3, canon, ev, lens, n4_, ptr<Fr>(coset_pre_), nullptr, nullptr));
+        }
     }
     CHK(sync_results(s));
     Aff lro[3] = {hp[0], hp[1], hp[2]};

@@ -1,0 +1,570 @@
+// libapk's communicator: the exchange steps of the path behind the C-ABI (include/apk.h "multi-GPU behind the boundary").
+//
+//   control plane  TCP star through rank 0: rendezvous, headers, status words + 64/96-byte partial sums, barriers
+//   data plane     RCCL (librccl dlopen'ed, libapk's own HIP runtime and stream): grouped ncclSend/ncclRecv for the scatter of
+//                  scalar slices and for the peer copies of polynomials; or - two ranks on one GPU, no librccl, CPU tier tests -
+//                  the same bytes staged through the host and the TCP star
+//   schedules      sharded MSM (BASELINE configs[3]); split proof: commitment batches dealt by index range, optional per-wire
+//                  coset evaluations dealt by wire
+//
+// Host only (no kernels): every GPU touch point goes through `apk_compute`, whose built-in table calls the bound context and
+// which the CPU tier replaces to run this same code in two processes without a GPU.
+#include <arpa/inet.h>
+#include <dlfcn.h>
+#include <errno.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <string.h>
+#include <sys/socket.h>
+#include <sys/time.h>
+#include <unistd.h>
+
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include "backend.h"
+
+struct apk_ctx {   // same layout as in apk_api.cpp
+    apk::Backend* be;
+    int curve;
+};
+
+namespace apk {
+
+// ---- the deal: contiguous shares of a flattened (commitment, index) list ----------------------------------------------------
+struct Seg { uint32_t k; uint64_t lo, hi; };
+static void my_share(uint64_t total, int rank, int world, uint64_t& lo, uint64_t& hi) {
+    const uint64_t base = total / world, rem = total % world;
+    lo = (uint64_t)rank * base + ((uint64_t)rank < rem ? rank : rem);
+    hi = lo + base + ((uint64_t)rank < rem ? 1 : 0);
+}
+static std::vector<Seg> deal(const uint32_t* lens, uint32_t count, int rank, int world) {
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < count; i++) total += lens[i];
+    uint64_t lo, hi, base = 0;
+    my_share(total, rank, world, lo, hi);
+    std::vector<Seg> out;
+    for (uint32_t k = 0; k < count; k++) {
+        const uint64_t a = lo > base ? lo : base, b = hi < base + lens[k] ? hi : base + lens[k];
+        if (a < b) out.push_back({k, a - base, b - base});
+        base += lens[k];
+    }
+    return out;
+}
+
+// ---- sockets -------------------------------------------------------------------------------------------------------------------
+static int send_all(int fd, const void* buf, size_t n) {
+    const uint8_t* p = (const uint8_t*)buf;
+    while (n) {
+        const ssize_t w = ::send(fd, p, n, MSG_NOSIGNAL);
+        if (w < 0) { if (errno == EINTR) continue; set_error("comm: send failed: %s", strerror(errno)); return APK_ERR_STATE; }
+        p += w; n -= (size_t)w;
+    }
+    return APK_OK;
+}
+static int recv_all(int fd, void* buf, size_t n) {
+    uint8_t* p = (uint8_t*)buf;
+    while (n) {
+        const ssize_t r = ::recv(fd, p, n, 0);
+        if (r == 0) { set_error("comm: peer closed the connection"); return APK_ERR_STATE; }
+        if (r < 0) {
+            if (errno == EINTR) continue;
+            set_error("comm: recv failed: %s", errno == EAGAIN || errno == EWOULDBLOCK ? "timed out waiting for a peer" : strerror(errno));
+            return APK_ERR_STATE;
+        }
+        p += r; n -= (size_t)r;
+    }
+    return APK_OK;
+}
+static void tune(int fd, int timeout_s) {
+    int one = 1;
+    setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+    int big = 8 << 20;
+    setsockopt(fd, SOL_SOCKET, SO_SNDBUF, &big, sizeof big);
+    setsockopt(fd, SOL_SOCKET, SO_RCVBUF, &big, sizeof big);
+    struct timeval tv = {timeout_s, 0};
+    setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+    setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
+}
+
+// ---- RCCL, loaded on demand -----------------------------------------------------------------------------------------------------
+struct Rccl {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool load() {
+        if (h) return true;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* nm : names) { h = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+        if (!h) return false;
+#define SYM(f, name) f = reinterpret_cast<decltype(f)>(dlsym(h, name)); if (!f) { dlclose(h); h = nullptr; return false; }
+        SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+        SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(AllGather, "ncclAllGather") SYM(GroupStart, "ncclGroupStart")
+        SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+        return true;
+    }
+};
+static Rccl g_rccl;
+#define NCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { set_error("comm: RCCL %s: %s", #x, g_rccl.GetErrorString(r_)); return APK_ERR_HIP; } } while (0)
+#define HCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("comm: HIP %s: %s", #x, hipGetErrorString(e_)); return APK_ERR_HIP; } } while (0)
+#define CHK(x) do { int rc_ = (x); if (rc_ != APK_OK) return rc_; } while (0)
+
+enum : int32_t { OP_COMMIT = 1, OP_WIRES = 2, OP_STOP = 3 };
+struct Header { int32_t op, basis; uint32_t count; uint32_t lens[4]; };
+
+}  // namespace apk
+
+using namespace apk;
+
+struct apk_comm {
+    int rank = 0, world = 1;
+    int listen_fd = -1;
+    std::vector<int> peer;          // rank 0: fd of every worker (index = rank); workers: peer[0] = fd to rank 0
+    int timeout_s = 300;
+    apk_ctx* ctx = nullptr;
+    apk_compute cp{};               // effective table (built-in entries filled by bind)
+    apk_compute user_cp{};          // what set_compute supplied
+    bool have_user_cp = false;
+    bool device_is_host = false;    // CPU tier: "device" pointers are host pointers
+    // RCCL
+    bool rccl = false;
+    ncclComm_t nccl = nullptr;
+    hipStream_t stream = nullptr;
+    int device = -1;
+    // grow-only staging
+    void* d_stage = nullptr; size_t stage_cap = 0;       // leader: world x chunk; workers: chunk
+    void* d_wire_in = nullptr; size_t wire_in_cap = 0;   // workers: a canonical polynomial
+    void* d_wire_out = nullptr; size_t wire_out_cap = 0; // workers: its 4n evaluations
+    std::vector<uint8_t> h_stage;
+    bool split_on = false;
+    uint64_t steps = 0;
+
+    int fd_of(int r) const { return rank == 0 ? peer[r] : peer[0]; }
+};
+
+// ---- built-in compute table: the bound context ------------------------------------------------------------------------------------
+static int bi_msm(void* u, int basis, uint32_t count, const void* const* sc, const uint64_t* off, const uint64_t* len, void* out) {
+    return apk_msm_g1_batch_device(((apk_comm*)u)->ctx, basis, count, sc, off, len, out);
+}
+static int bi_coset(void* u, const void* in, uint64_t len, void* out) { return apk_coset_ntt_device(((apk_comm*)u)->ctx, in, len, out); }
+static int bi_alloc(void* u, size_t b, void** p) { return apk_device_alloc(((apk_comm*)u)->ctx, b, p); }
+static int bi_release(void* u, void* p) { return apk_device_free(((apk_comm*)u)->ctx, p); }
+static int bi_copy(void* u, void* d, const void* s, size_t b, int kind) {
+    apk_ctx* c = ((apk_comm*)u)->ctx;
+    return kind == 0 ? apk_device_copy(c, d, s, b) : kind == 1 ? apk_device_upload(c, d, s, b) : apk_device_download(c, d, s, b);
+}
+
+static void resolve_compute(apk_comm* c) {
+    apk_compute t{};
+    t.user = c; t.msm_batch = bi_msm; t.coset_ntt = bi_coset; t.alloc = bi_alloc; t.release = bi_release; t.copy = bi_copy;
+    t.g1_bytes = c->ctx ? apk_g1_bytes(c->ctx->curve) : 0;
+    t.n = c->ctx ? c->ctx->be->domain_size() : 0;
+    c->device_is_host = false;
+    if (c->have_user_cp) {
+        const apk_compute& u = c->user_cp;
+        // a replaced entry runs with the table's own user pointer; mixing built-in and replaced entries is allowed
+        if (u.msm_batch) t.msm_batch = u.msm_batch;
+        if (u.coset_ntt) t.coset_ntt = u.coset_ntt;
+        if (u.alloc) t.alloc = u.alloc;
+        if (u.release) t.release = u.release;
+        if (u.copy) { t.copy = u.copy; c->device_is_host = true; }
+        if (u.g1_bytes) t.g1_bytes = u.g1_bytes;
+        if (u.n) t.n = u.n;
+    }
+    c->cp = t;
+}
+// the user pointer an entry runs with: replaced entries get the table's, built-in ones the communicator
+#define CP_USER(c, field) ((c)->have_user_cp && (c)->user_cp.field ? (c)->user_cp.user : (void*)(c))
+
+static int ensure(apk_comm* c, void** p, size_t* cap, size_t need) {
+    if (*cap >= need && *p) return APK_OK;
+    if (*p) { (void)c->cp.release(CP_USER(c, release), *p); *p = nullptr; *cap = 0; }
+    const size_t want = need + need / 8 + 256;
+    CHK(c->cp.alloc(CP_USER(c, alloc), want, p));
+    *cap = want;
+    return APK_OK;
+}
+
+// ---- control-plane collectives (host memory) ------------------------------------------------------------------------------------
+static int ctl_bcast(apk_comm* c, void* buf, size_t n) {
+    if (c->world == 1) return APK_OK;
+    if (c->rank == 0) { for (int r = 1; r < c->world; r++) CHK(send_all(c->peer[r], buf, n)); return APK_OK; }
+    return recv_all(c->peer[0], buf, n);
+}
+static int ctl_allgather(apk_comm* c, const void* mine, void* all, size_t n) {
+    memcpy((uint8_t*)all + (size_t)c->rank * n, mine, n);
+    if (c->world == 1) return APK_OK;
+    if (c->rank == 0) {
+        for (int r = 1; r < c->world; r++) CHK(recv_all(c->peer[r], (uint8_t*)all + (size_t)r * n, n));
+        for (int r = 1; r < c->world; r++) CHK(send_all(c->peer[r], all, n * c->world));
+        return APK_OK;
+    }
+    CHK(send_all(c->peer[0], mine, n));
+    return recv_all(c->peer[0], all, n * c->world);
+}
+
+// ---- data-plane: scatter of per-rank chunks held by rank 0; peer copies between rank 0 and one worker -------------------------
+// d_all (rank 0): world x chunk bytes, rank r's chunk at r * chunk; d_mine: chunk bytes on every rank (rank 0: unused, its share
+// is read in place).
+static int data_scatter(apk_comm* c, const void* d_all, void* d_mine, size_t chunk) {
+    if (c->world == 1 || chunk == 0) return APK_OK;
+    if (c->rccl) {
+        HCHK(hipSetDevice(c->device));
+        NCHK(g_rccl.GroupStart());
+        if (c->rank == 0) {
+            for (int r = 1; r < c->world; r++) NCHK(g_rccl.Send((const uint8_t*)d_all + (size_t)r * chunk, chunk, ncclUint8, r, c->nccl, c->stream));
+        } else {
+            NCHK(g_rccl.Recv(d_mine, chunk, ncclUint8, 0, c->nccl, c->stream));
+        }
+        NCHK(g_rccl.GroupEnd());
+        HCHK(hipStreamSynchronize(c->stream));
+        return APK_OK;
+    }
+    if (c->h_stage.size() < chunk) c->h_stage.resize(chunk);
+    if (c->rank == 0) {
+        for (int r = 1; r < c->world; r++) {
+            CHK(c->cp.copy(CP_USER(c, copy), c->h_stage.data(), (const uint8_t*)d_all + (size_t)r * chunk, chunk, 2));
+            CHK(send_all(c->peer[r], c->h_stage.data(), chunk));
+        }
+        return APK_OK;
+    }
+    CHK(recv_all(c->peer[0], c->h_stage.data(), chunk));
+    return c->cp.copy(CP_USER(c, copy), d_mine, c->h_stage.data(), chunk, 1);
+}
+// rank 0 <-> worker w: `to_worker` says which way the bytes flow.  Called on rank 0 and on w only.
+static int data_p2p(apk_comm* c, int w, bool to_worker, void* d_buf, size_t bytes) {
+    const bool sending = (c->rank == 0) == to_worker;
+    if (c->rccl) {
+        HCHK(hipSetDevice(c->device));
+        const int other = c->rank == 0 ? w : 0;
+        NCHK(g_rccl.GroupStart());
+        if (sending) NCHK(g_rccl.Send(d_buf, bytes, ncclUint8, other, c->nccl, c->stream));
+        else NCHK(g_rccl.Recv(d_buf, bytes, ncclUint8, other, c->nccl, c->stream));
+        NCHK(g_rccl.GroupEnd());
+        HCHK(hipStreamSynchronize(c->stream));
+        return APK_OK;
+    }
+    if (c->h_stage.size() < bytes) c->h_stage.resize(bytes);
+    const int fd = c->fd_of(w);
+    if (sending) {
+        CHK(c->cp.copy(CP_USER(c, copy), c->h_stage.data(), d_buf, bytes, 2));
+        return send_all(fd, c->h_stage.data(), bytes);
+    }
+    CHK(recv_all(fd, c->h_stage.data(), bytes));
+    return c->cp.copy(CP_USER(c, copy), d_buf, c->h_stage.data(), bytes, 1);
+}
+
+// ---- schedules ---------------------------------------------------------------------------------------------------------------------
+// One commitment batch, every rank.  d_scalars only on rank 0.  out_points (count affine points) on rank 0.
+static int commit_round(apk_comm* c, int basis, uint32_t count, const uint32_t* lens, const void* const* d_scalars, void* out_points) {
+    const size_t nb = c->cp.g1_bytes;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < count; i++) total += lens[i];
+    const size_t chunk = (size_t)((total + c->world - 1) / c->world) * APK_FR_BYTES;
+    // rank 0 reads its own share in place; the workers' slices are packed into the staging buffer and scattered
+    if (c->world > 1) {
+        CHK(ensure(c, &c->d_stage, &c->stage_cap, c->rank == 0 ? chunk * c->world : chunk));
+        if (c->rank == 0)
+            for (int r = 1; r < c->world; r++) {
+                size_t at = (size_t)r * chunk;
+                for (const Seg& s : deal(lens, count, r, c->world)) {
+                    const size_t bytes = (size_t)(s.hi - s.lo) * APK_FR_BYTES;
+                    CHK(c->cp.copy(CP_USER(c, copy), (uint8_t*)c->d_stage + at, (const uint8_t*)d_scalars[s.k] + s.lo * APK_FR_BYTES, bytes, 0));
+                    at += bytes;
+                }
+            }
+        CHK(data_scatter(c, c->d_stage, c->d_stage, chunk));
+    }
+    // this rank's partial sums: status word + count points (infinity = all zero where the rank holds no part of a commitment)
+    const std::vector<Seg> segs = deal(lens, count, c->rank, c->world);
+    const size_t rec = 8 + (size_t)count * nb;
+    std::vector<uint8_t> mine(rec, 0), all(rec * c->world, 0);
+    int32_t status = APK_OK;
+    std::string err;
+    if (!segs.empty()) {
+        const void* ptrs[4]; uint64_t offs[4], ls[4];
+        size_t at = 0;
+        for (size_t i = 0; i < segs.size(); i++) {
+            const Seg& s = segs[i];
+            ptrs[i] = c->rank == 0 ? (const uint8_t*)d_scalars[s.k] + s.lo * APK_FR_BYTES : (const uint8_t*)c->d_stage + at;
+            offs[i] = s.lo; ls[i] = s.hi - s.lo;
+            at += (size_t)(s.hi - s.lo) * APK_FR_BYTES;
+        }
+        std::vector<uint8_t> res(segs.size() * nb);
+        status = c->cp.msm_batch(CP_USER(c, msm_batch), basis, (uint32_t)segs.size(), ptrs, offs, ls, res.data());
+        if (status == APK_OK) for (size_t i = 0; i < segs.size(); i++) memcpy(mine.data() + 8 + segs[i].k * nb, res.data() + i * nb, nb);
+        else err = apk_last_error();
+    }
+    memcpy(mine.data(), &status, 4);
+    CHK(ctl_allgather(c, mine.data(), all.data(), rec));
+    for (int r = 0; r < c->world; r++) {
+        int32_t st;
+        memcpy(&st, all.data() + (size_t)r * rec, 4);
+        if (st != APK_OK) { set_error("comm: rank %d failed its share of the commitment batch (code %d)%s%s", r, st, r == c->rank ? ": " : "", r == c->rank ? err.c_str() : ""); return st; }
+    }
+    c->steps++;
+    if (c->rank != 0) return APK_OK;
+    std::vector<uint8_t> col((size_t)c->world * nb);
+    for (uint32_t k = 0; k < count; k++) {
+        for (int r = 0; r < c->world; r++) memcpy(col.data() + (size_t)r * nb, all.data() + (size_t)r * rec + 8 + k * nb, nb);
+        CHK(apk_g1_sum(c->ctx ? c->ctx->curve : (nb == 64 ? APK_BN254 : APK_BLS12_381), col.data(), c->world, (uint8_t*)out_points + k * nb));
+    }
+    return APK_OK;
+}
+
+// The 4n-coset evaluations of `count` canonical polynomials, polynomial i on rank i mod world.
+static int wires_round(apk_comm* c, uint32_t count, const uint32_t* lens, const void* const* d_can, void* const* d_ev) {
+    const size_t ev_bytes = (size_t)4 * c->cp.n * APK_FR_BYTES;
+    int32_t status = APK_OK;
+    if (c->rank == 0) {
+        // send the dealt polynomials first (their owners start while this rank transforms its own), then collect
+        for (uint32_t i = 0; i < count; i++)
+            if (i % c->world) CHK(data_p2p(c, i % c->world, true, const_cast<void*>(d_can[i]), (size_t)lens[i] * APK_FR_BYTES));
+        for (uint32_t i = 0; i < count; i++)
+            if (i % c->world == 0 && status == APK_OK) status = c->cp.coset_ntt(CP_USER(c, coset_ntt), d_can[i], lens[i], d_ev[i]);
+        for (uint32_t i = 0; i < count; i++)
+            if (i % c->world) {
+                int32_t st = APK_OK;
+                CHK(recv_all(c->peer[i % c->world], &st, 4));
+                if (st != APK_OK) { if (status == APK_OK) { status = st; set_error("comm: rank %u failed the coset evaluation of wire %u (code %d)", i % c->world, i, st); } continue; }
+                CHK(data_p2p(c, i % c->world, false, d_ev[i], ev_bytes));
+            }
+    } else {
+        for (uint32_t i = 0; i < count; i++)
+            if ((int)(i % c->world) == c->rank) {
+                CHK(ensure(c, &c->d_wire_in, &c->wire_in_cap, (size_t)lens[i] * APK_FR_BYTES));
+                CHK(ensure(c, &c->d_wire_out, &c->wire_out_cap, ev_bytes));
+                CHK(data_p2p(c, c->rank, true, c->d_wire_in, (size_t)lens[i] * APK_FR_BYTES));
+                int32_t st = c->cp.coset_ntt(CP_USER(c, coset_ntt), c->d_wire_in, lens[i], c->d_wire_out);
+                CHK(send_all(c->peer[0], &st, 4));
+                if (st == APK_OK) CHK(data_p2p(c, c->rank, false, c->d_wire_out, ev_bytes));
+                else status = st;
+            }
+    }
+    c->steps++;
+    return status;
+}
+
+static int hook_commit(void* u, int basis, uint32_t count, const void* const* d_scalars, const uint32_t* lens, void* out_points) {
+    return apk_comm_commit((apk_comm*)u, basis, count, d_scalars, lens, out_points);
+}
+static int hook_wires(void* u, uint32_t count, const void* const* d_can, const uint32_t* lens, void* const* d_ev) {
+    return apk_comm_wires((apk_comm*)u, count, d_can, lens, d_ev);
+}
+
+extern "C" {
+
+int apk_comm_create(int rank, int world, const char* addr, int port, apk_comm** out) {
+    if (!out || world < 1 || rank < 0 || rank >= world || world > 64) { set_error("comm: bad rank / world"); return APK_ERR_ARG; }
+    apk_comm* c = new apk_comm();
+    c->rank = rank; c->world = world;
+    c->timeout_s = env_int("APK_COMM_TIMEOUT_S", 300, 1, 86400);
+    if (world == 1) { *out = c; return APK_OK; }
+    if (!addr || port <= 0 || port > 65535) { delete c; set_error("comm: address / port"); return APK_ERR_ARG; }
+    struct sockaddr_in sa{};
+    sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)port);
+    if (inet_pton(AF_INET, addr, &sa.sin_addr) != 1) { delete c; set_error("comm: '%s' is not an IPv4 address", addr); return APK_ERR_ARG; }
+    if (rank == 0) {
+        c->peer.assign(world, -1);
+        c->listen_fd = socket(AF_INET, SOCK_STREAM, 0);
+        int one = 1;
+        setsockopt(c->listen_fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+        if (bind(c->listen_fd, (struct sockaddr*)&sa, sizeof sa) != 0 || listen(c->listen_fd, world) != 0) {
+            set_error("comm: cannot listen on %s:%d: %s", addr, port, strerror(errno));
+            apk_comm_destroy(c);
+            return APK_ERR_STATE;
+        }
+        struct timeval tv = {c->timeout_s, 0};
+        setsockopt(c->listen_fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+        for (int i = 1; i < world; i++) {
+            const int fd = accept(c->listen_fd, nullptr, nullptr);
+            if (fd < 0) { set_error("comm: rank 0 waited %d s for %d more rank(s): %s", c->timeout_s, world - i, strerror(errno)); apk_comm_destroy(c); return APK_ERR_STATE; }
+            tune(fd, c->timeout_s);
+            int32_t r = -1;
+            if (recv_all(fd, &r, 4) != APK_OK || r <= 0 || r >= world || c->peer[r] != -1) { close(fd); set_error("comm: bad hello from a peer"); apk_comm_destroy(c); return APK_ERR_STATE; }
+            c->peer[r] = fd;
+        }
+    } else {
+        c->peer.assign(1, -1);
+        const double deadline = (double)c->timeout_s;
+        double waited = 0;
+        for (;;) {
+            const int fd = socket(AF_INET, SOCK_STREAM, 0);
+            if (connect(fd, (struct sockaddr*)&sa, sizeof sa) == 0) { c->peer[0] = fd; break; }
+            close(fd);
+            if (waited >= deadline) { set_error("comm: rank %d could not reach rank 0 at %s:%d: %s", rank, addr, port, strerror(errno)); apk_comm_destroy(c); return APK_ERR_STATE; }
+            usleep(50 * 1000); waited += 0.05;
+        }
+        tune(c->peer[0], c->timeout_s);
+        int32_t r = rank;
+        if (send_all(c->peer[0], &r, 4) != APK_OK) { apk_comm_destroy(c); return APK_ERR_STATE; }
+    }
+    *out = c;
+    return APK_OK;
+}
+
+void apk_comm_destroy(apk_comm* c) {
+    if (!c) return;
+    if (c->split_on && c->rank == 0) (void)apk_comm_split_end(c);
+    if (c->cp.release) {
+        if (c->d_stage) (void)c->cp.release(CP_USER(c, release), c->d_stage);
+        if (c->d_wire_in) (void)c->cp.release(CP_USER(c, release), c->d_wire_in);
+        if (c->d_wire_out) (void)c->cp.release(CP_USER(c, release), c->d_wire_out);
+    }
+    if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (int fd : c->peer) if (fd >= 0) close(fd);
+    if (c->listen_fd >= 0) close(c->listen_fd);
+    delete c;
+}
+
+int apk_comm_rank(const apk_comm* c) { return c ? c->rank : -1; }
+int apk_comm_world(const apk_comm* c) { return c ? c->world : 0; }
+const char* apk_comm_transport(const apk_comm* c) { return c && c->rccl ? "rccl" : "tcp"; }
+
+int apk_comm_barrier(apk_comm* c) {
+    if (!c) { set_error("null communicator"); return APK_ERR_ARG; }
+    uint8_t one = 1;
+    std::vector<uint8_t> all(c->world);
+    return ctl_allgather(c, &one, all.data(), 1);
+}
+
+int apk_comm_max_f64(apk_comm* c, double* v) {
+    if (!c || !v) { set_error("null argument"); return APK_ERR_ARG; }
+    std::vector<double> all(c->world);
+    CHK(ctl_allgather(c, v, all.data(), sizeof(double)));
+    for (double x : all) if (x > *v) *v = x;
+    return APK_OK;
+}
+
+int apk_comm_set_compute(apk_comm* c, const apk_compute* t) {
+    if (!c) { set_error("null communicator"); return APK_ERR_ARG; }
+    c->have_user_cp = t != nullptr;
+    if (t) c->user_cp = *t;
+    resolve_compute(c);
+    return APK_OK;
+}
+
+int apk_comm_bind(apk_comm* c, apk_ctx* ctx) {
+    if (!c) { set_error("null communicator"); return APK_ERR_ARG; }
+    c->ctx = ctx;
+    resolve_compute(c);
+    if (!ctx && !(c->have_user_cp && c->user_cp.msm_batch)) { set_error("comm: no context and no compute table"); return APK_ERR_ARG; }
+    // data plane: RCCL when every rank owns a different GPU; the ranks agree through the control plane
+    c->rccl = false;
+    int32_t dev = -1;
+    if (ctx && !c->device_is_host) dev = ctx->be->device_ordinal();
+    int32_t can = (c->world > 1 && dev >= 0 && env_int("APK_COMM_RCCL", 1, 0, 1) && g_rccl.load()) ? 1 : 0;
+    std::vector<int32_t> devs(c->world), cans(c->world);
+    CHK(ctl_allgather(c, &dev, devs.data(), 4));
+    CHK(ctl_allgather(c, &can, cans.data(), 4));
+    bool all_can = c->world > 1;
+    for (int r = 0; r < c->world; r++) {
+        all_can = all_can && cans[r];
+        for (int q = 0; q < r; q++) if (devs[q] == devs[r]) all_can = false;   // RCCL refuses two ranks on one device (single node)
+    }
+    if (all_can && !c->nccl) {
+        ncclUniqueId id{};
+        if (c->rank == 0) NCHK(g_rccl.GetUniqueId(&id));
+        CHK(ctl_bcast(c, &id, sizeof id));
+        c->device = dev;
+        HCHK(hipSetDevice(dev));
+        HCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        NCHK(g_rccl.CommInitRank(&c->nccl, c->world, id, c->rank));
+    }
+    c->rccl = all_can && c->nccl;
+    return APK_OK;
+}
+
+int apk_msm_g1_sharded(apk_comm* c, const void* d_scalars, uint64_t len, void* out) {
+    if (!c || !out || !c->cp.msm_batch) { set_error("comm: not bound"); return APK_ERR_ARG; }
+    const size_t nb = c->cp.g1_bytes, rec = 8 + nb;
+    std::vector<uint8_t> mine(rec, 0), all(rec * c->world, 0);
+    int32_t status = APK_OK;
+    std::string err;
+    if (len) {
+        const void* p[1] = {d_scalars}; const uint64_t off[1] = {0}, ls[1] = {len};
+        status = c->cp.msm_batch(CP_USER(c, msm_batch), 0, 1, p, off, ls, mine.data() + 8);
+        if (status != APK_OK) err = apk_last_error();
+    }
+    memcpy(mine.data(), &status, 4);
+    CHK(ctl_allgather(c, mine.data(), all.data(), rec));       // the ONE exchange step: a 64/96-byte point per rank
+    std::vector<uint8_t> pts((size_t)c->world * nb);
+    for (int r = 0; r < c->world; r++) {
+        int32_t st;
+        memcpy(&st, all.data() + (size_t)r * rec, 4);
+        if (st != APK_OK) { set_error("comm: rank %d failed its slice of the sharded MSM (code %d)%s%s", r, st, r == c->rank ? ": " : "", r == c->rank ? err.c_str() : ""); return st; }
+        memcpy(pts.data() + (size_t)r * nb, all.data() + (size_t)r * rec + 8, nb);
+    }
+    c->steps++;
+    return apk_g1_sum(c->ctx ? c->ctx->curve : (nb == 64 ? APK_BN254 : APK_BLS12_381), pts.data(), c->world, out);
+}
+
+int apk_comm_commit(apk_comm* c, int basis, uint32_t count, const void* const* d_scalars, const uint32_t* lens, void* out_points) {
+    if (!c || c->rank != 0 || !count || count > 4 || !d_scalars || !lens || !out_points) { set_error("comm: commit is the leader's call (1..4 commitments)"); return APK_ERR_ARG; }
+    Header h{};
+    h.op = OP_COMMIT; h.basis = basis; h.count = count;
+    for (uint32_t i = 0; i < count; i++) h.lens[i] = lens[i];
+    CHK(ctl_bcast(c, &h, sizeof h));
+    return commit_round(c, basis, count, h.lens, d_scalars, out_points);
+}
+
+int apk_comm_wires(apk_comm* c, uint32_t count, const void* const* d_can, const uint32_t* lens, void* const* d_ev) {
+    if (!c || c->rank != 0 || !count || count > 4 || !d_can || !lens || !d_ev) { set_error("comm: wires is the leader's call (1..4 polynomials)"); return APK_ERR_ARG; }
+    Header h{};
+    h.op = OP_WIRES; h.count = count;
+    for (uint32_t i = 0; i < count; i++) h.lens[i] = lens[i];
+    CHK(ctl_bcast(c, &h, sizeof h));
+    return wires_round(c, count, h.lens, d_can, d_ev);
+}
+
+int apk_comm_split_begin(apk_comm* c) {
+    if (!c || c->rank != 0 || !c->ctx) { set_error("comm: split_begin is the leader's call on a bound circuit context"); return APK_ERR_ARG; }
+    CHK(apk_ctx_set_commit_hook(c->ctx, hook_commit, c));
+    if (env_int("APK_SPLIT_WIRES", 0, 0, 1) && c->world > 1) {
+        if (!c->cp.n) { set_error("comm: the compute table does not state the domain size"); return APK_ERR_STATE; }
+        CHK(apk_ctx_set_wire_hook(c->ctx, hook_wires, c));
+    }
+    c->split_on = true;
+    return APK_OK;
+}
+
+int apk_comm_split_end(apk_comm* c) {
+    if (!c || c->rank != 0) { set_error("comm: split_end is the leader's call"); return APK_ERR_ARG; }
+    if (c->ctx) { (void)apk_ctx_set_commit_hook(c->ctx, nullptr, nullptr); (void)apk_ctx_set_wire_hook(c->ctx, nullptr, nullptr); }
+    c->split_on = false;
+    Header h{};
+    h.op = OP_STOP;
+    return ctl_bcast(c, &h, sizeof h);
+}
+
+int apk_comm_serve(apk_comm* c, uint64_t* steps_served) {
+    if (!c || c->rank == 0) { set_error("comm: serve is the workers' call"); return APK_ERR_ARG; }
+    for (;;) {
+        Header h{};
+        CHK(ctl_bcast(c, &h, sizeof h));
+        if (h.op == OP_STOP) break;
+        if (h.count == 0 || h.count > 4) { set_error("comm: malformed header"); return APK_ERR_STATE; }
+        int rc;
+        if (h.op == OP_COMMIT) rc = commit_round(c, h.basis, h.count, h.lens, nullptr, nullptr);
+        else if (h.op == OP_WIRES) rc = wires_round(c, h.count, h.lens, nullptr, nullptr);
+        else { set_error("comm: unknown step %d", h.op); return APK_ERR_STATE; }
+        // a failed step was reported to every rank of the step; the worker stays in the loop for the leader's next call
+        (void)rc;
+    }
+    if (steps_served) *steps_served = c->steps;
+    return APK_OK;
+}
+
+}  // extern "C"

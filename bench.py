@@ -23,7 +23,7 @@ Modes:
                      partial MSMs, all-gather of the partial sums), transcript on rank 0; strong scaling - meant for
                      --curve bls12_381 --log-n 21;
   launcher-selftest: NOT a measurement - the launcher, rendezvous, barrier / MAX reduction and JSON plumbing with a no-op
-                     step on gloo (CPU tier test of this file).
+                     step (CPU tier test of this file).
 
 Extra objects on the JSON line (prompt ④): `roofline` for the dominant kernel (msm_accumulate_kernel, HIP events on the
 stream it runs on, algorithmic bytes = 96 B per (scalar, point) pair on BN254; `traffic` = HBM bytes per launch from
@@ -99,38 +99,32 @@ def maybe_self_launch(args, argv) -> bool:
 
 
 class Ranks:
-    """RANK / LOCAL_RANK / WORLD_SIZE + the barrier / MAX-over-ranks timing of the contract."""
+    """RANK / LOCAL_RANK / WORLD_SIZE + the barrier / MAX-over-ranks timing of the contract, on libapk's OWN communicator
+    (include/apk.h apk_comm_*: TCP control plane, RCCL data plane) - no torch in the process, hence no second HIP runtime.
+    The launcher (torchrun) only exports the environment.  Every library call of a step returns its result to the host, so the
+    device is idle when a step returns: the barrier alone brackets the timed region the way barrier + synchronize would."""
 
-    def __init__(self, args, backend: str):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
+    def __init__(self, args, need_gpu: bool = True):
+        from algoplonk_amd import _lib, parallel
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.backend = backend
         if self.world != args.gpus:
             raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world))
-        self.cuda = backend == "nccl"
-        if self.cuda:
-            if not torch.cuda.is_available():
+        if need_gpu:
+            ndev = _lib.device_count()
+            if ndev == 0:
                 raise SystemExit("bench.py needs an MI355X: no HIP device visible (the HIP path has no CPU fallback)")
-            torch.cuda.set_device(self.local_rank)
-        if self.world > 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if self.cuda:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
-            else:
-                dist.init_process_group("gloo")
+            if self.local_rank >= ndev:
+                raise SystemExit("bench.py: LOCAL_RANK %d but only %d HIP device(s) visible" % (self.local_rank, ndev))
+        self.comm = parallel.Comm.from_env()
+        self.backend = "libapk comm"
 
     def fence(self):
-        if self.world > 1:
-            self.dist.barrier()
-        if self.cuda:
-            self.torch.cuda.synchronize()
+        self.comm.barrier()
 
     def timed(self, step, steps: int, warmup: int) -> float:
-        """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize; MAX over ranks."""
+        """W untimed steps, then EXACTLY K steps bracketed by barriers; MAX over ranks."""
         for _ in range(warmup):
             step()
         self.fence()
@@ -138,16 +132,10 @@ class Ranks:
         for _ in range(steps):
             step()
         self.fence()
-        elapsed = time.perf_counter() - t1
-        if self.world > 1:
-            t = self.torch.tensor([elapsed], dtype=self.torch.float64, device="cuda" if self.cuda else "cpu")
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        return elapsed
+        return self.comm.max(time.perf_counter() - t1)
 
     def close(self):
-        if self.world > 1:
-            self.dist.destroy_process_group()
+        self.comm.close()
 
 
 # ---------------------------------------------------------------------------------------------------- probes
@@ -236,7 +224,7 @@ def main(argv=None) -> None:
         return
     if args.mode == "launcher-selftest":
         return launcher_selftest(args)
-    rk = Ranks(args, "nccl")
+    rk = Ranks(args)
     from algoplonk_amd import ecc
     cv = ecc.BN254 if args.curve == "bn254" else ecc.BLS12_381
     if args.mode == "msm-sharded":
@@ -247,10 +235,11 @@ def main(argv=None) -> None:
 
 
 def bench_prove_split(args, cv, rk) -> None:
-    """One proof at a time on N GPUs: every rank holds the circuit context; rank 0 proves with its commitments routed through
-    SplitCommitter, the other ranks serve.  A step = one proof; value = proofs/s of the whole job (strong scaling)."""
+    """One proof at a time on N GPUs: every rank holds the circuit context; rank 0 proves with its commitment batches (and,
+    with APK_SPLIT_WIRES=1, its per-wire coset evaluations) dealt to the ranks by libapk's communicator, the other ranks serve
+    (apk_comm_split_begin / apk_comm_serve, csrc/comm.cpp).  A step = one proof; value = proofs/s of the whole job (strong)."""
     import hashlib
-    from algoplonk_amd import _lib, frontend, parallel, plonk, setup, workloads, MarshalProof
+    from algoplonk_amd import _lib, frontend, plonk, setup, workloads, MarshalProof
     from algoplonk_amd._lib import lib, check
 
     seed = 0xA190 if args.curve == "bn254" else 0xA193
@@ -258,7 +247,7 @@ def bench_prove_split(args, cv, rk) -> None:
     n = wl.ccs.domain_size()
     srs = setup.unsafe_srs(cv, n, wl.tau, device=rk.local_rank)
     pk, vk = plonk.Setup(wl.ccs, srs, device=rk.local_rank, msm_window=args.msm_window, slots=1)
-    sc = parallel.SplitCommitter(cv, pk.ctx, rk.rank, rk.world)
+    rk.comm.bind(pk.ctx)
     line = None
     if rk.rank == 0:
         L, R, O = frontend.wire_columns(wl.ccs, wl.solution)
@@ -277,31 +266,28 @@ def bench_prove_split(args, cv, rk) -> None:
 
         step()                                    # single-GPU reference proof (no hook) for the byte comparison
         want = MarshalProof(plonk.Proof(cv, proof))
-        sc.install()
+        rk.comm.split_begin()
         for _ in range(args.warmup):
             step()
-        rk.torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step()
-        rk.torch.cuda.synchronize()
         elapsed = time.perf_counter() - t1
         got = MarshalProof(plonk.Proof(cv, proof))
-        batches = sc.batches
-        sc.stop()
+        rk.comm.split_end()
         line = {
             "metric": "proofs/sec", "value": round(args.steps / elapsed, 4), "unit": "proofs/sec", "n_gpus": rk.world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u32x8 Fr / u32x12 Fp (Montgomery)" if cv.name != "bn254" else "u32x8 (Montgomery Fr/Fp)", "data": "synthetic",
             "config": {"workload": wl.name + ", one proof at a time", "log_n": args.log_n, "curve": cv.name,
-                       "parallelism": "commitment batches dealt by index range x%d (scatter + all-gather of partial sums), transcript on rank 0" % rk.world,
-                       "world_size": rk.world, "backend": "nccl (RCCL)" if rk.world > 1 else "single process"},
-            "commit_batches_per_proof": batches // (args.steps + args.warmup),
+                       "parallelism": "commitment batches dealt by index range x%d (scatter + all-gather of partial sums)%s, transcript on rank 0"
+                                      % (rk.world, ", wires dealt by polynomial" if os.environ.get("APK_SPLIT_WIRES") == "1" else ""),
+                       "world_size": rk.world, "backend": "libapk comm: tcp control plane, %s data plane" % rk.comm.transport},
             "proof_sha256_prefix": hashlib.sha256(got).hexdigest()[:16], "matches_single_gpu_proof": got == want,
         }
     else:
-        sc.serve()
-    # the contract's barrier + MAX over ranks: the leader's clock covers every rank's work (workers only serve its rounds)
+        rk.comm.serve()
+    # the contract's barrier: the leader's clock covers every rank's work (workers only serve its steps)
     rk.fence()
     if rk.rank == 0:
         print(json.dumps(line), flush=True)
@@ -309,7 +295,7 @@ def bench_prove_split(args, cv, rk) -> None:
 
 
 def launcher_selftest(args) -> None:
-    rk = Ranks(args, "gloo")
+    rk = Ranks(args, need_gpu=False)
     state = {"n": 0}
 
     def step():
@@ -443,12 +429,10 @@ def bench_prove(args, cv, rk) -> None:
     out_pt = C.create_string_buffer(2 * cv.fp_bytes)
     for _ in range(3):
         check(lib.apk_msm_g1_device(pk.ctx, 0, dptr[0], n, out_pt))
-    rk.torch.cuda.synchronize()
     reps = 20
     m0 = time.perf_counter()
     for _ in range(reps):
         check(lib.apk_msm_g1_device(pk.ctx, 0, dptr[0], n, out_pt))
-    rk.torch.cuda.synchronize()
     msm_s = (time.perf_counter() - m0) / reps
     msm_mscalar = n / msm_s / 1e6
     # the same MSM with the device kept busy: 16 callers (one per proving slot), each issuing its MSMs back to back - the rate
@@ -498,7 +482,7 @@ def bench_prove(args, cv, rk) -> None:
             "data": "synthetic",
             "config": {"workload": name, "log_n": args.log_n, "curve": cv.name, "proofs_per_step": args.inflight,
                        "srs": "synthetic tau=SHA256(seed)", "parallelism": "replicas x%d" % rk.world, "world_size": rk.world,
-                       "backend": "nccl (RCCL)" if rk.world > 1 else "single process"},
+                       "backend": ("libapk comm: tcp control plane, %s data plane" % rk.comm.transport) if rk.world > 1 else "single process"},
             "proof_latency_ms": round(lat_ms, 3), "msm_mscalar_per_s": round(msm_mscalar, 3),
             "msm_ms": round(msm_s * 1e3, 4), "msm_mscalar_per_s_saturated": round(msm_sat_mscalar, 3), "setup_s": round(setup_s, 2),
             "msm_batch_avg_ms": round(st.msm_total_ms / max(st.msm_batches, 1), 4),
@@ -512,7 +496,7 @@ def bench_prove(args, cv, rk) -> None:
 def bench_sharded_msm(args, cv, rk) -> None:
     """BASELINE.json configs[3]: one 2^log_n MSM (seed 0xA192, uniform scalars, SRS-shaped points) sharded by index range:
     every rank keeps the windowed tables of its slice resident, computes a full partial sum, then ONE all-gather of a
-    64/96-byte point per rank + world-1 host point additions (algoplonk_amd/parallel.py).  Strong scaling."""
+    64/96-byte point per rank + world-1 host point additions (apk_msm_g1_sharded, csrc/comm.cpp).  Strong scaling."""
     from algoplonk_amd import parallel, plonk, setup, workloads
     from algoplonk_amd import _lib
     from algoplonk_amd._lib import lib, check
@@ -523,17 +507,14 @@ def bench_sharded_msm(args, cv, rk) -> None:
     srs = setup.unsafe_srs(cv, n, tau, device=rk.local_rank)
     scalars = cv.fr_vector([g.fr(cv.r) for _ in range(n)])
     bases = srs.g1[: n * 2 * cv.fp_bytes]
-    sm = parallel.ShardedMsm(cv, bases, device=rk.local_rank, rank=rk.rank, world=rk.world, msm_window=args.msm_window)
-    mine = scalars[sm.lo * 32: sm.hi * 32]
-    d = C.c_void_p()
-    check(lib.apk_device_alloc(sm._ctx, len(mine), C.byref(d)))
-    check(lib.apk_device_upload(sm._ctx, d, mine, len(mine)))
+    sm = parallel.ShardedMsm(cv, bases, device=rk.local_rank, comm=rk.comm, msm_window=args.msm_window)
+    sm.upload(scalars)                            # this rank's slice of the scalars resident in HBM
+    d = sm._d
     out = C.create_string_buffer(2 * cv.fp_bytes)
     res = [b""]
 
     def step():
-        check(lib.apk_msm_g1_device(sm._ctx, 0, d, sm.hi - sm.lo, out))
-        res[0] = parallel.gather_and_add(cv, out.raw) if rk.world > 1 else out.raw
+        res[0] = sm.run()                         # apk_msm_g1_sharded: local MSM, ONE all-gather of a point per rank, local additions
 
     elapsed = rk.timed(step, args.steps, args.warmup)
     # dominant kernel of this rank's share, HIP events on its stream
@@ -562,7 +543,7 @@ def bench_sharded_msm(args, cv, rk) -> None:
             "scaling": "strong", "vs_baseline": None, "dtype": "u29x9 Fp (BN254) / u28x14 Fp (BLS12-381) unsaturated Montgomery",
             "data": "synthetic", "config": {"workload": "%s single MSM 2^%d sharded by index range" % (cv.name, args.log_n),
                                             "parallelism": "index-range x%d + all-gather of %d-byte points" % (rk.world, 2 * cv.fp_bytes),
-                                            "world_size": rk.world, "backend": "nccl (RCCL)" if rk.world > 1 else "single process"},
+                                            "world_size": rk.world, "backend": ("libapk comm: tcp control plane, %s data plane" % rk.comm.transport) if rk.world > 1 else "single process"},
             "result_sha256_prefix": hashlib.sha256(res[0]).hexdigest()[:16],
             "roofline": roofline_from_stats(args, cv, st, pmc), "cpu_baseline": cpu_baseline}), flush=True)
     rk.close()

@@ -158,6 +158,69 @@ int apk_prove_device(apk_ctx* ctx, const void* d_L, const void* d_R, const void*
  * runs the launches the prover queued behind the batch.  Return APK_OK or an error code.  NULL removes the hook. */
 typedef int (*apk_commit_hook)(void* user, int basis, uint32_t count, const void* const* d_scalars, const uint32_t* lens, void* out_points);
 int apk_ctx_set_commit_hook(apk_ctx* ctx, apk_commit_hook hook, void* user);
+/* Same idea for the per-wire transforms of round 1 ("per-wire NTTs batch across the GPUs", BASELINE.json north_star): with a
+ * wire hook installed the prover does not run the 4n-coset evaluations of l, r, o itself; it hands the hook the `count` blinded
+ * canonical polynomials (device memory of this context, lens[i] Fr) and expects d_evals[i] (4n Fr each, device memory of this
+ * context) filled when the hook returns.  apk_coset_ntt_device is what a rank runs on the polynomial it was dealt. */
+typedef int (*apk_wire_hook)(void* user, uint32_t count, const void* const* d_canonical, const uint32_t* lens, void* const* d_evals);
+int apk_ctx_set_wire_hook(apk_ctx* ctx, apk_wire_hook hook, void* user);
+int apk_coset_ntt_device(apk_ctx* ctx, const void* d_canonical, uint64_t len, void* d_evals);
+
+/* ---- multi-GPU behind the boundary: one process per GPU, libapk's own communicator ---------------------
+ * The reference's host is Go (algoplonk.go:89): a cgo caller cannot use a Python process group, so the exchange steps of the
+ * path live here.  An apk_comm is one rank of `world` cooperating processes.
+ *   control plane : a TCP star through rank 0 (rendezvous, headers, the 64/96-byte partial sums, barriers) - apk_comm_create;
+ *   data plane    : RCCL over xGMI on libapk's OWN HIP runtime and stream (ncclSend/ncclRecv groups for the scatter of scalar
+ *                   slices and the peer copies of polynomials; librccl is dlopen'ed by apk_comm_bind when world > 1, each rank
+ *                   owns a different GPU and APK_COMM_RCCL is not 0); otherwise the same bytes are staged through the host
+ *                   and the TCP star - that is what the CPU tier tests drive (two processes, no GPU) and what lets two ranks
+ *                   share ONE GPU in the GPU tier.
+ * Schedules (csrc/comm.cpp):
+ *   apk_msm_g1_sharded : BASELINE configs[3] - ONE MSM split by index range: every rank commits its slice on the MSM-only
+ *                        context bound to the communicator, ONE all-gather of a 64/96-byte point per rank, local additions;
+ *                        the result is returned on every rank.  (A numeric all-reduce cannot add curve points.)
+ *   split proof        : ONE proof, several GPUs.  The leader (rank 0) calls apk_comm_split_begin, proves as usual
+ *                        (apk_prove*), then apk_comm_split_end; every other rank sits in apk_comm_serve.  Each commitment batch
+ *                        is dealt by index range of its flattened (scalar, point) pairs: header broadcast, one scatter of the
+ *                        scalar slices, apk_msm_g1_batch_device on every rank, all-gather of the partial sums; with
+ *                        APK_SPLIT_WIRES=1 the 4n-coset evaluation of wire i is dealt to rank i mod world (peer copies of the
+ *                        canonical polynomial out and of the evaluations back).
+ * Every rank holds the circuit context (apk_ctx_create with the same inputs), so any rank can commit any index range.
+ * Errors on one rank are reported on all ranks of the step (status words travel with the partial sums); a peer that stops
+ * answering fails the call after APK_COMM_TIMEOUT_S seconds (default 300). */
+typedef struct apk_comm apk_comm;
+int apk_comm_create(int rank, int world, const char* addr, int port, apk_comm** out);   /* rank 0 listens on addr:port */
+void apk_comm_destroy(apk_comm* comm);
+int apk_comm_rank(const apk_comm* comm);
+int apk_comm_world(const apk_comm* comm);
+int apk_comm_barrier(apk_comm* comm);
+int apk_comm_max_f64(apk_comm* comm, double* value);       /* in place: maximum over the ranks (bench.py's timing protocol) */
+/* This rank's context (a circuit context for the split proof, an MSM-only context for the sharded MSM) and the data plane. */
+int apk_comm_bind(apk_comm* comm, apk_ctx* ctx);
+const char* apk_comm_transport(const apk_comm* comm);      /* "rccl" or "tcp" (after apk_comm_bind) */
+int apk_msm_g1_sharded(apk_comm* comm, const void* d_scalars, uint64_t len, void* out);
+int apk_comm_split_begin(apk_comm* comm);
+int apk_comm_split_end(apk_comm* comm);
+int apk_comm_serve(apk_comm* comm, uint64_t* steps_served);
+/* Test seam: the GPU touch points of the schedules as a table, so that the CPU tier can run the SAME C code (transport, dealing,
+ * error propagation) in two processes without a GPU - "device" pointers are then host pointers and the table's msm is the
+ * oracle's.  NULL entries keep the built-in implementation (the bound context).  kind: 0 device-to-device, 1 host-to-device,
+ * 2 device-to-host. */
+typedef struct {
+    void* user;
+    int (*msm_batch)(void* user, int basis, uint32_t count, const void* const* d_scalars, const uint64_t* offsets,
+                     const uint64_t* lens, void* out_points);
+    int (*coset_ntt)(void* user, const void* d_in, uint64_t len, void* d_out);
+    int (*alloc)(void* user, size_t bytes, void** d_ptr);
+    int (*release)(void* user, void* d_ptr);
+    int (*copy)(void* user, void* dst, const void* src, size_t bytes, int kind);
+    size_t g1_bytes;          /* 64 / 96 */
+    uint64_t n;               /* domain size (coset evaluations are 4n Fr) */
+} apk_compute;
+int apk_comm_set_compute(apk_comm* comm, const apk_compute* table);
+/* the schedules' entry points as the hooks call them (exposed for the tests of the seam) */
+int apk_comm_commit(apk_comm* comm, int basis, uint32_t count, const void* const* d_scalars, const uint32_t* lens, void* out_points);
+int apk_comm_wires(apk_comm* comm, uint32_t count, const void* const* d_canonical, const uint32_t* lens, void* const* d_evals);
 
 /* ---- the verifier: the host-side mirror of plonk.Verify(proof, vk, publicWitness) (algoplonk.go:93) --------------------
  * (*CompiledCircuit).Verify runs the prover AND gnark's verifier before it hands out a VerifiedProof (algoplonk.go:79-98).

@@ -1,0 +1,204 @@
+"""CPU tier: libapk's communicator (csrc/comm.cpp) in two and three PROCESSES without a GPU.  The C code under test is the
+one a GPU node runs - TCP rendezvous and control plane, the dealing of a commitment batch by index range, the scatter of
+the scalar slices (host-staged data plane: what two ranks sharing one GPU use as well), status words travelling with the
+partial sums, the per-wire dealing, the worker loop - and only the GPU touch points are replaced through the `apk_compute`
+seam of include/apk.h: "device" memory is host memory, the per-rank MSM and the coset NTT are the C oracle's."""
+import ctypes as C
+import multiprocessing as mp
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _compute_table(cv, clib, bases: bytes, n: int = 0, fail_msm: bool = False):
+    """apk_compute over host memory: alloc / copy are malloc / memmove, msm_batch commits over `bases` (this rank's "context")
+    with the C oracle, coset_ntt is the oracle's 4n coset NTT of the zero-padded polynomial."""
+    from algoplonk_amd import _lib
+    nb = 2 * cv.fp_bytes
+    store = {}
+    base_buf = C.create_string_buffer(bases, len(bases))
+
+    def alloc(_u, nbytes, out):
+        buf = C.create_string_buffer(max(nbytes, 1))
+        store[C.addressof(buf)] = buf
+        out[0] = C.addressof(buf)
+        return 0
+
+    def release(_u, p):
+        store.pop(p, None)
+        return 0
+
+    def copy(_u, dst, src, nbytes, kind):
+        C.memmove(dst, src, nbytes)
+        return 0
+
+    def msm(_u, basis, count, scalars, offsets, lens, out):
+        if fail_msm:
+            return _lib.APK_ERR_HIP
+        for b in range(count):
+            rc = clib.orc_msm(cv.abi, C.addressof(base_buf) + offsets[b] * nb, scalars[b], lens[b], 1, out + b * nb)
+            if rc:
+                return rc
+        return 0
+
+    def coset(_u, d_in, length, d_out):
+        C.memset(d_out, 0, 4 * n * 32)
+        C.memmove(d_out, d_in, length * 32)
+        return clib.orc_ntt(cv.abi, d_out, 4 * n, 0, 1)
+
+    cbs = (_lib.CP_MSM(msm), _lib.CP_COSET(coset), _lib.CP_ALLOC(alloc), _lib.CP_RELEASE(release), _lib.CP_COPY(copy))
+    t = _lib.Compute()
+    t.user, t.msm_batch, t.coset_ntt, t.alloc, t.release, t.copy, t.g1_bytes, t.n = None, cbs[0], cbs[1], cbs[2], cbs[3], cbs[4], nb, n
+    return t, (cbs, store, base_buf)
+
+
+def _setup_paths():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _sharded_worker(rank, world, port, q):
+    _setup_paths()
+    try:
+        from algoplonk_amd import ecc, parallel
+        from oracle import c_oracle, curves as oc, plonk as oplonk
+        from oracle.prng import SplitMix64
+        clib = c_oracle.load()
+        comm = parallel.Comm(rank, world, "127.0.0.1", port)
+        assert (comm.rank, comm.world) == (rank, world)
+        for cv, ov in ((ecc.BN254, oc.BN254), (ecc.BLS12_381, oc.BLS12_381)):
+            nb = 2 * cv.fp_bytes
+            for n in (21, 2, 1):                    # 1 and 2 bases: ranks with an empty share send the point at infinity
+                tau = 0x1234567
+                g = SplitMix64(42)
+                pts = cv.g1_vector([ov.mul(ov.g1, pow(tau, i, cv.r)) for i in range(n)])
+                scalars = [g.fr(cv.r) for _ in range(n)]
+                lo, hi = parallel.my_share(n, rank, world)
+                table, keep = _compute_table(cv, clib, pts[lo * nb: hi * nb] or bytes(nb))
+                comm.set_compute(table, keep)
+                comm.bind(None)
+                assert comm.transport == "tcp"
+                mine = C.create_string_buffer(cv.fr_vector(scalars[lo:hi]) or b"\0")
+                got = cv.g1_from_bytes(comm.msm_sharded(cv, C.addressof(mine), hi - lo))
+                assert got == ov.mul(ov.g1, oplonk.poly_eval(scalars, tau, cv.r)), ("sharded MSM != full MSM", cv.name, n)
+        # the timing protocol of bench.py: barrier, MAX over ranks
+        comm.barrier()
+        assert comm.max(float(rank)) == float(world - 1)
+        comm.close()
+        q.put((rank, "ok"))
+    except Exception as e:
+        import traceback
+        q.put((rank, "FAIL: %r %s" % (e, traceback.format_exc()[-800:])))
+
+
+def _split_worker(rank, world, port, q):
+    _setup_paths()
+    try:
+        from algoplonk_amd import _lib, ecc, parallel
+        from algoplonk_amd._lib import lib
+        from oracle import c_oracle, curves as oc, plonk as oplonk
+        from oracle.prng import SplitMix64
+        clib = c_oracle.load()
+        cv, ov = ecc.BLS12_381, oc.BLS12_381
+        n = 8
+        tau, nbases = 0xABCDEF12345, n + 3
+        pts = cv.g1_vector([ov.mul(ov.g1, pow(tau, i, cv.r)) for i in range(nbases)])
+        g = SplitMix64(7)
+        vectors = [[g.fr(cv.r) for _ in range(m)] for m in (10, 10, 10, 11, 5)]
+        comm = parallel.Comm(rank, world, "127.0.0.1", port)
+        table, keep = _compute_table(cv, clib, pts, n=n)       # every rank holds the whole SRS (the circuit context)
+        comm.set_compute(table, keep)
+        comm.bind(None)
+        steps = 0
+        if rank == 0:
+            host = [C.create_string_buffer(cv.fr_vector(v)) for v in vectors]
+            ptr = [C.addressof(b) for b in host]
+            # a batch of three (round 1 / round 3 of the prover), a single commitment, a batch of two of unequal lengths
+            for batch in ([0, 1, 2], [3], [4, 3]):
+                lens = [len(vectors[i]) for i in batch]
+                got = comm.commit(cv, 0, [ptr[i] for i in batch], lens)
+                want = [ov.mul(ov.g1, oplonk.poly_eval(vectors[i], tau, cv.r)) for i in batch]
+                assert [cv.g1_from_bytes(b) for b in got] == want, batch
+                steps += 1
+            # per-wire dealing: the 4n-coset evaluations of three canonical polynomials, polynomial i on rank i mod world
+            evs = [C.create_string_buffer(4 * n * 32) for _ in range(3)]
+            comm.wires([ptr[0], ptr[1], ptr[2]], [10, 10, 10], [C.addressof(e) for e in evs])
+            steps += 1
+            w4 = ov.omega(4 * n)
+            for i in range(3):
+                got = cv.fr_vector_decode(evs[i].raw)
+                want = [oplonk.poly_eval(vectors[i], ov.coset_shift * pow(w4, j, cv.r) % cv.r, cv.r) for j in range(4 * n)]
+                assert got == want, ("wire", i)
+            comm.split_end()
+        else:
+            assert comm.serve() == 4
+        comm.close()
+        # a rank that fails its share fails the step on EVERY rank, with its rank named
+        comm = parallel.Comm(rank, world, "127.0.0.1", port + 1)
+        table, keep = _compute_table(cv, clib, pts, n=n, fail_msm=(rank == world - 1))
+        comm.set_compute(table, keep)
+        comm.bind(None)
+        if rank == 0:
+            buf = C.create_string_buffer(cv.fr_vector(vectors[0]))
+            with pytest.raises(_lib.ApkError, match="rank %d failed its share" % (world - 1)):
+                comm.commit(cv, 0, [C.addressof(buf)], [10])
+            comm.split_end()
+        else:
+            comm.serve()
+        comm.close()
+        q.put((rank, "ok"))
+    except Exception as e:
+        import traceback
+        q.put((rank, "FAIL: %r %s" % (e, traceback.format_exc()[-800:])))
+
+
+def _run(target, world, extra_ports=1):
+    from algoplonk_amd.parallel import free_port
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=240) for _ in procs]
+    [p.join(timeout=60) for p in procs]
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_msm_over_the_c_communicator(world):
+    """BASELINE.json configs[3]: ONE MSM split by index range, one all-gather of a point per rank, local additions."""
+    _run(_sharded_worker, world)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_split_proof_schedule_over_the_c_communicator(world):
+    """commitment batches dealt by index range + wires dealt by polynomial; leader / worker loop."""
+    _run(_split_worker, world)
+
+
+def test_world_1_needs_no_peer():
+    sys.path.insert(0, ROOT)
+    from algoplonk_amd import parallel
+    c = parallel.Comm(0, 1)
+    c.barrier()
+    assert c.max(3.5) == 3.5 and c.transport == "tcp"
+    c.close()
+
+
+def test_my_share_and_deal_tile_the_work():
+    from algoplonk_amd.parallel import deal, my_share
+    for total in (0, 1, 7, 8, 131072):
+        for world in (1, 2, 3, 8):
+            spans = [my_share(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+    for lens in ([18, 18, 18], [7], [5, 19], [1, 1, 1, 1]):
+        segs = [deal(lens, r, 3) for r in range(3)]
+        seen = sorted((k, i) for ss in segs for k, lo, hi in ss for i in range(lo, hi))
+        assert seen == [(k, i) for k, n in enumerate(lens) for i in range(n)]
+        sizes = [sum(hi - lo for _, lo, hi in ss) for ss in segs]
+        assert max(sizes) - min(sizes) <= 1

@@ -257,8 +257,9 @@ def test_msm_only_context_and_index_range_sharding(gpu, cname):
     acc = bytes(2 * cv.fp_bytes)
     world = 4
     for rank in range(world):
-        sm = parallel.ShardedMsm(cv, srs.g1, device=gpu, rank=rank, world=world)
-        acc = parallel.g1_add(cv, acc, sm.partial(sc_bytes))
+        sm = parallel.ShardedMsm(cv, srs.g1, device=gpu, comm=parallel.Comm(0, 1), share=(rank, world))
+        sm.upload(sc_bytes)
+        acc = parallel.g1_add(cv, acc, sm.run())
         # an MSM-only context refuses what it cannot do, loudly
         assert lib.apk_ntt(sm._ctx, 0, 0, 0, sc_bytes) == _lib.APK_ERR_STATE
         sm.close()
@@ -277,12 +278,13 @@ def test_msm_over_degenerate_bases_hits_the_doubling_and_cancellation_paths(gpu,
     i4 = pow(ov.omega(4), 1, cv.r)
     for tau in (1, cv.r - 1, i4):
         srs = ap_setup.unsafe_srs(cv, n, tau, device=gpu)
-        sm = parallel.ShardedMsm(cv, srs.g1, device=gpu, rank=0, world=1)
+        sm = parallel.ShardedMsm(cv, srs.g1, device=gpu, comm=parallel.Comm(0, 1))
         x = g.fr(cv.r)
         cases = [[g.fr(cv.r) for _ in range(n + 3)], [x] * (n + 3), [x if i % 2 == 0 else cv.r - x for i in range(n + 3)],
                  [g.below(4) for _ in range(n + 3)], [1] * (n + 3)]
         for sc in cases:
-            got = cv.g1_from_bytes(sm.partial(cv.fr_vector(sc)))
+            sm.upload(cv.fr_vector(sc))
+            got = cv.g1_from_bytes(sm.run())
             assert got == ov.mul(ov.g1, oplonk.poly_eval(sc, tau, cv.r)), (cname, tau == 1, len(sc))
         sm.close()
 
@@ -535,8 +537,8 @@ def test_public_api_pythagorean_compile_verify_export(gpu, tmp_path):
 @pytest.mark.parametrize("cname", ["bn254", "bls12-381"])
 def test_commit_hook_and_ranged_batch_msm(gpu, cname):
     """SURVEY.md section 8e row 2 on ONE GPU: (1) apk_msm_g1_batch_device = partial commitments over index ranges, against
-    the oracle; (2) a proof whose commitments all go through the context's commit hook (SplitCommitter, world = 1: the same
-    code path the ranks of a node run, minus the collectives) is byte-identical to the plain proof - with and without BSB22."""
+    the oracle; (2) a proof whose commitments all go through the context's commit hook (libapk's communicator at world = 1: the
+    same C code path the ranks of a node run, minus the exchange) is byte-identical to the plain proof - with and without BSB22."""
     from algoplonk_amd import parallel, workloads
     cv, ov = CURVES[cname]
     ccs, w, sol = random_chain_ccs(cv, 9, 0xA190 + 9)
@@ -565,21 +567,22 @@ def test_commit_hook_and_ranged_batch_msm(gpu, cname):
     # (2) the hook path
     bl = blinding(cv, 5)
     plain = MarshalProof(ap_plonk.Prove(ccs, pk, w, bl))
-    split = parallel.SplitCommitter(cv, pk.ctx, 0, 1)
-    split.install()
+    split = parallel.Comm(0, 1).bind(pk.ctx)
+    split.split_begin()
     hooked = MarshalProof(ap_plonk.Prove(ccs, pk, w, bl))
-    assert split.batches == 4                                          # {L,R,O}, {Z}, {H1,H2,H3}, {W_zeta, W_omega*zeta}
-    split.stop()
+    split.split_end()
+    split.close()
     assert hooked == plain and MarshalProof(ap_plonk.Prove(ccs, pk, w, bl)) == plain
     pk.close()
     ccs2, w2, bl2, tau2 = workloads.random_circuit_bsb22(cv, 8, 0xA193, nb_commitments=1, committed=4)
     srs2 = ap_setup.unsafe_srs(cv, ccs2.domain_size(), tau2, device=gpu, lagrange=True)
     pk2, vk2 = ap_plonk.Setup(ccs2, srs2, device=gpu)
     plain2 = MarshalProof(ap_plonk.Prove(ccs2, pk2, w2, bl2, hiding=[(3, 4)]))
-    split2 = parallel.SplitCommitter(cv, pk2.ctx, 0, 1)
-    split2.install()
-    assert MarshalProof(ap_plonk.Prove(ccs2, pk2, w2, bl2, hiding=[(3, 4)])) == plain2 and split2.batches == 5
-    split2.stop()
+    split2 = parallel.Comm(0, 1).bind(pk2.ctx)
+    split2.split_begin()
+    assert MarshalProof(ap_plonk.Prove(ccs2, pk2, w2, bl2, hiding=[(3, 4)])) == plain2
+    split2.split_end()
+    split2.close()
     pk2.close()
 
 
