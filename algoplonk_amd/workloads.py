@@ -102,6 +102,53 @@ def random_circuit_bsb22(curve: ecc.ID, log_n: int, seed: int, nb_commitments: i
     return ccs, w, [gb.fr(r) for _ in range(9)], tau_from_seed(seed, r)
 
 
+def skewed_circuit(curve: ecc.ID, log_n: int, seed: int, nb_public: int = 2) -> Workload:
+    """The hard input of SURVEY.md section 7 ("Lagrange-basis MSMs take witness values: many zeros / ones / small values"): a
+    circuit shaped like bit-decomposition-heavy gadgets (range checks, SHA-style logic) - half of the gates are XOR / AND over
+    boolean wires, a quarter multiplex 16-bit values by a boolean, a quarter are the uniform random gates of `random_circuit`.
+    Solved wire columns: ~80 % in {0, 1} (AND gates drift towards 0), the rest 16-bit or uniform values.  (The reference's own MiMC-Merkle example,
+    examples/merkle/logicsigVerifier/main.go:45-61, is the opposite extreme: 17 levels x 2 MiMC permutations of field-sized
+    values and 16 path bits - more than 99 % of its wires are uniform.)"""
+    r = curve.r
+    n = 1 << log_n
+    g = SplitMix64(seed)
+    sol = [g.fr(r) for _ in range(nb_public + 2)]
+    cons = []
+    m1 = r - 1
+    bools, smalls = [], []
+
+    def emit(ql, qr, qm, qk, xa, xb, pool=None):
+        nv = len(sol)
+        a, b = sol[xa], sol[xb]
+        cons.append((ql % r, qr % r, qm % r, m1, qk % r, xa, xb, nv))
+        sol.append((ql * a + qr * b + qm * a % r * b + qk) % r)
+        if pool is not None:
+            pool.append(nv)
+
+    budget = n - nb_public
+    for i in range(8):                                  # constant wires: the seeds of the boolean and the 16-bit pools
+        emit(0, 0, 0, i & 1, 0, 0, bools)
+        emit(0, 0, 0, g.below(1 << 16), 0, 0, smalls)
+    while len(cons) < budget:
+        kind = g.below(4)
+        if kind < 2:
+            xa, xb = bools[g.below(len(bools))], bools[g.below(len(bools))]
+            if g.below(2):
+                emit(1, 1, -2, 0, xa, xb, bools)        # XOR
+            else:
+                emit(0, 0, 1, 0, xa, xb, bools)         # AND
+        elif kind == 2:
+            emit(0, 0, 1, 0, smalls[g.below(len(smalls))], bools[g.below(len(bools))], smalls)   # 16-bit value AND-ed with a bit
+        else:
+            nv = len(sol)
+            emit(g.fr(r), g.fr(r), g.fr(r), g.fr(r), g.below(nv), g.below(nv))
+    ccs = frontend.ConstraintSystem(r, ["p%d" % i for i in range(nb_public)], ["s0", "s1"], cons, "gates", len(sol))
+    w = frontend.Witness(r, sol[:nb_public], sol[nb_public:nb_public + 2])
+    gb = SplitMix64(seed ^ 0xB11D)
+    return Workload("%s bit-heavy circuit (~80%% of the wire values in {0,1}), 2^%d constraints" % (curve.name, log_n), curve, ccs, w,
+                    sol, [gb.fr(r) for _ in range(9)], tau_from_seed(seed, r))
+
+
 def random_circuit(curve: ecc.ID, log_n: int, seed: int, nb_public: int = 2) -> Workload:
     """BASELINE.json configs[1]/[2]: n - nb_public random gates c = ql*a + qr*b + qm*a*b + qk over earlier wires."""
     r = curve.r

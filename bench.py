@@ -66,6 +66,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes behind roofline.traffic")
+    ap.add_argument("--witness", default="uniform", choices=["uniform", "bits"],
+                    help="wire values of the synthetic circuit: uniform Fr (BASELINE.md section 2) or the bit-heavy circuit of "
+                         "workloads.skewed_circuit; the default run reports the bit-heavy rate beside the headline (`witness_bits`)")
     ap.add_argument("--mode", default="prove", choices=["prove", "msm-sharded", "prove-split", "launcher-selftest"])
     return ap.parse_args(argv)
 
@@ -363,7 +366,7 @@ def bench_prove(args, cv, rk) -> None:
         ccs, witness, blinding, tau = workloads.random_circuit_bsb22(cv, args.log_n, seed, nb_commitments=args.bsb22)
         name = "%s random circuit, 2^%d constraints, %d BSB22 commitment(s)" % (cv.name, args.log_n, args.bsb22)
     else:
-        wl = workloads.random_circuit(cv, args.log_n, seed)
+        wl = (workloads.skewed_circuit if args.witness == "bits" else workloads.random_circuit)(cv, args.log_n, seed)
         ccs, witness, blinding, tau, name = wl.ccs, wl.witness, wl.blinding, wl.tau, wl.name
     n = ccs.domain_size()
     srs = setup.unsafe_srs(cv, n, tau, device=rk.local_rank, lagrange=bool(args.bsb22))
@@ -452,6 +455,11 @@ def bench_prove(args, cv, rk) -> None:
         t.join()
     msm_sat_mscalar = sat_threads * sat_reps * n / (time.perf_counter() - s0) / 1e6
 
+    # ---- the hard input: the same measurement on a circuit whose wires are mostly 0 / 1 / 16-bit values
+    witness_bits = None
+    if rk.world == 1 and args.witness == "uniform" and not args.bsb22 and args.log_n <= 19:
+        witness_bits = skewed_leg(args, cv, rk, seed, value)
+
     pmc = None
     cpu_baseline = None
     if rk.rank == 0 and rk.world == 1:
@@ -487,10 +495,67 @@ def bench_prove(args, cv, rk) -> None:
             "msm_ms": round(msm_s * 1e3, 4), "msm_mscalar_per_s_saturated": round(msm_sat_mscalar, 3), "setup_s": round(setup_s, 2),
             "msm_batch_avg_ms": round(st.msm_total_ms / max(st.msm_batches, 1), 4),
             "ntt_ms_per_proof": round(st.ntt_ms / max(st.proofs, 1), 4),
+            "round_ms": [round(x / max(st.proofs, 1), 3) for x in st.round_ms],
+            "host_lincomb_ms": round(st.host_lincomb_ms / max(st.proofs, 1), 3),
+            "witness_bits": witness_bits,
             "proof_sha256_prefix": gpu_proof_sha, "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line), flush=True)
     rk.close()
+
+
+def skewed_leg(args, cv, rk, seed, uniform_value):
+    """proofs/s on workloads.skewed_circuit (~80 % of the wire values in {0, 1}, the rest 16-bit or uniform), same size, same
+    number of concurrent callers, a sixth of the steps.  This prover commits the CANONICAL (blinded) wire polynomials: after the
+    iNTT the MSM scalars are uniform whatever the witness looks like, so the rate must match the headline - the line checks it."""
+    from algoplonk_amd import _lib, frontend, plonk, setup, workloads
+    from algoplonk_amd._lib import lib, check
+    wl = workloads.skewed_circuit(cv, args.log_n, seed ^ 0x5EED)
+    srs = setup.unsafe_srs(cv, wl.ccs.domain_size(), wl.tau, device=rk.local_rank)
+    pk, vk = plonk.Setup(wl.ccs, srs, device=rk.local_rank, msm_window=args.msm_window, slots=args.inflight)
+    L, R, O = frontend.wire_columns(wl.ccs, wl.solution)
+    small = sum(1 for col in (L, R, O) for v in col if v < 2) / (3.0 * len(L))
+    dptr = []
+    for vec in (L, R, O):
+        b = cv.fr_vector(vec)
+        p = C.c_void_p()
+        check(lib.apk_device_alloc(pk.ctx, len(b), C.byref(p)))
+        check(lib.apk_device_upload(pk.ctx, p, b, len(b)))
+        dptr.append(p)
+    pub, bl = cv.fr_vector(wl.witness.public), cv.fr_vector(wl.blinding)
+    proofs = [_lib.Proof() for _ in range(args.inflight)]
+    errors = []
+
+    def one(i):
+        rc = lib.apk_prove_device(pk.ctx, dptr[0], dptr[1], dptr[2], pub, bl, None, C.byref(proofs[i]))
+        if rc != 0:
+            errors.append((rc, lib.apk_last_error()))
+
+    def step():
+        ts = [threading.Thread(target=one, args=(i,)) for i in range(args.inflight)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+
+    steps = max(3, args.steps // 6)
+    elapsed = rk.timed(step, steps, 2)
+    ok = not errors
+    if ok:
+        try:
+            plonk.Verify(plonk.Proof(cv, proofs[0]), _with_g2(vk, cv, wl.tau), wl.witness)
+        except Exception:
+            ok = False
+    pk.close()
+    value = steps * args.inflight / elapsed
+    return {"workload": wl.name, "wire_values_in_0_1": round(small, 3), "value": round(value, 3), "unit": "proofs/sec", "steps": steps,
+            "ratio_to_uniform": round(value / uniform_value, 4), "proof_verifies": ok}
+
+
+def _with_g2(vk, cv, tau):
+    from algoplonk_amd import setup
+    vk.KzgG2 = setup.g2_from_tau(cv, tau)
+    return vk
 
 
 def bench_sharded_msm(args, cv, rk) -> None:

@@ -239,6 +239,23 @@ def test_full_size_proof_is_accepted_by_the_transcribed_verifier(gpu, cname, log
     assert ov.add(pk.msm(a), pk.msm(b)) == pk.msm([(x + y) % cv.r for x, y in zip(a, b)])
     # NTT round trip at full size
     assert pk.ntt(pk.ntt(a), inverse=True) == a
+    # the primitives at full size, byte for byte against the C oracle's (orc_msm: classic per-window Pippenger on Jacobian
+    # points; orc_ntt: plain radix-2) - SURVEY.md section 8a rows a4 / a6 at BASELINE.json's sizes, not only as properties
+    clib = c_oracle.load()
+    g = SplitMix64(0xA192)
+    sc = cv.fr_vector([g.fr(cv.r) for _ in range(n + 3)])
+    want, got = C.create_string_buffer(2 * cv.fp_bytes), C.create_string_buffer(2 * cv.fp_bytes)
+    for length in (n + 3, n + 2, n):
+        assert clib.orc_msm(cv.abi, srs.g1, sc, length, os.cpu_count() or 1, want) == 0
+        check(lib.apk_msm_g1(pk.ctx, 0, sc, length, got))
+        assert got.raw == want.raw, ("msm", length)
+    for which, size in ((0, n), (1, 4 * n)):
+        for inverse, coset in ((0, 0), (1, 0)) + (((0, 1), (1, 1)) if which else ()):
+            data = sc[: 32 * n] * (size // n)
+            a_buf, b_buf = C.create_string_buffer(data, len(data)), C.create_string_buffer(data, len(data))
+            assert clib.orc_ntt(cv.abi, a_buf, size, inverse, coset) == 0
+            check(lib.apk_ntt(pk.ctx, which, inverse, coset, b_buf))
+            assert a_buf.raw == b_buf.raw, ("ntt", which, inverse, coset)
     pk.close()
 
 
@@ -405,7 +422,8 @@ def test_bsb22_inside_a_random_circuit_2p10(gpu, cname):
 
 def test_skewed_scalars_at_full_size_are_correct_and_not_pathological(gpu):
     """A Lagrange-basis commitment of a real witness is full of 0 / 1 / small values: one bucket then holds ~n entries.
-    The work-unit split + the heavy-bucket merge keep such an MSM within a small factor of the uniform case."""
+    The work-unit split + the heavy-bucket merge keep such an MSM within 2x of the uniform case (scalars resident in HBM,
+    median of 7 runs each)."""
     import time
     cv, ov = CURVES["bn254"]
     n = 1 << 17
@@ -417,17 +435,26 @@ def test_skewed_scalars_at_full_size_are_correct_and_not_pathological(gpu):
     g = SplitMix64(1)
     uniform = [g.fr(cv.r) for _ in range(n)]
     cases = {"uniform": uniform, "ones": [1] * n, "bits": [i & 1 for i in range(n)], "small": [g.below(1 << 10) for _ in range(n)],
-             "minus_one": [cv.r - 1] * n}
+             "minus_one": [cv.r - 1] * n, "zeros_and_uniform": [0 if i % 8 else uniform[i] for i in range(n)],
+             "bytes": [g.below(256) for _ in range(n)]}
+    d = C.c_void_p()
+    check(lib.apk_device_alloc(ctx, 32 * n, C.byref(d)))
     times = {}
     for name, sc in cases.items():
         buf = cv.fr_vector(sc)
-        check(lib.apk_msm_g1(ctx, 0, buf, n, out))          # warm
-        t0 = time.perf_counter()
-        check(lib.apk_msm_g1(ctx, 0, buf, n, out))
-        times[name] = time.perf_counter() - t0
+        check(lib.apk_device_upload(ctx, d, buf, len(buf)))
+        check(lib.apk_msm_g1_device(ctx, 0, d, n, out))      # warm
         assert cv.g1_from_bytes(out.raw) == ov.mul(ov.g1, oplonk.poly_eval(sc, tau, cv.r)), name
+        runs = []
+        for _ in range(7):
+            t0 = time.perf_counter()
+            check(lib.apk_msm_g1_device(ctx, 0, d, n, out))
+            runs.append(time.perf_counter() - t0)
+        times[name] = sorted(runs)[3]
+    check(lib.apk_device_free(ctx, d))
     lib.apk_ctx_destroy(ctx)
-    assert max(times.values()) < 20 * times["uniform"] + 0.05, times
+    print("skewed MSM times (ms):", {k: round(v * 1e3, 3) for k, v in times.items()})
+    assert max(times.values()) < 2.0 * times["uniform"] + 0.0002, times
 
 
 @pytest.mark.parametrize("cname,log_n", [("bls12-381", 17), ("bn254", 16)])
