@@ -413,7 +413,8 @@ class CurveBackend : public Backend {
         // Logical threads per workgroup: the longer of rows / cols, at most 128 (512 lanes leave each lane 256 registers).
         static const int quad_env = env_int("APK_MSM_QUAD_TAIL", -1, -1, 15);
         const int quad = quad_env >= 0 ? quad_env : (slots_.size() <= 2 ? 7 : 14);
-        const uint32_t lt = (rows > cols ? rows : cols) > 128 ? 128 : (rows > cols ? rows : cols);
+        constexpr uint32_t LT_MAX = MsmQuad<FPP>::LT;   // 128 quads (512 lanes) on the 9-limb field, 64 on the 14-limb one
+        const uint32_t lt = (rows > cols ? rows : cols) > LT_MAX ? LT_MAX : (rows > cols ? rows : cols);
         if (quad & 1)
             msm_rowcol_quad_kernel<FPP><<<dim3(rows + cols, a.batch), 4 * lt, lt * sizeof(PtU), st>>>(ptr<PtU>(s.bucket_sum), NB_, rows, cols, ptr<PtU>(s.rowcol));
         else if (quad & 8)

@@ -522,8 +522,14 @@ __global__ void __launch_bounds__(256) msm_rowcol_hybrid_kernel(const XYZZ<FP, F
     if (t == 0) rc[(size_t)m * (rows + cols) + x] = qa;
 }
 
+// Workgroup size of the four-lane reduction kernels.  256 registers per lane are enough for the 9-limb field at 512 lanes;
+// the 14-limb field (BLS12-381: a point is 56 registers, an addition keeps four of them and a product's operands live) spilled
+// to scratch memory there, so its workgroups are 256 lanes: one wave per SIMD, the whole 512-entry register file per lane
+// (the compiler parks what does not fit the 256 architected VGPRs in accumulation registers, not in memory).
+template <class FP> struct MsmQuad { static constexpr uint32_t THREADS = FP::N > 8 ? 256 : 512, LT = THREADS / 4; };
+
 template <class FP>
-__global__ void __launch_bounds__(512) msm_rowcol_quad_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum, uint32_t nb, uint32_t rows,
+__global__ void __launch_bounds__(MsmQuad<FP>::THREADS) msm_rowcol_quad_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum, uint32_t nb, uint32_t rows,
                                                               uint32_t cols, XYZZ<FP, FeU<FP>>* __restrict__ rc) {
     using PT = XYZZ<FP, FeU<FP>>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -613,7 +619,7 @@ __global__ void __launch_bounds__(256) msm_final_quad_kernel(const XYZZ<FP, FeU<
 // of concurrent streams is safe.  `lt` logical threads (quads) do the bit sum; blockDim.x = max(4 * lt, 256); LDS holds
 // max(lt, 64) points.
 template <class FP>
-__global__ void __launch_bounds__(512) msm_bitsum_final_quad_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ rc, uint32_t rows, uint32_t cols,
+__global__ void __launch_bounds__(MsmQuad<FP>::THREADS) msm_bitsum_final_quad_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ rc, uint32_t rows, uint32_t cols,
                                                                     uint32_t lt, XYZZ<FP, FeU<FP>>* __restrict__ bit_partial,
                                                                     uint32_t* __restrict__ done_count, int cols_log,
                                                                     XYZZ<FP>* __restrict__ result_xyzz) {
@@ -652,7 +658,7 @@ __global__ void __launch_bounds__(512) msm_bitsum_final_quad_kernel(const XYZZ<F
 }
 
 template <class FP>
-__global__ void __launch_bounds__(512) msm_bitsum_quad_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ rc, uint32_t rows, uint32_t cols,
+__global__ void __launch_bounds__(MsmQuad<FP>::THREADS) msm_bitsum_quad_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ rc, uint32_t rows, uint32_t cols,
                                                               XYZZ<FP, FeU<FP>>* __restrict__ bit_partial) {
     using PT = XYZZ<FP, FeU<FP>>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Emit algoplonk_amd/csrc/ffu_asm.h: the unsaturated-limb Montgomery product and square of ffu.h as ONE inline-asm statement
-each, for the 9 x 29-bit fields (BN254 Fp: the MSM's bucket accumulation; the two scalar fields: NTT tiles, quotient kernel).
+each, for the 9 x 29-bit fields (BN254 Fp: the MSM's bucket accumulation; the two scalar fields: NTT tiles, quotient kernel)
+and - round 3 - the 14 x 28-bit BLS12-381 Fp (428 instead of ~470 compiler-scheduled VALU instructions per product).
 
 Why asm: hipcc splits every column of the C++ product scanning into two accumulator chains for instruction-level
 parallelism and merges them with a v_lshl_add_u64 - 16 extra instructions per product.  tools/ubench/valu_rates.hip shows that
@@ -16,16 +17,22 @@ at the head of the statement (VOP3 takes no literals on gfx9-family targets); m_
 read in column k + L - 1, r_k is written in column k + L).
 Run: python tools/gen_umul_asm.py > algoplonk_amd/csrc/ffu_asm.h
 """
-FIELDS = {
-    "FpBN254": 21888242871839275222246405745257275088696311157297823662689037894645226208583,
-    "FrBN254": 21888242871839275222246405745257275088548364400416034343698204186575808495617,
-    "FrBLS12381": 52435875175126190479447740508185965837690552500527637822603658699938581184513,
+FIELDS = {   # name: (modulus, limbs, bits per limb)
+    "FpBN254": (21888242871839275222246405745257275088696311157297823662689037894645226208583, 9, 29),
+    "FrBN254": (21888242871839275222246405745257275088548364400416034343698204186575808495617, 9, 29),
+    "FrBLS12381": (52435875175126190479447740508185965837690552500527637822603658699938581184513, 9, 29),
+    # 14 x 28 bits: 14 outputs + 28 inputs in one statement (clang has no 30-operand limit; GCC's does not apply to hipcc)
+    "FpBLS12381": (4002409555221667393417789825735904156556882819939007885332058136124031650490837864442687629129015664037894272559787, 14, 28),
 }
-L, B = 9, 29
-MASK = (1 << B) - 1
+L, B, MASK = 9, 29, (1 << 29) - 1        # set per field by use()
 ACC_LO, ACC_HI, TMP = 60, 61, 62          # fixed VGPRs: accumulator pair (even aligned), scratch
-D0 = 64                                   # v64..v72: doubled limbs of the squaring
-S0 = 84                                   # s84..s92 = p_0..p_8, s93 = q
+D0 = 64                                   # v64..v(63+L): doubled limbs of the squaring
+S0 = 84                                   # s84..s(83+L) = p_0..p_(L-1), s(84+L) = q  (L = 14: s84..s98)
+
+
+def use(l, b):
+    global L, B, MASK
+    L, B, MASK = l, b, (1 << b) - 1
 
 
 def limbs(x):
@@ -127,7 +134,8 @@ def emit_fn(name, ins, nin):
 print("// GENERATED by tools/gen_umul_asm.py - do not edit.\n#pragma once\n#include <stdint.h>\n")
 print("template <class P> struct UMulAsm { static constexpr bool available = false; };\n")
 print("#if defined(__HIP_DEVICE_COMPILE__) && !defined(APK_NO_UMUL_ASM)")
-for name, p in FIELDS.items():
+for name, (p, l, b) in FIELDS.items():
+    use(l, b)
     print("template <> struct UMulAsm<%s> {" % name)
     print("    static constexpr bool available = true;")
     emit_fn("mul", body_mul(p), 2)
