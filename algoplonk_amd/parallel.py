@@ -86,7 +86,9 @@ class Comm:
         if world == 1:
             return cls(0, 1)
         addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
-        path = "/tmp/apk_rdzv_%s_%s%s" % (os.getuid(), os.environ.get("MASTER_PORT", "0"), tag)
+        # the ranks of one launch share their parent (the launcher's agent): its pid keeps a stale file of an earlier, crashed
+        # launch on the same MASTER_PORT from being read
+        path = "/tmp/apk_rdzv_%s_%s_%s%s" % (os.getuid(), os.environ.get("MASTER_PORT", "0"), os.getppid(), tag)
         if rank == 0:
             port = free_port()
             with open(path + ".tmp", "w") as f:

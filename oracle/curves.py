@@ -13,9 +13,10 @@ mathematics; the constants are the ones the reference itself pins:
   * compressed point flags   setup/trusted_setup_test.go:53-59,183-189 (KAT hex strings),
                              verifier/verifier.go:95-99 (0x40 = infinity in raw encoding)
 
-PARITY STATUS: value-level parity against gnark is UNPINNED - the reference holds no
-golden proof bytes, MSM or NTT outputs.  What IS pinned and checked in tests/test_oracle_*.py:
-SRS decompression KATs, blob shape/offsets, the verifier logic transcribed from the templates.
+PARITY STATUS: pinned by the reference's SRS decompression KATs (tests/test_oracle_kat.py) and, through the
+executed verifier templates (tests/test_template_pin.py), for every group operation and encoding the
+verification of a proof touches - including the encodings of the point at infinity (raw_bytes below).
+MSM / NTT outputs against gnark's: no golden values exist in the reference.
 """
 from __future__ import annotations
 

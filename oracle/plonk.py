@@ -11,10 +11,14 @@ What it restates
   known-tau G1 check for synthetic SRS (SURVEY.md App. E last line).
 * The proof / public-input wire formats of helper.go:13-24,27-88,91-110.
 
-PARITY STATUS: "parity unpinned" at the value level (no golden proof bytes exist in the reference,
-SURVEY.md §8c).  Pinned and tested: blob shape/offsets (bsb22_test.go:70,83,97-120), transcript
-composition, verifier acceptance, rejection under the reference's mutations
-(testutils/verifier_integration_test.go:188-228).
+PARITY STATUS.  `verify` is PINNED: tests/test_template_pin.py holds its verdicts and every intermediate
+(challenges, PI, lin(zeta), [lin], folding challenge, folded digest/claims) to the reference's own
+templates, rendered and EXECUTED in the build container (tests/golden/make_template_fixtures.py ->
+tests/golden/template_verdicts.json: k = 0,1,2 commitments, both curves, the reference's mutations of
+testutils/verifier_integration_test.go:188-228).  `prove` is pinned only through that verifier (it
+makes proofs the executed template accepts): its bytes against gnark's for the same randomness are
+"parity unpinned" - the reference holds no golden proof bytes and gnark cannot run here.
+Also pinned: blob shape/offsets (bsb22_test.go:70,83,97-120).
 
 The polynomial arithmetic here is deliberately the *textbook* route (numerator on an 8n domain, exact
 division by X^n-1 with a zero-remainder check) so it is independent from the 4n-coset schedule the HIP
