@@ -217,11 +217,14 @@ class CurveBackend : public Backend {
                       uint32_t out_len, const Fr* pre, const Fr* post, const Fr* scale) {
         const int log_n = which ? (int)log_n_ + 2 : (int)log_n_;
         const Fr* tw = which ? (inverse ? ptr<Fr>(twi_4n_) : ptr<Fr>(tw_4n_)) : (inverse ? ptr<Fr>(twi_n_) : ptr<Fr>(twu_n_));
-        // small transforms are latency-bound: 512-element tiles (16 KiB LDS) give >= 256 workgroups at 2^17;
-        // large ones are bandwidth-bound: 2048-element tiles and fewer passes
+        // small transforms are latency-bound: 512-element tiles (18 KiB LDS) give >= 256 workgroups at 2^17.  Large ones were
+        // assumed bandwidth-bound (2048-element tiles, fewest passes) until round 3 measured them: at 2^21 / 2^23 the 72 KiB tile
+        // leaves two workgroups = 2 waves per SIMD on a CU, the pass runs at 6.9 cycles per VALU instruction and 1.9 TB/s - bound
+        // by neither (profiles/r03_pmc_bls12381_2p21_*).  1024-element tiles (36 KiB, 4 workgroups per CU), 9 stages per pass:
+        // 6.84 instead of 8.65 ms of NTT per BLS12-381 2^21 proof; 512 / 7 is the same, 2048 with 8..10 stages all 8.6 ms.
         static const int tile_env = env_int("APK_NTT_TILE_LOG", 0, 0, NTT_TILE_LOG);     // 0 = default; clamped to what the LDS tile holds
         static const int stages_env = env_int("APK_NTT_STAGES", 0, 0, NTT_TILE_LOG);
-        int tile_log = log_n <= 19 ? 9 : NTT_TILE_LOG;
+        int tile_log = log_n <= 19 ? 9 : 10;
         int max_s = log_n <= 19 ? 7 : 9;
         if (tile_env) tile_log = tile_env;
         if (stages_env) max_s = stages_env;

@@ -2,7 +2,12 @@
 
 `utils.SerializeCompiledCircuit` gob-encodes `CompiledCircuitBytes{Ccs, Pk, Vk []byte; Curve ecc.ID}` where the three byte
 slices are gnark's `WriteTo` outputs; `DeserializeCompiledCircuit` reverses it.  This module mirrors those two functions
-(same names) and the layers underneath, so a Go-less host can exchange compiled circuits with a Go AlgoPlonk process:
+(same names) and the layers underneath.  WHAT IS INTEROPERABLE WITH A GO PROCESS TODAY: the gob envelope and the kzg SRS
+encodings (pinned by the reference's own files).  What is NOT: the plonk Vk / Pk blobs (restated from memory, unpinned - and
+gnark's list very likely also carries the KZG verifying key's precomputed pairing lines `Kzg.Lines` between Kzg.G2[1] and
+CommitmentConstraintIndexes, which this writer does not emit and this reader refuses, loudly, as trailing bytes) and the
+constraint system (own tagged encoding; gnark's file is CBOR + intcomp-compressed blocks).  Files written
+here are therefore read back HERE; a circuit compiled by Go reaches libapk through the cgo shim, not a file.
 
 layer                                    | status
 -----------------------------------------+----------------------------------------------------------------------------------
@@ -364,7 +369,11 @@ def DeserializeCompiledCircuit(filepath: str, device: int = 0, slots: int = 1):
     except Exception as e:
         raise ValueError("error reading PK data: %s" % e)
     try:
-        vk = read_plonk_vk(cv, io.BytesIO(vk_b))
+        vr = io.BytesIO(vk_b)
+        vk = read_plonk_vk(cv, vr)
+        if vr.read(1):
+            raise ValueError("%d unconsumed byte(s) after the verifying key - a gnark-written key carries fields this reader does not "
+                             "know (e.g. Kzg.Lines): the plonk key layout here is unpinned" % (len(vk_b) - vr.tell() + 1))
     except Exception as e:
         raise ValueError("error reading VK data: %s" % e)
     pk, vk_now = plonk.Setup(ccs, srs, device=device, slots=slots)

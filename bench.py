@@ -506,7 +506,7 @@ def bench_prove(args, cv, rk) -> None:
 
 def skewed_leg(args, cv, rk, seed, uniform_value):
     """proofs/s on workloads.skewed_circuit (~80 % of the wire values in {0, 1}, the rest 16-bit or uniform), same size, same
-    number of concurrent callers, a sixth of the steps.  This prover commits the CANONICAL (blinded) wire polynomials: after the
+    number of concurrent callers, a quarter of the steps.  This prover commits the CANONICAL (blinded) wire polynomials: after the
     iNTT the MSM scalars are uniform whatever the witness looks like, so the rate must match the headline - the line checks it."""
     from algoplonk_amd import _lib, frontend, plonk, setup, workloads
     from algoplonk_amd._lib import lib, check
@@ -538,8 +538,8 @@ def skewed_leg(args, cv, rk, seed, uniform_value):
         for t in ts:
             t.join()
 
-    steps = max(3, args.steps // 6)
-    elapsed = rk.timed(step, steps, 2)
+    steps = max(6, args.steps // 4)
+    elapsed = rk.timed(step, steps, 3)
     ok = not errors
     if ok:
         try:
