@@ -490,7 +490,7 @@ def bench_prove(args, cv, rk) -> None:
             "data": "synthetic",
             "config": {"workload": name, "log_n": args.log_n, "curve": cv.name, "proofs_per_step": args.inflight,
                        "srs": "synthetic tau=SHA256(seed)", "parallelism": "replicas x%d" % rk.world, "world_size": rk.world,
-                       "backend": ("libapk comm: tcp control plane, %s data plane" % rk.comm.transport) if rk.world > 1 else "single process"},
+                       "backend": "libapk comm (barrier + MAX over TCP only: independent proofs exchange no data)" if rk.world > 1 else "single process"},
             "proof_latency_ms": round(lat_ms, 3), "msm_mscalar_per_s": round(msm_mscalar, 3),
             "msm_ms": round(msm_s * 1e3, 4), "msm_mscalar_per_s_saturated": round(msm_sat_mscalar, 3), "setup_s": round(setup_s, 2),
             "msm_batch_avg_ms": round(st.msm_total_ms / max(st.msm_batches, 1), 4),
