@@ -111,6 +111,8 @@ class Ranks:
         from algoplonk_amd import _lib, parallel
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if os.environ.get("APK_BENCH_SHARE_GPU") == "1":
+            self.local_rank = 0       # functional runs of the N > 1 modes on a one-GPU box: every rank on device 0 (NOT a measurement)
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         if self.world != args.gpus:
             raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world))
@@ -360,6 +362,11 @@ def bench_prove(args, cv, rk) -> None:
     from algoplonk_amd._lib import lib, check
 
     seed = {("bn254", 0): 0xA190, ("bls12_381", 0): 0xA191}.get((args.curve, args.bsb22), 0xA193)
+    # ---- the hard input FIRST, on a context of its own that is closed again before the headline context
+    # exists (measured behind it, with both contexts alive, the same leg read 7 % low whatever the witness was)
+    witness_bits = None
+    if rk.world == 1 and args.witness == "uniform" and not args.bsb22 and args.log_n <= 19:
+        witness_bits = skewed_leg(args, cv, rk, seed)
     t0 = time.time()
     pi2_host = None
     if args.bsb22:
@@ -455,10 +462,8 @@ def bench_prove(args, cv, rk) -> None:
         t.join()
     msm_sat_mscalar = sat_threads * sat_reps * n / (time.perf_counter() - s0) / 1e6
 
-    # ---- the hard input: the same measurement on a circuit whose wires are mostly 0 / 1 / 16-bit values
-    witness_bits = None
-    if rk.world == 1 and args.witness == "uniform" and not args.bsb22 and args.log_n <= 19:
-        witness_bits = skewed_leg(args, cv, rk, seed, value)
+    if witness_bits:
+        witness_bits["ratio_to_uniform"] = round(witness_bits["value"] / value, 4)
 
     pmc = None
     cpu_baseline = None
@@ -504,9 +509,9 @@ def bench_prove(args, cv, rk) -> None:
     rk.close()
 
 
-def skewed_leg(args, cv, rk, seed, uniform_value):
+def skewed_leg(args, cv, rk, seed):
     """proofs/s on workloads.skewed_circuit (~80 % of the wire values in {0, 1}, the rest 16-bit or uniform), same size, same
-    number of concurrent callers, a quarter of the steps.  This prover commits the CANONICAL (blinded) wire polynomials: after the
+    number of concurrent callers, a third of the steps.  This prover commits the CANONICAL (blinded) wire polynomials: after the
     iNTT the MSM scalars are uniform whatever the witness looks like, so the rate must match the headline - the line checks it."""
     from algoplonk_amd import _lib, frontend, plonk, setup, workloads
     from algoplonk_amd._lib import lib, check
@@ -538,8 +543,8 @@ def skewed_leg(args, cv, rk, seed, uniform_value):
         for t in ts:
             t.join()
 
-    steps = max(6, args.steps // 4)
-    elapsed = rk.timed(step, steps, 3)
+    steps = max(6, args.steps // 3)
+    elapsed = rk.timed(step, steps, args.warmup)
     ok = not errors
     if ok:
         try:
@@ -549,7 +554,7 @@ def skewed_leg(args, cv, rk, seed, uniform_value):
     pk.close()
     value = steps * args.inflight / elapsed
     return {"workload": wl.name, "wire_values_in_0_1": round(small, 3), "value": round(value, 3), "unit": "proofs/sec", "steps": steps,
-            "ratio_to_uniform": round(value / uniform_value, 4), "proof_verifies": ok}
+            "ratio_to_uniform": None, "proof_verifies": ok}
 
 
 def _with_g2(vk, cv, tau):

@@ -75,3 +75,27 @@ def test_split_proof_and_sharded_msm_between_processes_sharing_the_gpu(gpu, cnam
     res = [q.get(timeout=600) for _ in procs]
     [p.join(timeout=120) for p in procs]
     assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,extra", [("prove-split", ["--curve", "bls12_381", "--log-n", "12"]), ("msm-sharded", ["--log-n", "12"]),
+                                        ("prove", ["--log-n", "12", "--inflight", "2"])])
+def test_bench_py_runs_its_multi_rank_modes_under_the_contract_launcher(gpu, mode, extra):
+    """`python bench.py --gpus 2 ...` re-executes itself under torch.distributed.run (the contract's command line), the two ranks
+    rendezvous on libapk's communicator and rank 0 prints ONE JSON line with n_gpus = 2.  Functional only: both ranks share the
+    box's one GPU (APK_BENCH_SHARE_GPU=1), so the numbers mean nothing."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["APK_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", mode, "--steps", "3", "--warmup", "1",
+                        "--no-pmc", "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["steps"] == 3
+    if mode == "prove-split":
+        assert line["matches_single_gpu_proof"] is True and line["scaling"] == "strong"
+    if mode == "prove":
+        assert line["scaling"] == "weak" and line["value"] > 0
