@@ -19,6 +19,7 @@
 #include <sys/time.h>
 #include <unistd.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -149,6 +150,8 @@ struct apk_comm {
     std::vector<uint8_t> h_stage;
     bool split_on = false;
     uint64_t steps = 0;
+    std::mutex step_mu;             // leader: one step at a time (a context with several slots proves concurrently, and every
+                                    // proving thread calls the hooks; the workers serve the steps in the order they are announced)
 
     int fd_of(int r) const { return rank == 0 ? peer[r] : peer[0]; }
 };
@@ -513,6 +516,7 @@ int apk_msm_g1_sharded(apk_comm* c, const void* d_scalars, uint64_t len, void* o
 
 int apk_comm_commit(apk_comm* c, int basis, uint32_t count, const void* const* d_scalars, const uint32_t* lens, void* out_points) {
     if (!c || c->rank != 0 || !count || count > 4 || !d_scalars || !lens || !out_points) { set_error("comm: commit is the leader's call (1..4 commitments)"); return APK_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(c->step_mu);
     Header h{};
     h.op = OP_COMMIT; h.basis = basis; h.count = count;
     for (uint32_t i = 0; i < count; i++) h.lens[i] = lens[i];
@@ -522,6 +526,7 @@ int apk_comm_commit(apk_comm* c, int basis, uint32_t count, const void* const* d
 
 int apk_comm_wires(apk_comm* c, uint32_t count, const void* const* d_can, const uint32_t* lens, void* const* d_ev) {
     if (!c || c->rank != 0 || !count || count > 4 || !d_can || !lens || !d_ev) { set_error("comm: wires is the leader's call (1..4 polynomials)"); return APK_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(c->step_mu);
     Header h{};
     h.op = OP_WIRES; h.count = count;
     for (uint32_t i = 0; i < count; i++) h.lens[i] = lens[i];
