@@ -23,7 +23,11 @@ frstr/fpstr/hex/hexEncoded` at :43-106).  This script
   4. runs `verify()` on oracle proofs of the reference's test circuits for k = 0, 1, 2 BSB22 commitments on both curves, and
      on the reference's mutations (testutils/verifier_integration_test.go:188-228: flipped public-input byte, first G1
      point := second G1 point; :232-256: rekey) plus a non-canonical scalar and a truncated proof,
-  5. stores verdicts and intermediates (gamma, beta, alpha, zeta, PI, lin(zeta), [lin], folded digest, claims).
+  5. stores verdicts and intermediates (gamma, beta, alpha, zeta, PI, lin(zeta), [lin], folded digest, claims),
+  6. renders and runs the SMART-CONTRACT flavour of each verifier too (templateSmartContractBN254.go / ...BLS12_381.go: an ARC4
+     contract whose `verify(proof: DynamicArray[Bytes32], public_inputs: DynamicArray[Bytes32]) -> arc4.Bool` holds the same
+     logic over 32-byte words) on the same inputs and insists on the same verdict and intermediates: all four templates of the
+     reference are executed, and they agree with each other.
 tests/test_template_pin.py then holds oracle/plonk.py::verify, libapk's apk_verify and the HIP prover to this file.
 """
 from __future__ import annotations
@@ -58,7 +62,8 @@ def go_raw_string(path: str) -> str:
 class GoTemplate:
     """text/template subset.  Nodes: ("text", s) | ("action", expr) | ("range", ivar, evar, expr, body) | ("if", expr, body)."""
 
-    ACTION = re.compile(r"\{\{(-\s)?\s*(.*?)\s*(\s-)?\}\}", re.S)
+    # `{{/* ... */}}` comments may contain `}}` (templateSmartContractBN254.go:133 wraps a py.log call in one): matched first
+    ACTION = re.compile(r"\{\{(-\s)?\s*(/\*.*?\*/|.*?)\s*(\s-)?\}\}", re.S)
 
     def __init__(self, text: str, funcs: dict):
         self.funcs = dict(funcs)
@@ -94,6 +99,8 @@ class GoTemplate:
                     out.append(("text", t[1]))
                 continue
             body = t[1]
+            if body.startswith("/*"):
+                continue
             if body == "end":
                 return out
             if body.startswith("range"):
@@ -465,6 +472,50 @@ class _DynamicArray:
         return cls
 
 
+class _Bytes32:
+    """arc4.StaticArray[arc4.Byte, Literal[32]]: one 32-byte word of the proof / public-input arrays of the smart-contract
+    verifiers (templateSmartContractBN254.go:12)."""
+
+    def __init__(self, b=bytes(32)):
+        b = _bytes(b)
+        if len(b) != 32:
+            raise AvmError("Bytes32 of %d bytes" % len(b))
+        self.b = b
+
+    @property
+    def bytes(self) -> Bytes:
+        return Bytes(self.b)
+
+    def copy(self) -> "_Bytes32":
+        return _Bytes32(self.b)
+
+
+class _StaticArray:
+    def __class_getitem__(cls, item):
+        return _Bytes32
+
+
+class _WordArray(_DynamicArray):
+    @property
+    def length(self) -> UInt64:
+        return UInt64(len(self.items))
+
+
+class _ArcBool:
+    def __init__(self, v=False):
+        self.native = bool(v)
+
+    def __bool__(self):
+        return self.native
+
+
+def words(blob: bytes) -> _WordArray:
+    """utils.ProofAndPublicInputsForAtomicComposer (utils/utils.go:162-172,215-224): the blob as 32-byte words."""
+    if len(blob) % 32:
+        raise AvmError("blob is not a whole number of 32-byte words")
+    return _WordArray(*[_Bytes32(blob[i: i + 32]) for i in range(0, len(blob), 32)])
+
+
 class Avm:
     """Transaction context + the elliptic-curve opcodes, for one curve."""
 
@@ -577,22 +628,32 @@ def install_algopy(avm: Avm):
 
     class Global:
         zero_address = Bytes(bytes(32))
+        creator_address = Bytes(bytes([1]) * 32)
 
     def logicsig(name=None):
         return lambda f: f
+
+    def abimethod(*a, **kw):                    # @abimethod and @abimethod(create='require', ...)
+        if len(a) == 1 and callable(a[0]) and not kw:
+            return a[0]
+        return lambda f: f
+
+    class ARC4Contract:
+        pass
 
     algopy = types.ModuleType("algopy")
     arc4 = types.ModuleType("algopy.arc4")
     op = types.ModuleType("algopy.op")
     arc4.UInt256, arc4.DynamicArray = UInt256, _DynamicArray
+    arc4.abimethod, arc4.StaticArray, arc4.String, arc4.Byte, arc4.Bool = abimethod, _StaticArray, str, int, _ArcBool
     op.bzero, op.sha256, op.EllipticCurve, op.EC, op.setbit_bytes = bzero, sha256, EllipticCurve, EC, setbit_bytes
     for k, v in dict(logicsig=logicsig, subroutine=lambda f: f, BigUInt=BigUInt, Bytes=Bytes, UInt64=UInt64, urange=urange,
-                     arc4=arc4, op=op, Txn=Txn, Global=Global).items():
+                     arc4=arc4, op=op, Txn=Txn, Global=Global, ARC4Contract=ARC4Contract, log=lambda *a: None).items():
         setattr(algopy, k, v)
     sys.modules["algopy"], sys.modules["algopy.arc4"], sys.modules["algopy.op"] = algopy, arc4, op
 
 
-def run_template(program: str, avm: Avm, proof: bytes, public_inputs: bytes, rekey: bool = False):
+def run_template(program: str, avm: Avm, proof: bytes, public_inputs: bytes, rekey: bool = False, contract: bool = False):
     """One simulated logicsig evaluation.  app args = [method selector, arc4 byte[32][] proof, arc4 byte[32][] public inputs]
     (utils/utils.go:162-172,196-224; the logicsig strips the 2-byte count, templateLogicSigBN254.go:46-47)."""
     install_algopy(avm)
@@ -623,7 +684,13 @@ def run_template(program: str, avm: Avm, proof: bytes, public_inputs: bytes, rek
 
     sys.settrace(tracer)
     try:
-        ok = g["verify"]()
+        if contract:
+            # the ARC4 method `verify(proof: DynamicArray[Bytes32], public_inputs: DynamicArray[Bytes32]) -> arc4.Bool` of the
+            # smart-contract flavour (templateSmartContractBN254.go:54-58); a False return is what the caller's assert turns into a
+            # failed transaction (testutils/verifier_integration_test.go:379-437)
+            ok = bool(g["Verifier"]().verify(words(proof), words(public_inputs)))
+        else:
+            ok = g["verify"]()
         verdict, why = ("accept", "") if ok else ("reject", "returned False")
     except AssertionError:
         verdict, why = "reject", "assert"
@@ -752,29 +819,42 @@ def main():
     out = {"generator": "tests/golden/make_template_fixtures.py",
            "what": "verdicts and intermediates of the reference's rendered logicsig verifier templates, executed under an algopy/AVM shim",
            "templates": {}, "cases": []}
-    for ov, fname in ((ocurves.BN254, "templateLogicSigBN254.go"), (ocurves.BLS12_381, "templateLogicSigBLS12_381.go")):
+    for ov, fname, sc_name in ((ocurves.BN254, "templateLogicSigBN254.go", "templateSmartContractBN254.go"),
+                               (ocurves.BLS12_381, "templateLogicSigBLS12_381.go", "templateSmartContractBLS12_381.go")):
         ensure_mul_raw(ov)
         pr = pairing_module(ov)
-        path = os.path.join(REF, "verifier", fname)
-        out["templates"][fname] = {"sha256": hashlib.sha256(open(path, "rb").read()).hexdigest(),
-                                   "verifier.go_sha256": hashlib.sha256(open(os.path.join(REF, "verifier", "verifier.go"), "rb").read()).hexdigest()}
+        path, sc_path = os.path.join(REF, "verifier", fname), os.path.join(REF, "verifier", sc_name)
+        vgo = hashlib.sha256(open(os.path.join(REF, "verifier", "verifier.go"), "rb").read()).hexdigest()
+        for nm, pth in ((fname, path), (sc_name, sc_path)):
+            out["templates"][nm] = {"sha256": hashlib.sha256(open(pth, "rb").read()).hexdigest(), "verifier.go_sha256": vgo}
         tmpl = GoTemplate(go_raw_string(path), funcmap(ov))
+        sc_tmpl = GoTemplate(go_raw_string(sc_path), funcmap(ov))
         for name, builder, tau_seed, bl_seed in CASES:
             cs = build_case(ov, name, builder, tau_seed, bl_seed)
             vk = cs["vk"]
             g2 = [pr.G2_GEN, pr.g2_mul(pr.G2_GEN, cs["tau"])]
             program = tmpl.render(vk_view(ov, vk, g2))
+            sc_program = sc_tmpl.render(vk_view(ov, vk, g2))
             results = []
             for label, blob, pib, rekey in mutations(ov, cs["proof"], cs["public"]):
                 verdict, why, loc = run_template(program, Avm(ov, pr), blob, pib, rekey)
                 print("%-10s %-18s %-32s %s %s" % (ov.name, name, label, verdict, why), flush=True)
                 results.append({"mutation": label, "proof": blob.hex(), "public_inputs": pib.hex(), "rekey": rekey,
                                 "verdict": verdict, "why": why, "intermediates": intermediates(loc)})
+                if not rekey:
+                    # the smart-contract flavour of the same verifier (the rekey guard is a logicsig matter): same verdict, same
+                    # intermediates, or the two reference templates disagree with each other
+                    sc_verdict, sc_why, sc_loc = run_template(sc_program, Avm(ov, pr), blob, pib, False, contract=True)
+                    assert sc_verdict == verdict, (ov.name, name, label, verdict, why, sc_verdict, sc_why)
+                    a, b = intermediates(loc), intermediates(sc_loc)
+                    assert all(a[k] == b[k] for k in a if k in b), (ov.name, name, label)
+                    results[-1]["smart_contract"] = {"verdict": sc_verdict, "why": sc_why}
             assert results[0]["verdict"] == "accept" or name == "identity", (ov.name, name, results[0])
             out["cases"].append({
                 "curve": ov.name, "circuit": name, "tau_seed": tau_seed, "blinding_seed": bl_seed,
                 "bsb22_hiding": [list(h) for h in cs["hiding"]],
                 "rendered_program_sha256": hashlib.sha256(program.encode()).hexdigest(),
+                "rendered_smart_contract_sha256": hashlib.sha256(sc_program.encode()).hexdigest(),
                 "vk": {"size": vk.size, "size_inv": hex(vk.size_inv), "generator": hex(vk.generator), "coset_shift": vk.coset_shift,
                        "nb_public": vk.nb_public, "ql": pt_json(ov, vk.ql), "qr": pt_json(ov, vk.qr), "qm": pt_json(ov, vk.qm),
                        "qo": pt_json(ov, vk.qo), "qk": pt_json(ov, vk.qk), "s": [pt_json(ov, s) for s in vk.s],

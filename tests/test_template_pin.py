@@ -48,7 +48,8 @@ def _hexint(v):
 def test_the_fixture_names_its_generator_and_the_template_files():
     assert FIX["generator"] == "tests/golden/make_template_fixtures.py"
     assert os.path.exists(os.path.join(G, "make_template_fixtures.py"))
-    for name in ("templateLogicSigBN254.go", "templateLogicSigBLS12_381.go"):
+    # all four templates of the reference were rendered and run: the two logicsig verifiers and the two smart-contract ones
+    for name in ("templateLogicSigBN254.go", "templateLogicSigBLS12_381.go", "templateSmartContractBN254.go", "templateSmartContractBLS12_381.go"):
         assert len(FIX["templates"][name]["sha256"]) == 64 and len(FIX["templates"][name]["verifier.go_sha256"]) == 64
     # k = 0, 1, 2 commitments on both curves, the valid proof accepted, every mutation rejected
     seen = set()
@@ -58,6 +59,9 @@ def test_the_fixture_names_its_generator_and_the_template_files():
         assert verdicts.pop("valid") == "accept"
         assert verdicts and set(verdicts.values()) == {"reject"}
         assert {"public_input_byte_flipped", "first_g1_overwritten_by_second", "rekey"} <= set(verdicts)
+        # the smart-contract flavour (ARC4 method verify(proof, public_inputs) -> bool) gave the same verdict on every run
+        for r in c["results"]:
+            assert r["rekey"] or r["smart_contract"]["verdict"] == r["verdict"], (c["circuit"], r["mutation"])
     assert seen == {(cv, k) for cv in ("bn254", "bls12-381") for k in (0, 1, 2)}
     # circuits whose verifying key holds the point at infinity are in: [Qk] (pythagorean), [Qm] (identity, compile_test.go:13-20)
     assert any(c["vk"]["qm"] is None for c in CASES) and any(c["vk"]["qk"] is None for c in CASES)
