@@ -616,7 +616,8 @@ def test_commit_hook_and_ranged_batch_msm(gpu, cname):
 @pytest.mark.parametrize("cname", ["bn254", "bls12-381"])
 @pytest.mark.parametrize("nb_public", [0, 1, 7, 40])
 def test_prove_with_few_and_many_public_inputs(gpu, cname, nb_public):
-    """Edge cases of the public-input handling: none, one (the reference's identity circuit, compile_test.go:13-20), more rows
+    """Edge cases of the public-input handling on random-gate circuits: none, one (as many as the reference's identity circuit
+    has - that circuit itself, with [Qm] at infinity, is proved in tests/test_template_pin.py), more rows
     than the quotient kernel's direct Qk completion takes (falls back to iNTT + coset NTT of the completed column), and
     enough of them that PI(zeta) - the host-side sum behind lin(zeta) - has many Lagrange terms.  Byte-identical to the oracle."""
     cv, ov = CURVES[cname]
