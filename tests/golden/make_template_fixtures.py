@@ -86,10 +86,10 @@ class GoTemplate:
                 toks[i + 1] = ("text", nxt[1].lstrip(" \t\r\n"))
         self.toks = toks
         self.i = 0
-        self.tree = self._parse_block()
+        self.tree = self._parse_block(top=True)
         assert self.i == len(self.toks), "unbalanced {{ end }}"
 
-    def _parse_block(self):
+    def _parse_block(self, top=False):
         out = []
         while self.i < len(self.toks):
             t = self.toks[self.i]
@@ -102,6 +102,7 @@ class GoTemplate:
             if body.startswith("/*"):
                 continue
             if body == "end":
+                assert not top, "{{ end }} without a range / if"
                 return out
             if body.startswith("range"):
                 m = re.match(r"range\s+(\$\w+)\s*,\s*(\$\w+)\s*:=\s*(.*)$", body, re.S)
@@ -112,6 +113,7 @@ class GoTemplate:
             else:
                 assert not body.startswith(("else", "with", "define", "template", "block")), "unsupported action: " + body
                 out.append(("action", body))
+        assert top, "range / if without its {{ end }}"
         return out
 
     # ---- expressions -------------------------------------------------------------------------------------------------
@@ -815,6 +817,36 @@ def mutations(ov, blob: bytes, pib: bytes):
     return out
 
 
+def old_infinity_encoding_control():
+    """What the pin found, kept as a fixture: rounds 1-2 hashed infinity as 0x40 00.. on BOTH curves.  A BN254 proof made that
+    way (the prover's transcript sees 0x40.. for [Qk] = infinity of the Pythagorean circuit) is REJECTED by the executed BN254
+    template, which hashes the all-zero constant it also feeds to the ec ops."""
+    ov = ocurves.BN254
+    ensure_mul_raw(ov)
+    pr = pairing_module(ov)
+    tmpl = GoTemplate(go_raw_string(os.path.join(REF, "verifier", "templateLogicSigBN254.go")), funcmap(ov))
+    good_raw = type(ov).raw_bytes
+
+    def raw_bytes_0x40(self, P):
+        if P is None:
+            return bytes([0x40]) + bytes(2 * self.fp_bytes - 1)
+        return good_raw(self, P)
+
+    type(ov).raw_bytes = raw_bytes_0x40
+    try:
+        cs = build_case(ov, *CASES[0])                  # pythagorean: [Qk] is the point at infinity
+    finally:
+        type(ov).raw_bytes = good_raw
+    g2 = [pr.G2_GEN, pr.g2_mul(pr.G2_GEN, cs["tau"])]
+    verdict, why, loc = run_template(tmpl.render(vk_view(ov, cs["vk"], g2)), Avm(ov, pr), cs["proof"], cs["public"])
+    assert verdict == "reject", "the 0x40 encoding of infinity was expected to fail the BN254 template"
+    T = {}
+    assert not oplonk.verify(cs["vk"], cs["proof"], cs["public"], T)
+    print("negative control: BN254 proof with 0x40-encoded infinity in the transcript ->", verdict, why)
+    return {"what": "BN254 pythagorean proof whose prover hashed infinity as 0x40 00.. (the encoding of rounds 1-2)", "proof": cs["proof"].hex(),
+            "public_inputs": cs["public"].hex(), "verdict": verdict, "why": why, "gamma_of_the_template": intermediates(loc).get("gamma")}
+
+
 def main():
     out = {"generator": "tests/golden/make_template_fixtures.py",
            "what": "verdicts and intermediates of the reference's rendered logicsig verifier templates, executed under an algopy/AVM shim",
@@ -862,6 +894,7 @@ def main():
                        "g1": pt_json(ov, vk.g1),
                        "g2": [[[hex(c) for c in Q[0]], [hex(c) for c in Q[1]]] for Q in g2]},
                 "results": results})
+    out["negative_control"] = old_infinity_encoding_control()
     json.dump(out, open(os.path.join(HERE, "template_verdicts.json"), "w"), indent=1)
     print("wrote template_verdicts.json:", len(out["cases"]), "cases")
 
