@@ -2,8 +2,10 @@
 //
 //   control plane  TCP star through rank 0: rendezvous, headers, status words + 64/96-byte partial sums, barriers
 //   data plane     RCCL (librccl dlopen'ed, libapk's own HIP runtime and stream): grouped ncclSend/ncclRecv for the scatter of
-//                  scalar slices and for the peer copies of polynomials; or - two ranks on one GPU, no librccl, CPU tier tests -
-//                  the same bytes staged through the host and the TCP star
+//                  scalar slices and for the peer copies of polynomials; or HIP IPC: the sender exports its staging buffer
+//                  (hipIpcGetMemHandle), the receiver maps it and PULLS its bytes with one device-to-device copy (over xGMI between
+//                  GPUs, on-device when two ranks share a GPU) - used when RCCL cannot be (ranks sharing a device, no librccl,
+//                  APK_COMM_RCCL=0); or - CPU tier tests, IPC refused - the same bytes staged through the host and the TCP star
 //   schedules      sharded MSM (BASELINE configs[3]); split proof: commitment batches dealt by index range, optional per-wire
 //                  coset evaluations dealt by wire
 //
@@ -143,6 +145,13 @@ struct apk_comm {
     ncclComm_t nccl = nullptr;
     hipStream_t stream = nullptr;
     int device = -1;
+    // HIP IPC data plane: every rank exports ONE buffer (leader: d_stage, workers: d_wire_out); peers map it and pull
+    bool ipc = false;
+    uint32_t export_gen = 0;                             // bumped whenever the exported buffer is reallocated
+    hipIpcMemHandle_t export_handle{};
+    struct Mapping { uint32_t gen = 0; void* p = nullptr; };
+    std::vector<Mapping> maps;                           // by peer rank
+    std::vector<void*> retired;                          // exported buffers that were outgrown: freed at destroy (peers may map them)
     // grow-only staging
     void* d_stage = nullptr; size_t stage_cap = 0;       // leader: world x chunk; workers: chunk
     void* d_wire_in = nullptr; size_t wire_in_cap = 0;   // workers: a canonical polynomial
@@ -192,11 +201,53 @@ static void resolve_compute(apk_comm* c) {
 
 static int ensure(apk_comm* c, void** p, size_t* cap, size_t need) {
     if (*cap >= need && *p) return APK_OK;
-    if (*p) { (void)c->cp.release(CP_USER(c, release), *p); *p = nullptr; *cap = 0; }
-    const size_t want = need + need / 8 + 256;
+    const bool exported = c->ipc && p == (c->rank == 0 ? &c->d_stage : &c->d_wire_out);
+    if (*p) {
+        if (exported) c->retired.push_back(*p);          // a peer may still have it mapped
+        else (void)c->cp.release(CP_USER(c, release), *p);
+        *p = nullptr; *cap = 0;
+    }
+    const size_t want = exported ? need * 2 + 4096 : need + need / 8 + 256;
     CHK(c->cp.alloc(CP_USER(c, alloc), want, p));
     *cap = want;
+    if (exported) {
+        HCHK(hipSetDevice(c->device));
+        HCHK(hipIpcGetMemHandle(&c->export_handle, *p));
+        c->export_gen++;
+    }
     return APK_OK;
+}
+
+// ---- HIP IPC transfers: {generation, handle, offset, bytes} over the control plane, one device-to-device pull, one ack ----
+struct IpcMsg { uint32_t gen, pad; uint64_t offset, bytes; hipIpcMemHandle_t h; };
+static int ipc_offer(apk_comm* c, int fd, size_t offset, size_t bytes) {      // the exporter's side
+    IpcMsg m{};
+    m.gen = c->export_gen; m.offset = offset; m.bytes = bytes; m.h = c->export_handle;
+    return send_all(fd, &m, sizeof m);
+}
+static int ipc_wait_ack(int fd) {
+    int32_t st = APK_OK;
+    CHK(recv_all(fd, &st, 4));
+    if (st != APK_OK) { set_error("comm: the peer could not pull from the exported buffer (code %d)", st); return APK_ERR_HIP; }
+    return APK_OK;
+}
+static int ipc_pull(apk_comm* c, int from_rank, int fd, void* d_dst, size_t expect) {   // the importer's side
+    IpcMsg m{};
+    CHK(recv_all(fd, &m, sizeof m));
+    int32_t st = APK_OK;
+    hipError_t e = hipSetDevice(c->device);
+    apk_comm::Mapping& mp = c->maps[from_rank];
+    if (e == hipSuccess && (mp.gen != m.gen || !mp.p)) {
+        if (mp.p) (void)hipIpcCloseMemHandle(mp.p);
+        mp.p = nullptr;
+        e = hipIpcOpenMemHandle(&mp.p, m.h, hipIpcMemLazyEnablePeerAccess);
+        mp.gen = m.gen;
+    }
+    if (e == hipSuccess && m.bytes != expect) { set_error("comm: peer offered %llu bytes, %llu expected", (unsigned long long)m.bytes, (unsigned long long)expect); st = APK_ERR_STATE; }
+    if (e == hipSuccess && st == APK_OK) e = hipMemcpy(d_dst, (const uint8_t*)mp.p + m.offset, m.bytes, hipMemcpyDeviceToDevice);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error("comm: IPC pull failed: %s", hipGetErrorString(e)); st = APK_ERR_HIP; }
+    CHK(send_all(fd, &st, 4));
+    return st;
 }
 
 // ---- control-plane collectives (host memory) ------------------------------------------------------------------------------------
@@ -234,6 +285,16 @@ static int data_scatter(apk_comm* c, const void* d_all, void* d_mine, size_t chu
         HCHK(hipStreamSynchronize(c->stream));
         return APK_OK;
     }
+    if (c->ipc) {
+        // d_all is the leader's exported staging buffer: every worker pulls its chunk at once, the leader collects the acks
+        if (c->rank == 0) {
+            for (int r = 1; r < c->world; r++) CHK(ipc_offer(c, c->peer[r], (size_t)r * chunk, chunk));
+            int rc = APK_OK;
+            for (int r = 1; r < c->world; r++) { const int a = ipc_wait_ack(c->peer[r]); if (a != APK_OK) rc = a; }
+            return rc;
+        }
+        return ipc_pull(c, 0, c->peer[0], d_mine, chunk);
+    }
     if (c->h_stage.size() < chunk) c->h_stage.resize(chunk);
     if (c->rank == 0) {
         for (int r = 1; r < c->world; r++) {
@@ -257,6 +318,22 @@ static int data_p2p(apk_comm* c, int w, bool to_worker, void* d_buf, size_t byte
         NCHK(g_rccl.GroupEnd());
         HCHK(hipStreamSynchronize(c->stream));
         return APK_OK;
+    }
+    if (c->ipc) {
+        const int fd = c->fd_of(w);
+        if (!sending) return ipc_pull(c, c->rank == 0 ? w : 0, fd, d_buf, bytes);
+        // the leader's payload is a buffer of the prover: copied into the exported staging buffer first; a worker's payload IS its
+        // exported buffer (d_wire_out)
+        size_t off = 0;
+        if (c->rank == 0) {
+            CHK(ensure(c, &c->d_stage, &c->stage_cap, bytes));
+            CHK(c->cp.copy(CP_USER(c, copy), c->d_stage, d_buf, bytes, 0));
+        } else if (d_buf != c->d_wire_out) {
+            set_error("comm: a worker sends from its exported buffer only");
+            return APK_ERR_STATE;
+        }
+        CHK(ipc_offer(c, fd, off, bytes));
+        return ipc_wait_ack(fd);
     }
     if (c->h_stage.size() < bytes) c->h_stage.resize(bytes);
     const int fd = c->fd_of(w);
@@ -425,6 +502,8 @@ void apk_comm_destroy(apk_comm* c) {
         if (c->d_wire_in) (void)c->cp.release(CP_USER(c, release), c->d_wire_in);
         if (c->d_wire_out) (void)c->cp.release(CP_USER(c, release), c->d_wire_out);
     }
+    for (auto& mp : c->maps) if (mp.p) (void)hipIpcCloseMemHandle(mp.p);
+    if (c->cp.release) for (void* q : c->retired) (void)c->cp.release(CP_USER(c, release), q);
     if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (int fd : c->peer) if (fd >= 0) close(fd);
@@ -434,7 +513,7 @@ void apk_comm_destroy(apk_comm* c) {
 
 int apk_comm_rank(const apk_comm* c) { return c ? c->rank : -1; }
 int apk_comm_world(const apk_comm* c) { return c ? c->world : 0; }
-const char* apk_comm_transport(const apk_comm* c) { return c && c->rccl ? "rccl" : "tcp"; }
+const char* apk_comm_transport(const apk_comm* c) { return c && c->rccl ? "rccl" : c && c->ipc ? "ipc" : "tcp"; }
 
 int apk_comm_barrier(apk_comm* c) {
     if (!c) { set_error("null communicator"); return APK_ERR_ARG; }
@@ -487,6 +566,38 @@ int apk_comm_bind(apk_comm* c, apk_ctx* ctx) {
         NCHK(g_rccl.CommInitRank(&c->nccl, c->world, id, c->rank));
     }
     c->rccl = all_can && c->nccl;
+    // HIP IPC when RCCL is not in use and every rank holds device memory: each rank exports its buffer once and the next rank
+    // tries to map it - any refusal (no dmabuf IPC, containers without /dev/kfd sharing ...) and ALL ranks fall back to the TCP star
+    c->ipc = false;
+    c->maps.assign(c->world, apk_comm::Mapping{});
+    if (!c->rccl && c->world > 1) {
+        int32_t mine_ok = (dev >= 0 && env_int("APK_COMM_IPC", 1, 0, 1)) ? 1 : 0;
+        std::vector<int32_t> oks(c->world);
+        CHK(ctl_allgather(c, &mine_ok, oks.data(), 4));
+        bool try_ipc = true;
+        for (int32_t v : oks) try_ipc = try_ipc && v;
+        if (try_ipc) {
+            c->device = dev;
+            c->ipc = true;                              // ensure() exports what it allocates from here on
+            void** slot = c->rank == 0 ? &c->d_stage : &c->d_wire_out;
+            size_t* cap = c->rank == 0 ? &c->stage_cap : &c->wire_out_cap;
+            int32_t ok = ensure(c, slot, cap, 4096) == APK_OK ? 1 : 0;
+            std::vector<hipIpcMemHandle_t> hs(c->world);
+            CHK(ctl_allgather(c, &c->export_handle, hs.data(), sizeof(hipIpcMemHandle_t)));
+            CHK(ctl_allgather(c, &ok, oks.data(), 4));
+            bool all_ok = true;
+            for (int32_t v : oks) all_ok = all_ok && v;
+            if (all_ok) {
+                void* probe = nullptr;
+                const int nxt = (c->rank + 1) % c->world;
+                if (hipSetDevice(dev) != hipSuccess || hipIpcOpenMemHandle(&probe, hs[nxt], hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok = 0; }
+                else (void)hipIpcCloseMemHandle(probe);
+            }
+            CHK(ctl_allgather(c, &ok, oks.data(), 4));
+            for (int32_t v : oks) all_ok = all_ok && v;
+            c->ipc = all_ok;
+        }
+    }
     return APK_OK;
 }
 

@@ -1,6 +1,7 @@
 """GPU tier: libapk's communicator with real contexts.  The GPU boxes of this tier have ONE MI355X, so two (and three) ranks
 share device 0: RCCL refuses two ranks on one device, the communicator notices (apk_comm_bind compares the ranks' device
-ordinals) and stages the data plane through the host and its TCP star - every other line of csrc/comm.cpp (the dealing,
+ordinals) and moves the data plane to HIP IPC pulls (or, IPC off / refused, stages it through the host and its TCP star) -
+every other line of csrc/comm.cpp (the dealing,
 apk_msm_g1_batch_device over dealt index ranges, the per-wire dealing through apk_coset_ntt_device, the worker loop, the commit
 and wire hooks inside apk_prove) is what an 8-GPU node runs."""
 import ctypes as C
@@ -13,10 +14,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q, cname, split_wires):
+def _worker(rank, world, port, q, cname, split_wires, ipc):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     try:
+        os.environ["APK_COMM_IPC"] = "1" if ipc else "0"
         if split_wires:
             os.environ["APK_SPLIT_WIRES"] = "1"
         from algoplonk_amd import MarshalProof, _lib, parallel, plonk as ap_plonk, setup as ap_setup
@@ -31,7 +33,10 @@ def _worker(rank, world, port, q, cname, split_wires):
         srs = ap_setup.unsafe_srs(cv, ccs.domain_size(), tau, device=0)
         pk, vk = ap_plonk.Setup(ccs, srs, device=0)
         comm.bind(pk.ctx)
-        assert comm.transport == "tcp"                # two ranks on one device: host-staged data plane
+        # two ranks on one device: RCCL refuses; HIP IPC (the receiver maps the sender's staging buffer and pulls) unless it was
+        # switched off or the box refuses to share the allocation - then the host-staged TCP star
+        assert comm.transport in (("ipc", "tcp") if ipc else ("tcp",)), comm.transport
+        transport = comm.transport
         bl = blinding(cv, 5)
         if rank == 0:
             plain = MarshalProof(ap_plonk.Prove(ccs, pk, w, bl))
@@ -57,24 +62,27 @@ def _worker(rank, world, port, q, cname, split_wires):
         comm2.close()
         comm.close()
         pk.close()
-        q.put((rank, "ok"))
+        q.put((rank, "ok " + transport))
     except Exception as e:
         import traceback
         q.put((rank, "FAIL: %r %s" % (e, traceback.format_exc()[-900:])))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cname,world,split_wires", [("bn254", 2, False), ("bls12-381", 2, True), ("bn254", 3, True)])
-def test_split_proof_and_sharded_msm_between_processes_sharing_the_gpu(gpu, cname, world, split_wires):
+@pytest.mark.parametrize("cname,world,split_wires,ipc", [("bn254", 2, False, True), ("bls12-381", 2, True, True), ("bn254", 3, True, True),
+                                                         ("bn254", 2, True, False)])
+def test_split_proof_and_sharded_msm_between_processes_sharing_the_gpu(gpu, cname, world, split_wires, ipc):
     from algoplonk_amd.parallel import free_port
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, cname, split_wires)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, cname, split_wires, ipc)) for r in range(world)]
     [p.start() for p in procs]
     res = [q.get(timeout=600) for _ in procs]
     [p.join(timeout=120) for p in procs]
-    assert sorted(res) == [(r, "ok") for r in range(world)], res
+    assert all(r[1].startswith("ok") for r in res) and sorted(r[0] for r in res) == list(range(world)), res
+    assert len({r[1] for r in res}) == 1, res        # every rank agreed on the data plane
+    print("data plane:", res[0][1][3:])
 
 
 @pytest.mark.gpu
@@ -99,3 +107,31 @@ def test_bench_py_runs_its_multi_rank_modes_under_the_contract_launcher(gpu, mod
         assert line["matches_single_gpu_proof"] is True and line["scaling"] == "strong"
     if mode == "prove":
         assert line["scaling"] == "weak" and line["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_the_contract_fields(gpu):
+    """One small default-mode run of bench.py (2^12, a few steps): ONE JSON line with the contract's keys, the `roofline` object of
+    the dominant kernel (HIP-event launch time, algorithmic bytes, PMC traffic when rocprofv3 is there) and the `cpu_baseline`
+    object (the C oracle on the host cores, proof hash equal to the GPU's)."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log-n", "12", "--steps", "4", "--warmup", "1", "--inflight", "4",
+                        "--cpu-baseline-seconds", "2"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = lines[0]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["metric"] == "proofs/sec" and d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 4 * 4 / (d["ms_per_step"] * 4 / 1e3)) / d["value"] < 0.01          # value = proofs of the timed steps / their time
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma", "valu") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["kernel"] == "msm_accumulate_kernel"
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-5 and (rf["traffic"] is None or rf["traffic"] > 0)
+    assert abs(rf["achieved"] - rf["pairs_per_launch"] * rf["algorithmic_bytes_per_pair"] / (rf["avg_launch_ms"] * 1e-3) / 1e9) / rf["achieved"] < 0.01
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["unit"] == "proofs/sec" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert cb["matches_gpu_proof"] is True
+    assert len(d["round_ms"]) == 4 and d["witness_bits"]["proof_verifies"] is True
