@@ -244,7 +244,10 @@ static int ipc_pull(apk_comm* c, int from_rank, int fd, void* d_dst, size_t expe
         mp.gen = m.gen;
     }
     if (e == hipSuccess && m.bytes != expect) { set_error("comm: peer offered %llu bytes, %llu expected", (unsigned long long)m.bytes, (unsigned long long)expect); st = APK_ERR_STATE; }
-    if (e == hipSuccess && st == APK_OK) e = hipMemcpy(d_dst, (const uint8_t*)mp.p + m.offset, m.bytes, hipMemcpyDeviceToDevice);
+    // hipMemcpy device-to-device returns before the copy is done and the contexts' streams are non-blocking (they do not order
+    // themselves behind the null stream): copy on the communicator's own stream and wait for it
+    if (e == hipSuccess && st == APK_OK) e = hipMemcpyAsync(d_dst, (const uint8_t*)mp.p + m.offset, m.bytes, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess && st == APK_OK) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { (void)hipGetLastError(); set_error("comm: IPC pull failed: %s", hipGetErrorString(e)); st = APK_ERR_HIP; }
     CHK(send_all(fd, &st, 4));
     return st;
@@ -578,6 +581,7 @@ int apk_comm_bind(apk_comm* c, apk_ctx* ctx) {
         for (int32_t v : oks) try_ipc = try_ipc && v;
         if (try_ipc) {
             c->device = dev;
+            if (!c->stream) { HCHK(hipSetDevice(dev)); HCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); }
             c->ipc = true;                              // ensure() exports what it allocates from here on
             void** slot = c->rank == 0 ? &c->d_stage : &c->d_wire_out;
             size_t* cap = c->rank == 0 ? &c->stage_cap : &c->wire_out_cap;
