@@ -199,6 +199,19 @@ static void resolve_compute(apk_comm* c) {
 // the user pointer an entry runs with: replaced entries get the table's, built-in ones the communicator
 #define CP_USER(c, field) ((c)->have_user_cp && (c)->user_cp.field ? (c)->user_cp.user : (void*)(c))
 
+// everything that was allocated through the bound context (or the compute table) goes back to it: before the binding changes and
+// before the communicator dies - the context must still be alive then (apk_comm_bind(comm, NULL) before apk_ctx_destroy)
+static void release_buffers(apk_comm* c) {
+    for (auto& mp : c->maps) if (mp.p) { (void)hipIpcCloseMemHandle(mp.p); mp.p = nullptr; mp.gen = 0; }
+    if (c->cp.release) {
+        void** bufs[3] = {&c->d_stage, &c->d_wire_in, &c->d_wire_out};
+        size_t* caps[3] = {&c->stage_cap, &c->wire_in_cap, &c->wire_out_cap};
+        for (int i = 0; i < 3; i++) if (*bufs[i]) { (void)c->cp.release(CP_USER(c, release), *bufs[i]); *bufs[i] = nullptr; *caps[i] = 0; }
+        for (void* q : c->retired) (void)c->cp.release(CP_USER(c, release), q);
+    }
+    c->retired.clear();
+}
+
 static int ensure(apk_comm* c, void** p, size_t* cap, size_t need) {
     if (*cap >= need && *p) return APK_OK;
     const bool exported = c->ipc && p == (c->rank == 0 ? &c->d_stage : &c->d_wire_out);
@@ -500,13 +513,7 @@ int apk_comm_create(int rank, int world, const char* addr, int port, apk_comm** 
 void apk_comm_destroy(apk_comm* c) {
     if (!c) return;
     if (c->split_on && c->rank == 0) (void)apk_comm_split_end(c);
-    if (c->cp.release) {
-        if (c->d_stage) (void)c->cp.release(CP_USER(c, release), c->d_stage);
-        if (c->d_wire_in) (void)c->cp.release(CP_USER(c, release), c->d_wire_in);
-        if (c->d_wire_out) (void)c->cp.release(CP_USER(c, release), c->d_wire_out);
-    }
-    for (auto& mp : c->maps) if (mp.p) (void)hipIpcCloseMemHandle(mp.p);
-    if (c->cp.release) for (void* q : c->retired) (void)c->cp.release(CP_USER(c, release), q);
+    release_buffers(c);
     if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (int fd : c->peer) if (fd >= 0) close(fd);
@@ -543,9 +550,11 @@ int apk_comm_set_compute(apk_comm* c, const apk_compute* t) {
 
 int apk_comm_bind(apk_comm* c, apk_ctx* ctx) {
     if (!c) { set_error("null communicator"); return APK_ERR_ARG; }
+    release_buffers(c);                       // they belong to the previous binding
+    c->ipc = false;
     c->ctx = ctx;
     resolve_compute(c);
-    if (!ctx && !(c->have_user_cp && c->user_cp.msm_batch)) { set_error("comm: no context and no compute table"); return APK_ERR_ARG; }
+    if (!ctx && !(c->have_user_cp && c->user_cp.msm_batch)) return APK_OK;     // unbound: call before the context is destroyed
     // data plane: RCCL when every rank owns a different GPU; the ranks agree through the control plane
     c->rccl = false;
     int32_t dev = -1;

@@ -203,6 +203,7 @@ class ShardedMsm:
 
     def close(self) -> None:
         if self._ctx:
+            self.comm.bind(None)                  # the communicator's staging buffers were allocated through this context
             if self._d:
                 lib.apk_device_free(self._ctx, self._d)
             lib.apk_ctx_destroy(self._ctx)

@@ -172,9 +172,10 @@ int apk_coset_ntt_device(apk_ctx* ctx, const void* d_canonical, uint64_t len, vo
  *   control plane : a TCP star through rank 0 (rendezvous, headers, the 64/96-byte partial sums, barriers) - apk_comm_create;
  *   data plane    : RCCL over xGMI on libapk's OWN HIP runtime and stream (ncclSend/ncclRecv groups for the scatter of scalar
  *                   slices and the peer copies of polynomials; librccl is dlopen'ed by apk_comm_bind when world > 1, each rank
- *                   owns a different GPU and APK_COMM_RCCL is not 0); otherwise the same bytes are staged through the host
- *                   and the TCP star - that is what the CPU tier tests drive (two processes, no GPU) and what lets two ranks
- *                   share ONE GPU in the GPU tier.
+ *                   owns a different GPU and APK_COMM_RCCL is not 0); else HIP IPC (the sender exports its staging buffer, the
+ *                   receiver maps it and pulls with one device-to-device copy: peer reads over xGMI between GPUs, on-device
+ *                   copies when ranks share a GPU; APK_COMM_IPC=0 switches it off); else the same bytes are staged through the
+ *                   host and the TCP star - what the CPU tier tests drive (two processes, no GPU).
  * Schedules (csrc/comm.cpp):
  *   apk_msm_g1_sharded : BASELINE configs[3] - ONE MSM split by index range: every rank commits its slice on the MSM-only
  *                        context bound to the communicator, ONE all-gather of a 64/96-byte point per rank, local additions;
@@ -195,9 +196,11 @@ int apk_comm_rank(const apk_comm* comm);
 int apk_comm_world(const apk_comm* comm);
 int apk_comm_barrier(apk_comm* comm);
 int apk_comm_max_f64(apk_comm* comm, double* value);       /* in place: maximum over the ranks (bench.py's timing protocol) */
-/* This rank's context (a circuit context for the split proof, an MSM-only context for the sharded MSM) and the data plane. */
+/* This rank's context (a circuit context for the split proof, an MSM-only context for the sharded MSM) and the data plane.
+ * Collective: every rank calls it.  The communicator allocates its staging buffers through the bound context, so the context
+ * must outlive the binding: apk_comm_bind(comm, NULL) (not collective) or apk_comm_destroy BEFORE apk_ctx_destroy. */
 int apk_comm_bind(apk_comm* comm, apk_ctx* ctx);
-const char* apk_comm_transport(const apk_comm* comm);      /* "rccl" or "tcp" (after apk_comm_bind) */
+const char* apk_comm_transport(const apk_comm* comm);      /* "rccl", "ipc" or "tcp" (after apk_comm_bind) */
 int apk_msm_g1_sharded(apk_comm* comm, const void* d_scalars, uint64_t len, void* out);
 int apk_comm_split_begin(apk_comm* comm);
 int apk_comm_split_end(apk_comm* comm);

@@ -19,6 +19,7 @@ def _worker(rank, world, port, q, cname, split_wires, ipc):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     try:
         os.environ["APK_COMM_IPC"] = "1" if ipc else "0"
+        os.environ["APK_COMM_TIMEOUT_S"] = "30"          # a rank that dies must not keep its peers (and the GPU box) waiting
         if split_wires:
             os.environ["APK_SPLIT_WIRES"] = "1"
         from algoplonk_amd import MarshalProof, _lib, parallel, plonk as ap_plonk, setup as ap_setup
@@ -78,8 +79,8 @@ def test_split_proof_and_sharded_msm_between_processes_sharing_the_gpu(gpu, cnam
     port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, cname, split_wires, ipc)) for r in range(world)]
     [p.start() for p in procs]
-    res = [q.get(timeout=600) for _ in procs]
-    [p.join(timeout=120) for p in procs]
+    res = [q.get(timeout=240) for _ in procs]
+    [p.join(timeout=60) for p in procs]
     assert all(r[1].startswith("ok") for r in res) and sorted(r[0] for r in res) == list(range(world)), res
     assert len({r[1] for r in res}) == 1, res        # every rank agreed on the data plane
     print("data plane:", res[0][1][3:])
