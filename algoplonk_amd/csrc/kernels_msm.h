@@ -255,8 +255,14 @@ __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_apply_kernel(const ui
 }
 
 // ---- bucket accumulation: one lane per work unit ---------------------------------------------------------
+// Minimum waves per SIMD asked of the compiler for the 14-limb field: 2 (181 VGPRs).  3 (168 VGPRs, 52 bytes of scratch per lane)
+// was measured on one box, interleaved: 1 009-1 024 against 1 040-1 064 proofs/s at BLS12-381 2^14, no difference at 2^21.
+#ifndef APK_ACC_WAVES_BLS
+#define APK_ACC_WAVES_BLS 2
+#endif
+template <class FP> struct MsmAcc { static constexpr int MIN_WAVES = FP::N > 8 ? APK_ACC_WAVES_BLS : 1; };
 template <class FP>
-__global__ void __launch_bounds__(128) msm_accumulate_kernel(const Affine<FP>* __restrict__ table,
+__global__ void __launch_bounds__(128, MsmAcc<FP>::MIN_WAVES) msm_accumulate_kernel(const Affine<FP>* __restrict__ table,
                                                              const uint32_t* __restrict__ sorted,
                                                              const uint32_t* __restrict__ offsets,
                                                              const uint32_t* __restrict__ unit_off,
