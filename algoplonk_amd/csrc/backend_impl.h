@@ -341,11 +341,21 @@ class CurveBackend : public Backend {
         static const uint32_t unit_env = (uint32_t)env_int("APK_MSM_UNIT", 0, 0, MSM_UNIT_MAX);
         uint32_t unit = unit_env;
         if (!unit) {
-            uint64_t best = ~0ull;
-            for (uint32_t u = MSM_UNIT; u <= MSM_UNIT + 2; u++) {
-                const uint64_t full_units = entries / u > total_buckets / 2 ? entries / u - total_buckets / 2 : 1;
-                const uint64_t cost = (uint64_t)cdiv(cdiv(full_units, 64), simds_) * u;
-                if (cost < best) { best = cost; unit = u; }
+            // Large batches have lanes to spare: with 16-entry units a bucket of a 2^21 MSM (1 024 entries at c = 16) is merged from
+            // 64 partial sums - 63 general additions of 14 products beside 1 024 mixed ones of 10, +8.6 % - and every unit pays its
+            // first two cheap steps once.  Keep >= 8 waves per SIMD of full units and let the unit grow to MSM_UNIT_MAX beyond that
+            // (round 3, BLS12-381 2^21 on one box: 16 -> 15.6, 24 -> 16.1, 32 -> 15.9, 48 -> 16.3, 64 -> 16.3 proofs/s).
+            const uint64_t lanes_wanted = (uint64_t)simds_ * 64 * 8;
+            const uint64_t by_size = entries / lanes_wanted;
+            if (by_size >= 24) {
+                unit = by_size > (uint64_t)MSM_UNIT_MAX ? (uint32_t)MSM_UNIT_MAX : (uint32_t)by_size;
+            } else {
+                uint64_t best = ~0ull;
+                for (uint32_t u = MSM_UNIT; u <= MSM_UNIT + 2; u++) {
+                    const uint64_t full_units = entries / u > total_buckets / 2 ? entries / u - total_buckets / 2 : 1;
+                    const uint64_t cost = (uint64_t)cdiv(cdiv(full_units, 64), simds_) * u;
+                    if (cost < best) { best = cost; unit = u; }
+                }
             }
         }
         if (unit < (uint32_t)MSM_UNIT_MIN) unit = MSM_UNIT_MIN;
