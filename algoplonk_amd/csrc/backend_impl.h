@@ -127,10 +127,6 @@ class CurveBackend : public Backend {
     struct Slot {
         hipStream_t stream = nullptr;
         hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
-        // a second stream for the coset NTTs that have nothing to do with the commitment queued beside them (prove(): rounds 1
-        // and 2), forked and joined with events; used only while this is the one proof in flight on the context
-        hipStream_t side = nullptr;
-        hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
         bool busy = false;
         // polynomials
         DevBuf wl, wr, wo;             // L,R,O Lagrange (n)
@@ -192,7 +188,6 @@ class CurveBackend : public Backend {
     // intra-proof multi-GPU (apk_ctx_set_commit_hook): the prover's commitments go through the host's hook instead of this GPU
     apk_commit_hook hook_ = nullptr;
     void* hook_user_ = nullptr;
-    int want_slots_ = 1;            // slots of a circuit context (MSM-only contexts have one)
     apk_wire_hook wire_hook_ = nullptr;
     void* wire_hook_user_ = nullptr;
     // stats
@@ -211,9 +206,6 @@ class CurveBackend : public Backend {
             if (s->ev2) (void)hipEventDestroy(s->ev2);
             if (s->ev3) (void)hipEventDestroy(s->ev3);
             if (s->h_pinned) (void)hipHostFree(s->h_pinned);
-            if (s->side) (void)hipStreamSynchronize(s->side);
-            for (int i = 0; i < 2; i++) { if (s->ev_fork[i]) (void)hipEventDestroy(s->ev_fork[i]); if (s->ev_join[i]) (void)hipEventDestroy(s->ev_join[i]); }
-            if (s->side) (void)hipStreamDestroy(s->side);
             if (s->stream) (void)hipStreamDestroy(s->stream);
             delete s;
         }
@@ -243,12 +235,12 @@ class CurveBackend : public Backend {
         for (int i = 0; i < count; i++) { nb.in[i] = ins[i]; nb.out[i] = outs[i]; nb.in_len[i] = in_lens[i]; }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         Slot* owner = nullptr;
-        for (Slot* s : slots_) if (s->stream == st || (s->side && s->side == st)) owner = s;
+        for (Slot* s : slots_) if (s->stream == st) owner = s;
         if (passes > 1) {   // the passes hand each other unsaturated-limb elements through the slot's scratch
             if (!owner || log_n > 30) { set_error("ntt: no workspace for this stream"); return APK_ERR_STATE; }
             for (int i = 0; i < count; i++) nb.wide[i] = ptr<FeU<FRP>>(owner->ntt_wide) + ((size_t)i << log_n);
         }
-        Slot* timed = stats_on_ && owner && owner->stream == st ? owner : nullptr;
+        Slot* timed = stats_on_ ? owner : nullptr;
         if (timed) { e0 = timed->ev2; e1 = timed->ev3; HIPCHK(hipEventRecord(e0, st)); }
         int t0 = 0;
         for (int p = 0; p < passes; p++) {
@@ -525,14 +517,6 @@ class CurveBackend : public Backend {
 
     int alloc_slot(Slot& s) {
         HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-        static const int side_env = env_int("APK_SIDE_STREAM", 0, 0, 1);
-        if (side_env && !msm_only_) {
-            HIPCHK(hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking));
-            for (int i = 0; i < 2; i++) {
-                HIPCHK(hipEventCreateWithFlags(&s.ev_fork[i], hipEventDisableTiming));
-                HIPCHK(hipEventCreateWithFlags(&s.ev_join[i], hipEventDisableTiming));
-            }
-        }
         HIPCHK(hipEventCreate(&s.ev0));
         HIPCHK(hipEventCreate(&s.ev1));
         HIPCHK(hipEventCreate(&s.ev2));
@@ -599,13 +583,6 @@ class CurveBackend : public Backend {
     void release(Slot* s) {
         { std::lock_guard<std::mutex> lk(mu_); s->busy = false; }
         cv_.notify_one();
-    }
-    // how many slots are proving right now (the side streams pay only while a proof has the GPU to itself)
-    int busy_slots() {
-        std::lock_guard<std::mutex> lk(mu_);
-        int k = 0;
-        for (Slot* s : slots_) k += s->busy ? 1 : 0;
-        return k;
     }
     struct SlotGuard {
         CurveBackend* b; Slot* s;
@@ -789,7 +766,6 @@ class CurveBackend : public Backend {
         // beyond the cap wait for a slot, which also hides their host-side gaps
         static const int max_slots = env_int("APK_MAX_SLOTS", 16, 1, 64);
         if (nslots > max_slots) nslots = max_slots;
-        want_slots_ = nslots;
         for (int i = 0; i < nslots; i++) {
             Slot* s = new Slot();
             slots_.push_back(s);
@@ -1181,17 +1157,6 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         for (int j = 0; j < 3; j++) { b3.p[j] = canon[j]; b3.b[j].v[0] = bl[2 * j]; b3.b[j].v[1] = bl[2 * j + 1]; }
         blind3_kernel<FRP><<<3, 64, 0, st>>>(b3, n, 2); KCHK();
     }
-    // latency contexts: the three coset NTTs run on the slot's side stream BESIDE the commitment (the MSM's sort and reduction
-    // phases leave most SIMDs idle when there is a single proof in flight); joined before the next user of the NTT scratch
-    const bool use_side = s.side && qk_direct_ && !wire_hook_ && !hook_ && !stats_on_ && nb_commit_ == 0 && busy_slots() == 1;
-    if (use_side) {
-        Fr* ev[3] = {ptr<Fr>(s.el), ptr<Fr>(s.er), ptr<Fr>(s.eo)};
-        const uint32_t lens[3] = {n + 2, n + 2, n + 2};
-        HIPCHK(hipEventRecord(s.ev_fork[0], st));
-        HIPCHK(hipStreamWaitEvent(s.side, s.ev_fork[0], 0));
-        CHK(run_ntt_batch(s.side, 1, false, 3, canon, ev, lens, n4_, ptr<Fr>(coset_pre_), nullptr, nullptr));
-        HIPCHK(hipEventRecord(s.ev_join[0], s.side));
-    }
     {
         MsmBatchArgs a{};
         a.batch = 3;
@@ -1210,9 +1175,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     {
         Fr* ev[3] = {ptr<Fr>(s.el), ptr<Fr>(s.er), ptr<Fr>(s.eo)};
         const uint32_t lens[3] = {n + 2, n + 2, n + 2};
-        if (use_side) {
-            // (forked right after the blinding, see above: nothing to launch here)
-        } else if (wire_hook_) {
+        if (wire_hook_) {
             // per-wire transforms dealt to other GPUs (csrc/comm.cpp): the hook returns with the three
             // evaluation vectors complete in this context's memory
             HIPCHK(hipStreamSynchronize(st));
@@ -1278,7 +1241,6 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         const Fr den_total_inv = Fr::inv(hfr[0]);
         gp_finish_kernel<FRP><<<cdiv(n, POLY_THREADS), POLY_THREADS, 0, st>>>(g, n, den_total_inv, ptr<Fr>(s.zlag)); KCHK();
     }
-    if (use_side) HIPCHK(hipStreamWaitEvent(st, s.ev_join[0], 0));    // the NTT scratch is shared with the side stream
     CHK(inv_ntt_n(st, ptr<Fr>(s.zlag), ptr<Fr>(s.cz)));
     {
         Fr4<FRP> b{};
@@ -1288,15 +1250,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         a.batch = 1; a.scalars[0] = s.cz.p; a.len[0] = n + 3; a.offset[0] = 0;
         CHK(commit(s, tab_can_, 0, a, hp));
     }
-    if (use_side) {
-        // (queued on the side stream before the commitment above would be better still; the blinded Z is complete only here)
-        HIPCHK(hipEventRecord(s.ev_fork[1], st));
-        HIPCHK(hipStreamWaitEvent(s.side, s.ev_fork[1], 0));
-        CHK(coset_ntt_4n(s.side, ptr<Fr>(s.cz), n + 3, ptr<Fr>(s.ez)));
-        HIPCHK(hipEventRecord(s.ev_join[1], s.side));
-    } else {
-        CHK(coset_ntt_4n(st, ptr<Fr>(s.cz), n + 3, ptr<Fr>(s.ez)));
-    }
+    CHK(coset_ntt_4n(st, ptr<Fr>(s.cz), n + 3, ptr<Fr>(s.ez)));
     CHK(sync_results(s));
     const Aff zcom = hp[0];
     store_pt(out->z, zcom);
@@ -1336,7 +1290,6 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         for (int k = 0; k < 4; k++) q.zh_inv[k] = zh_inv_[k] * c5;
         for (int j = 0; j < q.nb_inject; j++) q.inj_delta[j] = q.inj_delta[j] * c5;
         q.n4 = n4_;
-        if (use_side) HIPCHK(hipStreamWaitEvent(st, s.ev_join[1], 0));
         quotient_kernel<FRP><<<cdiv(n4_, POLY_THREADS), POLY_THREADS, 0, st>>>(q, ptr<Fr>(s.quot)); KCHK();
         CHK(run_ntt(st, 1, true, ptr<Fr>(s.quot), ptr<Fr>(s.hcan), n4_, n4_, nullptr, ptr<Fr>(coset_post_inv_), nullptr));
         // h = h1 + X^(n+2) h2 + X^(2(n+2)) h3   (templateLogicSigBN254.go:79,220-226)
