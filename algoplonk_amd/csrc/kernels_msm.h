@@ -66,6 +66,7 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_digits_kernel(MsmBatch
                                                          uint32_t* __restrict__ counts,         // [batch][G][nb]
                                                          const uint32_t* __restrict__ offsets,  // SCATTER only
                                                          uint32_t* __restrict__ sorted) {
+    wave_priority<APK_PRIO_SORT>();
     using Fr = Fe<FR>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t* lds = reinterpret_cast<uint32_t*>(smem_raw);
@@ -131,6 +132,7 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_digits_kernel(MsmBatch
 template <int DUMMY>
 __global__ void __launch_bounds__(256) msm_colscan_kernel(uint32_t* __restrict__ counts, uint32_t nb, uint32_t G, uint32_t total_buckets,
                                                           uint32_t* __restrict__ hist) {
+    wave_priority<APK_PRIO_SORT>();
     const uint32_t kk = blockIdx.x * blockDim.x + threadIdx.x;  // b*nb + k
     if (kk >= total_buckets) return;
     const uint32_t b = kk / nb, k = kk % nb;
@@ -171,6 +173,7 @@ __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_local_kernel(const ui
                                                                          uint32_t* __restrict__ full_off, uint32_t* __restrict__ rem_rank,
                                                                          uint32_t* __restrict__ block_tot /* [3][nblocks] */,
                                                                          uint32_t* __restrict__ block_bins /* [nblocks][MSM_UNIT_MAX] */, uint32_t nblocks) {
+    wave_priority<APK_PRIO_SORT>();
     __shared__ uint32_t s_cnt[MSM_SCAN_BLOCK];
     __shared__ uint32_t s_unit[MSM_SCAN_BLOCK];
     __shared__ uint32_t s_full[MSM_SCAN_BLOCK];
@@ -202,6 +205,7 @@ template <int DUMMY>
 __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_totals_kernel(uint32_t* __restrict__ block_tot, uint32_t* __restrict__ block_bins,
                                                                           uint32_t nblocks, uint32_t total, uint32_t* __restrict__ offsets,
                                                                           uint32_t* __restrict__ unit_off, uint32_t* __restrict__ full_off) {
+    wave_priority<APK_PRIO_SORT>();
     __shared__ uint32_t s_cnt[MSM_SCAN_BLOCK];
     __shared__ uint32_t s_unit[MSM_SCAN_BLOCK];
     __shared__ uint32_t s_full[MSM_SCAN_BLOCK];
@@ -245,6 +249,7 @@ __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_apply_kernel(const ui
                                                                          uint32_t nblocks, uint32_t total, uint32_t unit,
                                                                          uint32_t* __restrict__ offsets, uint32_t* __restrict__ unit_off,
                                                                          uint32_t* __restrict__ full_off, uint32_t* __restrict__ rem_list) {
+    wave_priority<APK_PRIO_SORT>();
     const uint32_t i = blockIdx.x * MSM_SCAN_BLOCK + threadIdx.x;
     if (i >= total) return;
     offsets[i] += block_tot[blockIdx.x];
@@ -334,6 +339,7 @@ __global__ void __launch_bounds__(256) msm_combine_kernel(const XYZZ<FP, FeU<FP>
                                                           int lanes_log,  // lanes per bucket = 2^lanes_log <= MSM_COMBINE_LANES
                                                           uint32_t normal_blocks,
                                                           XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum) {
+    wave_priority<APK_PRIO_TAIL>();
     using PT = XYZZ<FP, FeU<FP>>;
     if (blockIdx.x >= normal_blocks) {   // block-uniform
         msm_combine_heavy_body<FP>(partial, unit_off, total_buckets, bucket_sum, blockIdx.x - normal_blocks, gridDim.x - normal_blocks);
@@ -404,6 +410,7 @@ __device__ __forceinline__ void msm_combine_heavy_body(const XYZZ<FP, FeU<FP>>* 
 template <class FP>
 __global__ void __launch_bounds__(256) msm_rowcol_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum, uint32_t nb, uint32_t rows,
                                                          uint32_t cols, XYZZ<FP, FeU<FP>>* __restrict__ rc) {
+    wave_priority<APK_PRIO_TAIL>();
     using PT = XYZZ<FP, FeU<FP>>;
     __shared__ PT sm[256];
     const uint32_t m = blockIdx.y, x = blockIdx.x, t = threadIdx.x;
@@ -429,6 +436,7 @@ __global__ void __launch_bounds__(256) msm_rowcol_kernel(const XYZZ<FP, FeU<FP>>
 template <class FP>
 __global__ void __launch_bounds__(256) msm_bitsum_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ rc, uint32_t rows, uint32_t cols,
                                                          XYZZ<FP, FeU<FP>>* __restrict__ bit_partial) {
+    wave_priority<APK_PRIO_TAIL>();
     using PT = XYZZ<FP, FeU<FP>>;
     __shared__ PT sm[256];
     const uint32_t bit = blockIdx.x, which = blockIdx.y, m = blockIdx.z, t = threadIdx.x;
@@ -453,6 +461,7 @@ __global__ void __launch_bounds__(256) msm_bitsum_kernel(const XYZZ<FP, FeU<FP>>
 template <class FP>
 __global__ void __launch_bounds__(64) msm_final_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ bit_partial, uint32_t nbits, int cols_log,
                                                        Affine<FP>* __restrict__ result, XYZZ<FP>* __restrict__ result_xyzz) {
+    wave_priority<APK_PRIO_TAIL>();
     using PT = XYZZ<FP, FeU<FP>>;
     __shared__ PT sm[64];
     const uint32_t m = blockIdx.x, t = threadIdx.x;
@@ -499,6 +508,7 @@ __device__ __forceinline__ void quad_tree_add(PT& acc, const PT& o, int q) {
 template <class FP>
 __global__ void __launch_bounds__(256) msm_rowcol_hybrid_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum, uint32_t nb, uint32_t rows,
                                                                 uint32_t cols, XYZZ<FP, FeU<FP>>* __restrict__ rc) {
+    wave_priority<APK_PRIO_TAIL>();
     using PT = XYZZ<FP, FeU<FP>>;
     __shared__ PT sm[256];
     const uint32_t m = blockIdx.y, x = blockIdx.x, t = threadIdx.x;
@@ -537,6 +547,7 @@ template <class FP> struct MsmQuad { static constexpr uint32_t THREADS = FP::N >
 template <class FP>
 __global__ void __launch_bounds__(MsmQuad<FP>::THREADS) msm_rowcol_quad_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum, uint32_t nb, uint32_t rows,
                                                               uint32_t cols, XYZZ<FP, FeU<FP>>* __restrict__ rc) {
+    wave_priority<APK_PRIO_TAIL>();
     using PT = XYZZ<FP, FeU<FP>>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     PT* sm = reinterpret_cast<PT*>(smem_raw);
@@ -591,6 +602,7 @@ __device__ __forceinline__ void msm_final_quad_body(const XYZZ<FP, FeU<FP>>* __r
 template <class FP>
 __global__ void __launch_bounds__(256) msm_final_quad_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ bit_partial, uint32_t nbits, int cols_log,
                                                              Affine<FP>* __restrict__ result, XYZZ<FP>* __restrict__ result_xyzz) {
+    wave_priority<APK_PRIO_TAIL>();
     using PT = XYZZ<FP, FeU<FP>>;
     __shared__ PT sm[64];
     const uint32_t m = blockIdx.x, t = threadIdx.x >> 2;
@@ -629,6 +641,7 @@ __global__ void __launch_bounds__(MsmQuad<FP>::THREADS) msm_bitsum_final_quad_ke
                                                                     uint32_t lt, XYZZ<FP, FeU<FP>>* __restrict__ bit_partial,
                                                                     uint32_t* __restrict__ done_count, int cols_log,
                                                                     XYZZ<FP>* __restrict__ result_xyzz) {
+    wave_priority<APK_PRIO_TAIL>();
     using PT = XYZZ<FP, FeU<FP>>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     PT* sm = reinterpret_cast<PT*>(smem_raw);
@@ -666,6 +679,7 @@ __global__ void __launch_bounds__(MsmQuad<FP>::THREADS) msm_bitsum_final_quad_ke
 template <class FP>
 __global__ void __launch_bounds__(MsmQuad<FP>::THREADS) msm_bitsum_quad_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ rc, uint32_t rows, uint32_t cols,
                                                               XYZZ<FP, FeU<FP>>* __restrict__ bit_partial) {
+    wave_priority<APK_PRIO_TAIL>();
     using PT = XYZZ<FP, FeU<FP>>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     PT* sm = reinterpret_cast<PT*>(smem_raw);

@@ -58,6 +58,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, cons
                                                                const Fe<FR>* __restrict__ post,  // or null
                                                                const Fe<FR>* __restrict__ scale, // or null: one element
                                                                NttPassArgs a) {
+    wave_priority<APK_PRIO_FR>();
     using Fr = Fe<FR>;
     using Fu = FeU<FR>;
     static_assert(Fu::HEADROOM >= 64, "values reach (2 + 2 log2 N) p < 64 p over the stages of a transform (N <= 2^30)");

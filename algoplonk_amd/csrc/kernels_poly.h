@@ -55,6 +55,7 @@ __global__ void blind3_kernel(Blind3<FR> a, uint32_t n, int d) {
 // out[i] = a[i] * b[i]  (b indexed with offset/stride so tables can be reused)
 template <class FR>
 __global__ void mul_kernel(Fe<FR>* out, const Fe<FR>* a, const Fe<FR>* b, uint32_t count) {
+    wave_priority<APK_PRIO_FR>();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) out[i] = a[i] * b[i];
 }
@@ -72,6 +73,7 @@ __global__ void __launch_bounds__(POLY_THREADS) gp_terms_kernel(const Fe<FR>* __
                                                                 const Fe<FR>* __restrict__ tw, uint32_t n, Fe<FR> beta,
                                                                 Fe<FR> gamma, Fe<FR> beta_u, Fe<FR> beta_u2,
                                                                 Fe<FR>* __restrict__ num, Fe<FR>* __restrict__ den) {
+    wave_priority<APK_PRIO_FR>();
     using Fr = Fe<FR>;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -128,6 +130,7 @@ __device__ __forceinline__ void scan_block_body(Fe<FR>* __restrict__ data, uint3
 template <class FR, class OP>
 __global__ void __launch_bounds__(POLY_THREADS) scan_block_kernel(Fe<FR>* __restrict__ data, uint32_t count, bool rev,
                                                                   Fe<FR>* __restrict__ block_tot) {
+    wave_priority<APK_PRIO_FR>();
     scan_block_body<FR, OP>(data, count, rev, block_tot);
 }
 
@@ -163,6 +166,7 @@ __device__ __forceinline__ Fe<FR> scan_totals_body(Fe<FR>* __restrict__ tot, uin
 }
 template <class FR, class OP>
 __global__ void __launch_bounds__(POLY_THREADS) scan_totals_kernel(Fe<FR>* __restrict__ tot, uint32_t nblocks) {
+    wave_priority<APK_PRIO_FR>();
     scan_totals_body<FR, OP>(tot, nblocks);
 }
 
@@ -174,10 +178,12 @@ struct GpScan {
 };
 template <class FR>
 __global__ void __launch_bounds__(POLY_THREADS) gp_scan_block_kernel(GpScan<FR> g, uint32_t count) {
+    wave_priority<APK_PRIO_FR>();
     scan_block_body<FR, OpMul>(g.data[blockIdx.y], count, blockIdx.y != 0, g.tot[blockIdx.y]);
 }
 template <class FR>
 __global__ void __launch_bounds__(POLY_THREADS) gp_scan_totals_kernel(GpScan<FR> g, uint32_t nblocks) {
+    wave_priority<APK_PRIO_FR>();
     Fe<FR> total = scan_totals_body<FR, OpMul>(g.tot[blockIdx.x], nblocks);
     // the product of all denominators: inverted on the HOST (a lone GPU lane needs ~100 us for one Kaliski inversion)
     if (blockIdx.x == 1 && threadIdx.x == POLY_THREADS - 1) g.tot[1][nblocks] = total;
@@ -185,6 +191,7 @@ __global__ void __launch_bounds__(POLY_THREADS) gp_scan_totals_kernel(GpScan<FR>
 // Z[0] = 1; Z[k] = num_prefix_incl[k-1] * den_suffix_incl[k] / den_total
 template <class FR>
 __global__ void __launch_bounds__(POLY_THREADS) gp_finish_kernel(GpScan<FR> g, uint32_t n, Fe<FR> den_total_inv, Fe<FR>* __restrict__ z) {
+    wave_priority<APK_PRIO_FR>();
     using Fr = Fe<FR>;
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -200,6 +207,7 @@ template <class FR, class OP>
 __global__ void __launch_bounds__(POLY_THREADS) scan_apply_kernel(const Fe<FR>* __restrict__ data, uint32_t count, bool rev,
                                                                   const Fe<FR>* __restrict__ block_excl,
                                                                   Fe<FR>* __restrict__ out, int shift) {
+    wave_priority<APK_PRIO_FR>();
     using Fr = Fe<FR>;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -242,6 +250,7 @@ struct QuotientArgs {
 // Bounds (R'/r >= 71): sums of a few products stay below 16 r, every product of such a sum with a canonical factor below 2 r.
 template <class FR>
 __global__ void __launch_bounds__(POLY_THREADS) quotient_kernel(QuotientArgs<FR> a, Fe<FR>* __restrict__ out) {
+    wave_priority<APK_PRIO_FR>();
     using Fr = Fe<FR>;
     using U = FeU<FR>;
     static_assert(U::HEADROOM >= 64, "lazy sums of up to 16 r times a canonical factor must stay below 2 r");
@@ -300,6 +309,7 @@ constexpr int EVAL_BLOCK = POLY_THREADS * EVAL_PER_THREAD;
 template <class FR>
 __global__ void __launch_bounds__(POLY_THREADS) eval_partial_kernel(EvalArgs<FR> a, const Fe<FR>* __restrict__ pw,
                                                                     uint32_t nblocks, Fe<FR>* __restrict__ partial) {
+    wave_priority<APK_PRIO_FR>();
     using Fr = Fe<FR>;
     __shared__ Fr sm[POLY_THREADS];
     const int p = blockIdx.y;
@@ -324,6 +334,7 @@ __global__ void __launch_bounds__(POLY_THREADS) eval_partial_kernel(EvalArgs<FR>
 template <class FR>
 __global__ void __launch_bounds__(POLY_THREADS) eval_final_kernel(const Fe<FR>* __restrict__ partial, uint32_t nblocks,
                                                                   Fe<FR>* __restrict__ result) {
+    wave_priority<APK_PRIO_FR>();
     using Fr = Fe<FR>;
     __shared__ Fr sm[POLY_THREADS];
     const int p = blockIdx.x;
@@ -352,6 +363,7 @@ struct LinCombArgs {
 
 template <class FR>
 __global__ void __launch_bounds__(POLY_THREADS) lincomb_kernel(LinCombArgs<FR> a, Fe<FR>* __restrict__ out) {
+    wave_priority<APK_PRIO_FR>();
     using Fr = Fe<FR>;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.out_len) return;
@@ -366,6 +378,7 @@ template <class FR>
 __global__ void __launch_bounds__(POLY_THREADS) div_finish_kernel(const Fe<FR>* __restrict__ suffix,
                                                                   const Fe<FR>* __restrict__ zinv_pw, uint32_t len,
                                                                   Fe<FR>* __restrict__ q) {
+    wave_priority<APK_PRIO_FR>();
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j + 1 >= len) return;
     q[j] = suffix[j + 1] * zinv_pw[j + 1];

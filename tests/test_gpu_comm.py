@@ -17,6 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _worker(rank, world, port, q, cname, split_wires, ipc):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import faulthandler
+    faulthandler.dump_traceback_later(200, exit=False, file=sys.stderr)     # a silent rank shows where it sits before the parent gives up
+    stage = lambda s: q.put((rank, "@" + s))                                # progress markers: a timeout names the step it happened in
     try:
         os.environ["APK_COMM_IPC"] = "1" if ipc else "0"
         os.environ["APK_COMM_TIMEOUT_S"] = "30"          # a rank that dies must not keep its peers (and the GPU box) waiting
@@ -27,13 +30,17 @@ def _worker(rank, world, port, q, cname, split_wires, ipc):
         from oracle import plonk as oplonk
         from oracle.prng import SplitMix64, tau_from_seed
         cv, ov = CURVES[cname]
+        stage("imported")
         comm = parallel.Comm(rank, world, "127.0.0.1", port)
+        stage("rendezvous")
         # ---- ONE proof, its commitments (and wires) dealt to the ranks: every rank holds the circuit context
         ccs, w, sol = random_chain_ccs(cv, 10, 0xA190 + 10)
         tau = tau_from_seed(99, cv.r)
         srs = ap_setup.unsafe_srs(cv, ccs.domain_size(), tau, device=0)
         pk, vk = ap_plonk.Setup(ccs, srs, device=0)
+        stage("setup")
         comm.bind(pk.ctx)
+        stage("bound " + comm.transport)
         # two ranks on one device: RCCL refuses; HIP IPC (the receiver maps the sender's staging buffer and pulls) unless it was
         # switched off or the box refuses to share the allocation - then the host-staged TCP star
         assert comm.transport in (("ipc", "tcp") if ipc else ("tcp",)), comm.transport
@@ -49,6 +56,7 @@ def _worker(rank, world, port, q, cname, split_wires, ipc):
         else:
             served = comm.serve()
             assert served == 2 * (4 + (1 if split_wires else 0)), served      # {L,R,O} {Z} {H1..3} {W, W'} (+ the wires) per proof
+        stage("split proofs")
         comm.barrier()
         # ---- ONE MSM sharded by index range (BASELINE.json configs[3]): MSM-only context over this rank's slice of the bases
         n = ccs.domain_size()
@@ -63,6 +71,7 @@ def _worker(rank, world, port, q, cname, split_wires, ipc):
         comm2.close()
         comm.close()
         pk.close()
+        faulthandler.cancel_dump_traceback_later()
         q.put((rank, "ok " + transport))
     except Exception as e:
         import traceback
@@ -79,7 +88,19 @@ def test_split_proof_and_sharded_msm_between_processes_sharing_the_gpu(gpu, cnam
     port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, cname, split_wires, ipc)) for r in range(world)]
     [p.start() for p in procs]
-    res = [q.get(timeout=240) for _ in procs]
+    import queue
+    import time
+    res, last, deadline = [], {}, time.monotonic() + 600           # a fresh box pages the image in under three processes at once
+    while len(res) < world:
+        try:
+            r = q.get(timeout=max(1.0, deadline - time.monotonic()))
+        except queue.Empty:
+            [p.kill() for p in procs]
+            pytest.fail("ranks silent for 600 s; finished %r, last stage per rank %r" % (res, last))
+        if r[1].startswith("@"):
+            last[r[0]] = r[1][1:]
+        else:
+            res.append(r)
     [p.join(timeout=60) for p in procs]
     assert all(r[1].startswith("ok") for r in res) and sorted(r[0] for r in res) == list(range(world)), res
     assert len({r[1] for r in res}) == 1, res        # every rank agreed on the data plane
