@@ -237,7 +237,7 @@ class CurveBackend : public Backend {
         Slot* owner = nullptr;
         for (Slot* s : slots_) if (s->stream == st) owner = s;
         if (passes > 1) {   // the passes hand each other unsaturated-limb elements through the slot's scratch
-            if (!owner || log_n > 30) { set_error("ntt: no workspace for this stream"); return APK_ERR_STATE; }
+            if (!owner || log_n > 29) { set_error("ntt: no workspace for this stream"); return APK_ERR_STATE; }
             for (int i = 0; i < count; i++) nb.wide[i] = ptr<FeU<FRP>>(owner->ntt_wide) + ((size_t)i << log_n);
         }
         Slot* timed = stats_on_ ? owner : nullptr;
@@ -251,7 +251,18 @@ class CurveBackend : public Backend {
             a.out_len = out_len;
             const dim3 grid(1u << (log_n - tile_log), count);
             const size_t lds = ((size_t)1 << tile_log) * sizeof(FeU<FRP>);
-            ntt_pass_kernel<FRP><<<grid, NTT_THREADS, lds, st>>>(nb, tw, pre, post, scale, a);
+            // radix 4 (two stages per LDS round trip, one four-element group per lane and step) pays above 2^19 only: kernels_ntt.h
+            static const int r4_env = env_int("APK_NTT_RADIX4", -1, -1, 1);
+            a.radix4 = r4_env >= 0 ? r4_env : (log_n > 19 ? 1 : 0);
+            static const int thr_env = env_int("APK_NTT_THREADS", 0, 0, NTT_THREADS) & ~63;
+            uint32_t threads = NTT_THREADS;
+            if (a.radix4) {
+                threads = (1u << tile_log) / 4;
+                if (threads < 64) threads = 64;
+                if (threads > (uint32_t)NTT_THREADS) threads = NTT_THREADS;
+            }
+            if (thr_env) threads = (uint32_t)thr_env;
+            ntt_pass_kernel<FRP><<<grid, threads, lds, st>>>(nb, tw, pre, post, scale, a);
             KCHK();
             t0 += s;
         }
@@ -280,7 +291,18 @@ class CurveBackend : public Backend {
     int build_tables(hipStream_t st, const Aff* d_bases, uint32_t count, MsmTables& T) {
         CHK(T.table.alloc((size_t)count * W_ * sizeof(Aff)));
         T.n_bases = count;
-        msm_table_kernel<FPP><<<cdiv(count, 256), 256, 0, st>>>(d_bases, count, win_, ptr<Aff>(T.table));
+        MsmPreScale pre{};
+#ifndef APK_MSM_NO_RINV
+        {   // R^-1 mod r as a plain integer = from_mont of the integer 1
+            Fr one_int{};
+            one_int.l[0] = 1u;
+            const Fr rinv = Fr::from_mont(one_int);
+            static_assert(Fr::N <= 16, "MsmPreScale holds 16 words");
+            for (int i = 0; i < Fr::N; i++) pre.l[i] = rinv.l[i];
+            pre.nwords = Fr::N;
+        }
+#endif
+        msm_table_kernel<FPP><<<cdiv(count, 256), 256, 0, st>>>(d_bases, count, win_, pre, ptr<Aff>(T.table));
         KCHK();
         T.built = true;
         return APK_OK;

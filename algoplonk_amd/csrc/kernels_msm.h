@@ -80,7 +80,14 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_digits_kernel(MsmBatch
     const uint32_t per = (len + G - 1) / G;
     const uint32_t lo = min(g * per, len), hi = min(lo + per, len);
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        // The scalars arrive in gnark's Montgomery form a * R and are used AS THEY ARE: the windowed tables hold the multiples of
+        // R^-1 * P_i (msm_table_kernel, once per circuit), so sum (a_i R) * (R^-1 P_i) = sum a_i P_i and neither sort pass pays a
+        // Montgomery product per scalar to leave the form (it was ~45 % of the two passes' instructions).
+#ifndef APK_MSM_NO_RINV
+        Fr s = reinterpret_cast<const Fr*>(a.scalars[b])[i];
+#else
         Fr s = Fr::from_mont(reinterpret_cast<const Fr*>(a.scalars[b])[i]);
+#endif
         uint32_t carry = 0;
         const uint32_t base_idx = a.offset[b] + i;
         // The windows are consecutive bit fields (off[j+1] = off[j] + width[j]): stream the limbs through a 64-bit buffer and
@@ -305,11 +312,31 @@ __global__ void __launch_bounds__(128, MsmAcc<FP>::MIN_WAVES) msm_accumulate_ker
     // (madd_lazy: no conditional subtractions; every XYZZ buffer of the MSM holds points of ec.h's lazy class)
     XYZZ<FP, FeU<FP>> acc = XYZZ<FP, FeU<FP>>::inf();
     bool flipped = false, unit_z = false;
+#ifndef APK_ACC_NO_PREFETCH
+    // Software pipeline.  An iteration used to start with two DEPENDENT loads (the entry, then its table record: a random
+    // 64/96-byte gather) and nothing to do until they landed - hidden only by other waves, of which the 14-limb field has two
+    // per SIMD and a lone 2^17 MSM two or three.  Now the record of entry e is in registers while the record of entry e + 1
+    // and the index of entry e + 2 are in flight behind the ~2 000 (4 700) instructions of the addition.  Past the end the
+    // loads repeat the last entry (no branch in the loop; the values are not used).
+    if (beg < end) {
+        const uint32_t last = end - 1;
+        uint32_t v0 = sorted[beg];
+        uint32_t v1 = sorted[beg + 1 <= last ? beg + 1 : last];
+        Affine<FP> rec = table[v0 & 0x7fffffffu];
+        for (uint32_t e = beg; e < end; e++) {
+            const Affine<FP> nxt = table[v1 & 0x7fffffffu];
+            const uint32_t v2 = sorted[e + 2 <= last ? e + 2 : last];
+            acc.madd_lazy(unpack_affine<FP>(rec), (v0 >> 31) != 0, flipped, unit_z);
+            rec = nxt; v0 = v1; v1 = v2;
+        }
+    }
+#else
     for (uint32_t e = beg; e < end; e++) {
         uint32_t v = sorted[e];
         Affine<FP> rec = table[v & 0x7fffffffu];
         acc.madd_lazy(unpack_affine<FP>(rec), (v >> 31) != 0, flipped, unit_z);
     }
+#endif
     acc.lazy_fix_sign(flipped);
     partial[slot] = acc;
 }
@@ -702,12 +729,26 @@ __global__ void __launch_bounds__(MsmQuad<FP>::THREADS) msm_bitsum_quad_kernel(c
 }
 
 // ---- table construction: table[j*n + i] = 2^(off[j]) * P_i (affine), stored as packed R'-domain records (ffu.h) ----------------------------------------
+// `pre` (canonical words, most significant last; nwords = 0: none): every base is multiplied by it first.  The backends pass
+// R^-1 mod r, which lets msm_digits_kernel read Montgomery-form scalars without converting them.
+struct MsmPreScale { uint32_t l[16]; int nwords; };
 template <class FP>
-__global__ void __launch_bounds__(256) msm_table_kernel(const Affine<FP>* __restrict__ bases, uint32_t n, MsmWindows win,
+__global__ void __launch_bounds__(256) msm_table_kernel(const Affine<FP>* __restrict__ bases, uint32_t n, MsmWindows win, MsmPreScale pre,
                                                         Affine<FP>* __restrict__ table) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Affine<FP> p = bases[i];
+    if (pre.nwords > 0 && !p.is_inf()) {
+        XYZZ<FP> acc = XYZZ<FP>::inf();
+        for (int w = pre.nwords - 1; w >= 0; w--) {
+            const uint32_t word = pre.l[w];   // uniform
+            for (int b = 31; b >= 0; b--) {
+                acc = XYZZ<FP>::dbl(acc);
+                if ((word >> b) & 1u) acc.madd(p);
+            }
+        }
+        p = acc.to_affine();
+    }
     table[i] = to_table_record<FP>(p);
     for (int j = 1; j < win.W; j++) {
         XYZZ<FP> q = XYZZ<FP>::dbl_affine(p);

@@ -39,6 +39,7 @@ struct NttPassArgs {
     int t0, t1;          // stages [t0, t1)
     int first, last;     // first pass gathers bit-reversed + pre-multiplies; last pass post-multiplies
     uint32_t out_len;    // last pass: elements >= out_len are not written
+    int radix4;          // two stages per LDS round trip (large transforms; see the kernel)
 };
 
 // Inside the tile the elements are UNSATURATED-limb values (ffu.h, 9 x 29 bits for both scalar fields) handled lazily:
@@ -61,7 +62,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, cons
     wave_priority<APK_PRIO_FR>();
     using Fr = Fe<FR>;
     using Fu = FeU<FR>;
-    static_assert(Fu::HEADROOM >= 64, "values reach (2 + 2 log2 N) p < 64 p over the stages of a transform (N <= 2^30)");
+    static_assert(Fu::HEADROOM >= 64, "values reach (4 + 2 log2 N) p < 64 p over the stages of a transform (N <= 2^29)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Fu* sm = reinterpret_cast<Fu*>(smem_raw);
     Fr* __restrict__ out = reinterpret_cast<Fr*>(nb.out[blockIdx.y]);
@@ -76,8 +77,9 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, cons
     const uint32_t g0 = blockIdx.x << clog;  // first group id of this tile
     const uint32_t lomask = (1u << a.t0) - 1u;
 
+    const uint32_t NT = blockDim.x;
     // load: element e of the tile = (mid, c) with c fastest
-    for (uint32_t e = threadIdx.x; e < tile_elems; e += NTT_THREADS) {
+    for (uint32_t e = threadIdx.x; e < tile_elems; e += NT) {
         uint32_t c = e & (C - 1), mid = e >> clog;
         uint32_t g = g0 + c;
         uint32_t idx = ((g >> a.t0) << a.t1) | (mid << a.t0) | (g & lomask);
@@ -97,11 +99,67 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, cons
         sm[e] = v;
     }
     __syncthreads();
-    // s butterfly stages; butterfly id -> (pair index within group, c)
-    const uint32_t nbf = tile_elems >> 1;
-    for (int q = 0; q < s; q++) {
+    int q = 0;
+    // Two stages per LDS round trip (radix 4): a lane holds the four elements {mid | b0 2^q | b1 2^(q+1)} of its group in
+    // registers, runs stage t on (x0,x1), (x2,x3) and stage t+1 on (y0,y2), (y1,y3).  In a prime field this saves no PRODUCT
+    // (the factor i = w^(N/4) is an ordinary element: 4 products per 4 butterflies either way) - it saves what surrounds the
+    // products: one of four twiddle loads + unpacks (stage t's two pairs share theirs; stage t+1's are tw[k] and tw[k + N/4]),
+    // half the LDS traffic and three quarters of the index arithmetic.  Measured (round 3, one box): BLS12-381 2^21 8.5 -> 7.7 ms
+    // of NTT per proof; at 2^17 the saturated rate does not move and a lone proof's transforms get SLOWER (0.45 -> 0.52 ms:
+    // half the lanes per tile, and these launches are latency-bound) - so the host asks for it above 2^19 only.
+    // padded: the zero-padded 4n transforms feed their first radix-4 step groups with one non-zero element (wave-uniform).
+    const bool padded = a.first && in_len < (1u << a.log_n);
+    const uint32_t nq = tile_elems >> 2;
+    for (; a.radix4 && q + 2 <= s; q += 2) {
         const int t = a.t0 + q;
-        for (uint32_t bf = threadIdx.x; bf < nbf; bf += NTT_THREADS) {
+        for (uint32_t u4 = threadIdx.x; u4 < nq; u4 += NT) {
+            const uint32_t c = u4 & (C - 1), pr = u4 >> clog;
+            const uint32_t low = pr & ((1u << q) - 1u);
+            const uint32_t m00 = ((pr >> q) << (q + 2)) | low;
+            const uint32_t g = g0 + c;
+            const uint32_t imod = (low << a.t0) | (g & lomask);   // index mod 2^t
+            const uint32_t e00 = (m00 << clog) | c, st1 = 1u << (q + clog);
+            const uint32_t e01 = e00 + st1, e10 = e00 + 2 * st1, e11 = e01 + 2 * st1;
+            Fu x0 = sm[e00], x1 = sm[e01], x2 = sm[e10], x3 = sm[e11];
+            if (padded && q == 0 && x1.is_zero() && x2.is_zero() && x3.is_zero()) {
+                sm[e01] = x0; sm[e10] = x0; sm[e11] = x0;    // all four outputs are x0
+                continue;
+            }
+            if (t != 0) {   // stage t: exponent imod * N / 2^(t+1); stage 0 has unit twiddles and fresh operands (below 2p)
+                Fr w = tw[imod << (a.log_n - 1 - t)];
+                const Fu w1 = Fu::unpack(w.l);
+                x1 = Fu::mul_nr(w1, x1);
+                x3 = Fu::mul_nr(w1, x3);
+            }
+            const Fu y0 = Fu::add_n(x0, x1);
+            const Fu y1 = Fu::template sub_k<2>(x0, x1);
+            Fu y2 = Fu::add_n(x2, x3);
+            Fu y3 = Fu::template sub_k<2>(x2, x3);
+            // stage t+1: exponents imod * N / 2^(t+2) and that + N/4
+            const uint32_t k2 = imod << (a.log_n - 2 - t);
+            {
+                Fr w = tw[k2 + (1u << (a.log_n - 2))];
+                y3 = Fu::mul_nr(Fu::unpack(w.l), y3);
+            }
+            if (t != 0) {
+                Fr w = tw[k2];
+                y2 = Fu::mul_nr(Fu::unpack(w.l), y2);
+                sm[e00] = Fu::add_n(y0, y2);
+                sm[e10] = Fu::template sub_k<2>(y0, y2);
+            } else {   // w2 = 1: y2 = x2 + x3 is below 4p, not a fresh product
+                sm[e00] = Fu::add_n(y0, y2);
+                sm[e10] = Fu::template sub_k<4>(y0, y2);
+            }
+            sm[e01] = Fu::add_n(y1, y3);
+            sm[e11] = Fu::template sub_k<2>(y1, y3);
+        }
+        __syncthreads();
+    }
+    // remaining stage(s), one butterfly at a time; butterfly id -> (pair index within group, c)
+    const uint32_t nbf = tile_elems >> 1;
+    for (; q < s; q++) {
+        const int t = a.t0 + q;
+        for (uint32_t bf = threadIdx.x; bf < nbf; bf += NT) {
             uint32_t c = bf & (C - 1), pr = bf >> clog;
             uint32_t low = pr & ((1u << q) - 1u);
             uint32_t mid0 = ((pr >> q) << (q + 1)) | low;
@@ -121,7 +179,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, cons
         }
         __syncthreads();
     }
-    for (uint32_t e = threadIdx.x; e < tile_elems; e += NTT_THREADS) {
+    for (uint32_t e = threadIdx.x; e < tile_elems; e += NT) {
         uint32_t c = e & (C - 1), mid = e >> clog;
         uint32_t g = g0 + c;
         uint32_t idx = ((g >> a.t0) << a.t1) | (mid << a.t0) | (g & lomask);

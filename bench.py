@@ -69,6 +69,8 @@ def parse_args(argv=None):
     ap.add_argument("--witness", default="uniform", choices=["uniform", "bits"],
                     help="wire values of the synthetic circuit: uniform Fr (BASELINE.md section 2) or the bit-heavy circuit of "
                          "workloads.skewed_circuit; the default run reports the bit-heavy rate beside the headline (`witness_bits`)")
+    ap.add_argument("--step-barrier", action="store_true",
+                    help="join all callers after every step (rounds 1-2); default: persistent callers, barriers only around the K steps")
     ap.add_argument("--mode", default="prove", choices=["prove", "msm-sharded", "prove-split", "launcher-selftest"])
     return ap.parse_args(argv)
 
@@ -136,6 +138,44 @@ class Ranks:
         t1 = time.perf_counter()
         for _ in range(steps):
             step()
+        self.fence()
+        return self.comm.max(time.perf_counter() - t1)
+
+    def timed_callers(self, one, callers: int, steps: int, warmup: int, step_barrier: bool = False) -> float:
+        """The same contract with `callers` PERSISTENT host threads (a proving service's request handlers): a step is one call of
+        `one(i)` by every caller i, the timed region holds exactly steps x callers calls between the two barriers.  Nothing waits
+        BETWEEN steps - a caller that is done with its proof of step k starts its proof of step k + 1 - so the proving slots do
+        not drain and refill 60 times inside the timed region (`step_barrier` joins every step like round 1-2 did)."""
+        if callers == 1 or step_barrier:
+            def step():
+                if callers == 1:
+                    one(0)
+                    return
+                ts = [threading.Thread(target=one, args=(i,)) for i in range(callers)]
+                for t in ts:
+                    t.start()
+                for t in ts:
+                    t.join()
+            return self.timed(step, steps, warmup)
+        gate = threading.Barrier(callers + 1)
+
+        def run(i):
+            for _ in range(warmup):
+                one(i)
+            gate.wait()          # every caller's warm-up is done
+            gate.wait()          # released together once the ranks have met
+            for _ in range(steps):
+                one(i)
+
+        ts = [threading.Thread(target=run, args=(i,)) for i in range(callers)]
+        for t in ts:
+            t.start()
+        gate.wait()
+        self.fence()
+        t1 = time.perf_counter()
+        gate.wait()
+        for t in ts:
+            t.join()
         self.fence()
         return self.comm.max(time.perf_counter() - t1)
 
@@ -408,17 +448,7 @@ def bench_prove(args, cv, rk) -> None:
         if rc != 0:
             errors.append((rc, lib.apk_last_error()))
 
-    def step():
-        if args.inflight == 1:
-            one(0)
-            return
-        ts = [threading.Thread(target=one, args=(i,)) for i in range(args.inflight)]
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
-
-    elapsed = rk.timed(step, args.steps, args.warmup)
+    elapsed = rk.timed_callers(one, args.inflight, args.steps, args.warmup, args.step_barrier)
     if errors:
         raise SystemExit("apk_prove failed: %r" % (errors[0],))
     total_proofs = args.steps * args.inflight * rk.world
@@ -494,6 +524,8 @@ def bench_prove(args, cv, rk) -> None:
             "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (Montgomery Fr/Fp)" if cv.name == "bn254" else "u32x8 Fr / u32x12 Fp (Montgomery)",
             "data": "synthetic",
             "config": {"workload": name, "log_n": args.log_n, "curve": cv.name, "proofs_per_step": args.inflight,
+                       "stepping": "joined after every step" if (args.step_barrier or args.inflight == 1) else
+                                   "%d persistent callers x K proofs each; barriers only around the K steps" % args.inflight,
                        "srs": "synthetic tau=SHA256(seed)", "parallelism": "replicas x%d" % rk.world, "world_size": rk.world,
                        "backend": "libapk comm (barrier + MAX over TCP only: independent proofs exchange no data)" if rk.world > 1 else "single process"},
             "proof_latency_ms": round(lat_ms, 3), "msm_mscalar_per_s": round(msm_mscalar, 3),
@@ -536,15 +568,8 @@ def skewed_leg(args, cv, rk, seed):
         if rc != 0:
             errors.append((rc, lib.apk_last_error()))
 
-    def step():
-        ts = [threading.Thread(target=one, args=(i,)) for i in range(args.inflight)]
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
-
     steps = max(6, args.steps // 3)
-    elapsed = rk.timed(step, steps, args.warmup)
+    elapsed = rk.timed_callers(one, args.inflight, steps, args.warmup, args.step_barrier)
     ok = not errors
     if ok:
         try:
