@@ -151,6 +151,11 @@ class CurveBackend : public Backend {
         MsmBatchArgs hook_args{};
         DevBuf tail_flag;          // epoch of the last proof whose quotient had a non-zero tail (tail_nonzero_kernel)
         uint32_t epoch = 0;
+        // tail filling (a lone proof only, see tail_fill()): the coset transforms that follow a commitment run on `side` from the
+        // moment the batch's accumulate kernel is done, beside the reduction tail that would otherwise have the GPU to itself
+        hipStream_t side = nullptr;
+        hipEvent_t ev_acc = nullptr, ev_side = nullptr;
+        int mark_acc = 0; bool side_pending = false;   // mark_acc: 1 = event behind the accumulate kernel, 2 = in front of the batch
     };
 
     int curve_ = CURVE_ID;
@@ -206,6 +211,9 @@ class CurveBackend : public Backend {
             if (s->ev2) (void)hipEventDestroy(s->ev2);
             if (s->ev3) (void)hipEventDestroy(s->ev3);
             if (s->h_pinned) (void)hipHostFree(s->h_pinned);
+            if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }
+            if (s->ev_acc) (void)hipEventDestroy(s->ev_acc);
+            if (s->ev_side) (void)hipEventDestroy(s->ev_side);
             if (s->stream) (void)hipStreamDestroy(s->stream);
             delete s;
         }
@@ -235,7 +243,7 @@ class CurveBackend : public Backend {
         for (int i = 0; i < count; i++) { nb.in[i] = ins[i]; nb.out[i] = outs[i]; nb.in_len[i] = in_lens[i]; }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         Slot* owner = nullptr;
-        for (Slot* s : slots_) if (s->stream == st) owner = s;
+        for (Slot* s : slots_) if (s->stream == st || (s->side && s->side == st)) owner = s;
         if (passes > 1) {   // the passes hand each other unsaturated-limb elements through the slot's scratch
             if (!owner || log_n > 29) { set_error("ntt: no workspace for this stream"); return APK_ERR_STATE; }
             for (int i = 0; i < count; i++) nb.wide[i] = ptr<FeU<FRP>>(owner->ntt_wide) + ((size_t)i << log_n);
@@ -385,6 +393,7 @@ class CurveBackend : public Backend {
         if (unit > (uint32_t)MSM_UNIT_MAX) unit = MSM_UNIT_MAX;
         const uint32_t max_units = (uint32_t)(entries / unit) + total_buckets;
         if (stats_on_) HIPCHK(hipEventRecord(s.ev0, st));
+        if (s.mark_acc == 2) HIPCHK(hipEventRecord(s.ev_acc, st));
         // counting sort by bucket: LDS-private histograms per scalar slice, column scan, bucket scan, scatter
         static const uint32_t slice = (uint32_t)env_int("APK_MSM_SLICE", 2048, 64, 1 << 20);  // scalars per sort workgroup
         // packed 16-bit counters: a slice must stay below 2^16 entries per bucket even when every digit of every scalar agrees
@@ -424,6 +433,7 @@ class CurveBackend : public Backend {
                                                                         total_buckets, max_units, unit, ptr<PtU>(s.partial));
         KCHK();
         if (stats_on_) HIPCHK(hipEventRecord(s.ev3, st));
+        if (s.mark_acc == 1) HIPCHK(hipEventRecord(s.ev_acc, st));
         // lanes per bucket: ~5 unit partials per lane, so the sequential part and the shuffle tree are balanced
         int lanes_log = 0;
         {
@@ -513,8 +523,42 @@ class CurveBackend : public Backend {
     }
 
     // stream sync + affine conversion of the MSM sums run_msm left in the pinned buffer (results land at h_pinned[0..])
+    // ---- tail filling --------------------------------------------------------------------------------------------------------
+    // A lone proof spends a fifth of its time in the reduction tails of its four commitment batches (combine, row/column sums,
+    // bit sums + final scaling: ~210 us per batch on a few hundred waves), and the launches queued behind a batch - the 4n coset
+    // transforms of the polynomials just committed - wait for the tail although they need neither its result nor its SIMDs.  When
+    // this proof is the only one in flight they go to a second stream gated on an event recorded right behind the accumulate
+    // kernel, so they start when the VALU-bound part of the MSM is over, not before (ungated, round 3's first attempt, they
+    // only slowed the accumulate kernel down by what they gained).  With several proofs in flight other proofs fill the tails
+    // and a second stream per slot costs throughput (-8 % with 16 slots), so the choice is made per proof.
+    int tail_fill(Slot& s) {
+        static const int on = env_int("APK_TAIL_FILL", 1, 0, 2);
+        static const int graphs = env_int("APK_MSM_GRAPH", 0, 0, 1);
+        if (!on || graphs || hook_ || wire_hook_ || stats_on_ || !qk_direct_) return 0;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            int busy = 0;
+            for (Slot* t : slots_) busy += t->busy ? 1 : 0;
+            if (busy != 1) return 0;
+        }
+        if (!s.side) {
+            // lowest priority: the tail kernels on the main stream are the critical path, the transforms only have to be done
+            // by the time the next round's challenge is known
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            if (hipStreamCreateWithPriority(&s.side, hipStreamNonBlocking, least) != hipSuccess) { s.side = nullptr; return 0; }
+            if (hipEventCreateWithFlags(&s.ev_acc, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&s.ev_side, hipEventDisableTiming) != hipSuccess) return 0;
+        }
+        return s.ev_acc && s.ev_side ? on : 0;
+    }
+    int side_begin(Slot& s) { HIPCHK(hipStreamWaitEvent(s.side, s.ev_acc, 0)); return APK_OK; }
+    int side_end(Slot& s) { HIPCHK(hipEventRecord(s.ev_side, s.side)); s.side_pending = true; return APK_OK; }
+
     int sync_results(Slot& s) {
         HIPCHK(hipStreamSynchronize(s.stream));
+        // whatever the main stream is handed from here on runs behind the side stream's transforms
+        if (s.side_pending) { s.side_pending = false; HIPCHK(hipStreamWaitEvent(s.stream, s.ev_side, 0)); }
         if (s.hook_pending) {
             s.hook_pending = false;
             const MsmBatchArgs& a = s.hook_args;
@@ -1179,11 +1223,15 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         for (int j = 0; j < 3; j++) { b3.p[j] = canon[j]; b3.b[j].v[0] = bl[2 * j]; b3.b[j].v[1] = bl[2 * j + 1]; }
         blind3_kernel<FRP><<<3, 64, 0, st>>>(b3, n, 2); KCHK();
     }
+    const int fill = tail_fill(s);
     {
         MsmBatchArgs a{};
         a.batch = 3;
         for (int j = 0; j < 3; j++) { a.scalars[j] = canon[j]; a.len[j] = n + 2; a.offset[j] = 0; }
-        CHK(commit(s, tab_can_, 0, a, hp));
+        s.mark_acc = fill;
+        const int rc = commit(s, tab_can_, 0, a, hp);
+        s.mark_acc = 0;
+        CHK(rc);
     }
     // completed Qk: public inputs and commitment values written into the Lagrange column, then iNTT
     if (!qk_direct_) {
@@ -1207,6 +1255,10 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
             const int rc = wire_hook_(wire_hook_user_, 3, cin, lens, eout);
             hook_slot() = nullptr;
             if (rc != APK_OK) { set_error("wire hook failed with %d", rc); return rc == APK_ERR_ARG ? APK_ERR_ARG : APK_ERR_STATE; }
+        } else if (fill) {
+            CHK(side_begin(s));
+            CHK(run_ntt_batch(s.side, 1, false, 3, canon, ev, lens, n4_, ptr<Fr>(coset_pre_), nullptr, nullptr));
+            CHK(side_end(s));
         } else {
             CHK(run_ntt_batch(st, 1, false, 3, canon, ev, lens, n4_, ptr<Fr>(coset_pre_), nullptr, nullptr));
         }
@@ -1270,9 +1322,18 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         blind_kernel<FRP><<<1, 64, 0, st>>>(ptr<Fr>(s.cz), n, b, 3); KCHK();
         MsmBatchArgs a{};
         a.batch = 1; a.scalars[0] = s.cz.p; a.len[0] = n + 3; a.offset[0] = 0;
-        CHK(commit(s, tab_can_, 0, a, hp));
+        s.mark_acc = fill;
+        const int rc = commit(s, tab_can_, 0, a, hp);
+        s.mark_acc = 0;
+        CHK(rc);
     }
-    CHK(coset_ntt_4n(st, ptr<Fr>(s.cz), n + 3, ptr<Fr>(s.ez)));
+    if (fill) {
+        CHK(side_begin(s));
+        CHK(coset_ntt_4n(s.side, ptr<Fr>(s.cz), n + 3, ptr<Fr>(s.ez)));
+        CHK(side_end(s));
+    } else {
+        CHK(coset_ntt_4n(st, ptr<Fr>(s.cz), n + 3, ptr<Fr>(s.ez)));
+    }
     CHK(sync_results(s));
     const Aff zcom = hp[0];
     store_pt(out->z, zcom);

@@ -1,4 +1,6 @@
-cd $GRAFT_REPO_ROOT
-echo "== unit sweep bn254 2^17"; bash tools/ab_env.sh 2 "--steps 40" "APK_MSM_UNIT=0" "APK_MSM_UNIT=20" "APK_MSM_UNIT=24" "APK_MSM_UNIT=32"
-echo "== callers"; bash tools/ab_args.sh 1 "--steps 40 --inflight 24" "--steps 40 --inflight 32" "--steps 30 --inflight 48" "--steps 20 --inflight 64"
-echo "== slots"; bash tools/ab_env.sh 1 "--steps 40" "APK_MAX_SLOTS=12" "APK_MAX_SLOTS=16" "APK_MAX_SLOTS=20"
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -2
+echo "== fill modes (value, latency, ...)"
+bash tools/ab_env.sh 3 "--steps 12" "APK_TAIL_FILL=0" "APK_TAIL_FILL=1" "APK_TAIL_FILL=2"
+echo "== bls 2^14"; bash tools/ab_env.sh 2 "--steps 12 --curve bls12_381 --log-n 14" "APK_TAIL_FILL=0" "APK_TAIL_FILL=1" "APK_TAIL_FILL=2"
+echo "== bls 2^21"; bash tools/ab_env.sh 1 "--curve bls12_381 --log-n 21 --bsb22 1 --steps 4 --warmup 1 --inflight 2" "APK_TAIL_FILL=1" "APK_TAIL_FILL=2"
