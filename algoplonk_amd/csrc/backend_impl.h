@@ -461,7 +461,22 @@ class CurveBackend : public Backend {
         const int quad = quad_env >= 0 ? quad_env : (slots_.size() <= 2 ? 7 : 14);
         constexpr uint32_t LT_MAX = MsmQuad<FPP>::LT;   // 128 quads (512 lanes) on the 9-limb field, 64 on the 14-limb one
         const uint32_t lt = (rows > cols ? rows : cols) > LT_MAX ? LT_MAX : (rows > cols ? rows : cols);
-        if (quad & 1)
+        // with other proofs in flight nobody waits for this batch's chain: the instruction-lean sixteen-lane form
+        static const int serial_env = env_int("APK_MSM_ROWCOL_SERIAL", -1, -1, 1);
+        bool serial = false;
+        static const int graphs_on = env_int("APK_MSM_GRAPH", 0, 0, 1);   // a captured batch must not depend on the moment of capture
+        if (quad_env < 0 && !graphs_on && rows % 4 == 0 && cols % 4 == 0) {
+            if (serial_env >= 0) serial = serial_env != 0;
+            else if (slots_.size() > 2) {
+                std::lock_guard<std::mutex> lk(mu_);
+                int busy = 0;
+                for (Slot* t : slots_) busy += t->busy ? 1 : 0;
+                serial = busy > 1;
+            }
+        }
+        if (serial)
+            msm_rowcol_serial_kernel<FPP><<<dim3((rows + cols + 15) / 16, a.batch), 256, 0, st>>>(ptr<PtU>(s.bucket_sum), NB_, rows, cols, ptr<PtU>(s.rowcol));
+        else if (quad & 1)
             msm_rowcol_quad_kernel<FPP><<<dim3(rows + cols, a.batch), 4 * lt, lt * sizeof(PtU), st>>>(ptr<PtU>(s.bucket_sum), NB_, rows, cols, ptr<PtU>(s.rowcol));
         else if (quad & 8)
             msm_rowcol_hybrid_kernel<FPP><<<dim3(rows + cols, a.batch), 256, 0, st>>>(ptr<PtU>(s.bucket_sum), NB_, rows, cols, ptr<PtU>(s.rowcol));

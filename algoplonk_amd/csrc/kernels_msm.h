@@ -565,6 +565,34 @@ __global__ void __launch_bounds__(256) msm_rowcol_hybrid_kernel(const XYZZ<FP, F
     if (t == 0) rc[(size_t)m * (rows + cols) + x] = qa;
 }
 
+// Row / column sums when other proofs keep the GPU busy: SIXTEEN lanes per row or column, each lane adds its 8-16 elements one
+// after the other, then a four-level shuffle tree.  The tree kernels above spend most of their instructions on levels where a
+// handful of lanes of a wave are live (255 additions cost ~20 k wave-instructions per row); here a wave of four lines does 19
+// addition-times for 4 x 255 additions (~14 k per row, ~8 k per column).  The chain is twice as long (19 dependent additions
+// instead of 3 + 5 short ones), so a lone proof keeps the tree form - the host picks per batch (run_msm_body).
+template <class FP>
+__global__ void __launch_bounds__(256) msm_rowcol_serial_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum, uint32_t nb, uint32_t rows,
+                                                                uint32_t cols, XYZZ<FP, FeU<FP>>* __restrict__ rc) {
+    wave_priority<APK_PRIO_TAIL>();
+    using PT = XYZZ<FP, FeU<FP>>;
+    const uint32_t m = blockIdx.y;
+    const uint32_t line = blockIdx.x * 16 + (threadIdx.x >> 4);   // rows first, then columns; a wave holds four lines of one kind
+    const uint32_t j = threadIdx.x & 15;
+    const PT* src = bucket_sum + (size_t)m * nb;
+    PT acc = PT::inf();
+    if (line < rows) {
+        for (uint32_t lo = j; lo < cols; lo += 16) acc.add_lazy(src[line * cols + lo]);
+    } else if (line < rows + cols) {
+        const uint32_t col = line - rows;
+        for (uint32_t hi = j; hi < rows; hi += 16) acc.add_lazy(src[hi * cols + col]);
+    }
+    for (int d = 8; d >= 1; d >>= 1) {
+        PT o = shfl_down_point<PT>(acc, d, 16);
+        if (j < (uint32_t)d) acc.add_lazy(o);
+    }
+    if (j == 0 && line < rows + cols) rc[(size_t)m * (rows + cols) + line] = acc;
+}
+
 // Workgroup size of the four-lane reduction kernels.  256 registers per lane are enough for the 9-limb field at 512 lanes;
 // the 14-limb field (BLS12-381: a point is 56 registers, an addition keeps four of them and a product's operands live) spilled
 // to scratch memory there, so its workgroups are 256 lanes: one wave per SIMD, the whole 512-entry register file per lane
