@@ -434,11 +434,29 @@ class CurveBackend : public Backend {
         KCHK();
         if (stats_on_) HIPCHK(hipEventRecord(s.ev3, st));
         if (s.mark_acc == 1) HIPCHK(hipEventRecord(s.ev_acc, st));
-        // lanes per bucket: ~5 unit partials per lane, so the sequential part and the shuffle tree are balanced
+        // Are other proofs keeping the GPU busy?  Then nobody waits for this batch's reduction chain and the instruction-lean
+        // forms of the tail kernels win (fewer, longer chains: every lane of a wave does useful additions); a lone proof keeps
+        // the short-chain forms.
+        bool others_busy = false;
+        if (slots_.size() > 2) {
+            std::lock_guard<std::mutex> lk(mu_);
+            int busy = 0;
+            for (Slot* t : slots_) busy += t->busy ? 1 : 0;
+            others_busy = busy > 1;
+        }
+        static const int graphs_on = env_int("APK_MSM_GRAPH", 0, 0, 1);   // a captured batch must not depend on the moment of capture
+        if (graphs_on) others_busy = false;
+        // lanes per bucket: ~5 unit partials per lane, so the sequential part and the shuffle tree are balanced; one lane walks up
+        // to 32 partials when the GPU has other work (a shuffle level costs every lane of the group an addition, useful or not)
+        static const int lean_env = env_int("APK_MSM_LEAN_TAIL", -1, -1, 1);
+        const bool lean = lean_env >= 0 ? lean_env != 0 : others_busy;
         int lanes_log = 0;
         {
             const uint64_t upb = (entries / unit) / total_buckets + 1;  // unit partials per bucket (estimate)
-            while ((1u << lanes_log) < MSM_COMBINE_LANES && (upb >> lanes_log) > 5) lanes_log++;
+            // (only with enough buckets to fill the SIMDs at one lane each: at BLS12-381 2^14 - 6 144 buckets, 11 partials
+            // each - one lane per bucket was measured SLOWER under load, 1 137 -> 1 114 proofs/s)
+            const uint64_t per_lane = lean && total_buckets >= 32768u ? 32 : 5;
+            while ((1u << lanes_log) < MSM_COMBINE_LANES && (upb >> lanes_log) > per_lane) lanes_log++;
         }
         {   // light and heavy merge in one launch (the heavy blocks return at once when no bucket is skewed)
             const uint32_t normal_blocks = cdiv((uint64_t)total_buckets << lanes_log, 256);
@@ -464,16 +482,7 @@ class CurveBackend : public Backend {
         // with other proofs in flight nobody waits for this batch's chain: the instruction-lean sixteen-lane form
         static const int serial_env = env_int("APK_MSM_ROWCOL_SERIAL", -1, -1, 1);
         bool serial = false;
-        static const int graphs_on = env_int("APK_MSM_GRAPH", 0, 0, 1);   // a captured batch must not depend on the moment of capture
-        if (quad_env < 0 && !graphs_on && rows % 4 == 0 && cols % 4 == 0) {
-            if (serial_env >= 0) serial = serial_env != 0;
-            else if (slots_.size() > 2) {
-                std::lock_guard<std::mutex> lk(mu_);
-                int busy = 0;
-                for (Slot* t : slots_) busy += t->busy ? 1 : 0;
-                serial = busy > 1;
-            }
-        }
+        if (quad_env < 0 && !graphs_on && rows % 4 == 0 && cols % 4 == 0) serial = serial_env >= 0 ? serial_env != 0 : lean;
         if (serial)
             msm_rowcol_serial_kernel<FPP><<<dim3((rows + cols + 15) / 16, a.batch), 256, 0, st>>>(ptr<PtU>(s.bucket_sum), NB_, rows, cols, ptr<PtU>(s.rowcol));
         else if (quad & 1)
