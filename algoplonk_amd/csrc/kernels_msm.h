@@ -59,7 +59,10 @@ struct MsmBatchArgs {
 // share a word (a slice holds <= 4096 scalars x 17 windows < 2^16 entries, so a half never overflows into its neighbour);
 // the scatter pass then keeps only the entry's RANK inside (slice, bucket) in LDS and adds the two bases - the bucket's global
 // offset and the slice's prefix inside the bucket - from global memory (both L2 resident).
-constexpr uint32_t MSM_PACKED_NB = 65536;
+#ifndef APK_MSM_PACKED_NB
+#define APK_MSM_PACKED_NB 65536
+#endif
+constexpr uint32_t MSM_PACKED_NB = APK_MSM_PACKED_NB;
 constexpr int MSM_DIGITS_THREADS = 1024;  // per sort workgroup: the slice's LDS atomics and scattered stores are latency-bound
 template <class FR, bool SCATTER>
 __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_digits_kernel(MsmBatchArgs a, MsmWindows win, uint32_t nb, uint32_t n_max, uint32_t G,

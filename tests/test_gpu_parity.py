@@ -638,3 +638,47 @@ def test_prove_with_few_and_many_public_inputs(gpu, cname, nb_public):
         with pytest.raises(ap_plonk.VerificationError):
             ap_plonk.Verify(proof, vk, bad)
     pk.close()
+
+
+_VARIANT_SCRIPT = r"""
+import hashlib, sys, os
+sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+from algoplonk_amd import MarshalProof, plonk, setup
+from oracle.prng import tau_from_seed
+from helpers import CURVES, blinding, random_chain_ccs
+cname, log_n, window = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+cv, _ = CURVES[cname]
+ccs, w, _ = random_chain_ccs(cv, log_n, 77)
+srs = setup.unsafe_srs(cv, ccs.domain_size(), tau_from_seed(9, cv.r), device=0)
+pk, vk = plonk.Setup(ccs, srs, device=0, msm_window=window, slots=3)
+print("SHA", hashlib.sha256(MarshalProof(plonk.Prove(ccs, pk, w, blinding(cv, 3)))).hexdigest())
+"""
+
+
+@pytest.mark.parametrize("cname,log_n,window,variants", [
+    ("bn254", 12, 16, [{"APK_MSM_LEAN_TAIL": "1"}, {"APK_MSM_LEAN_TAIL": "0", "APK_TAIL_FILL": "0"}, {"APK_TAIL_FILL": "2"},
+                       {"APK_NTT_RADIX4": "1"}, {"APK_NTT_RADIX4": "1", "APK_NTT_THREADS": "64"}]),
+    ("bls12-381", 10, 12, [{"APK_MSM_LEAN_TAIL": "1", "APK_NTT_RADIX4": "1"}]),
+])
+def test_run_time_variants_give_the_same_bytes(gpu, cname, log_n, window, variants):
+    """The forms the library picks at run time - lean tail kernels when other proofs are in flight (sixteen-lane row/column
+    sums, one lane per bucket in the merge), the tail-filling side stream of a lone proof, radix-4 NTT steps above 2^19 - are
+    scheduling choices: every one of them, forced through its environment knob in a process of its own (the knobs are read
+    once), must produce the proof bytes of the default build.  c = 16 at BN254 so the merge kernel's lean form (>= 32 k buckets)
+    is really taken."""
+    import subprocess
+    import sys
+
+    def sha(extra):
+        env = dict(os.environ)
+        env.update(extra)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+        out = subprocess.run([sys.executable, "-c", _VARIANT_SCRIPT, cname, str(log_n), str(window)], cwd=root, env=env,
+                             capture_output=True, text=True, timeout=240)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return [ln.split()[1] for ln in out.stdout.splitlines() if ln.startswith("SHA ")][0]
+
+    want = sha({})
+    for v in variants:
+        assert sha(v) == want, v

@@ -1,7 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -2
-echo "== lean tail 0 / auto: bn254 2^17"
-bash tools/ab_env.sh 2 "--steps 40" "APK_MSM_LEAN_TAIL=0" "APK_MSM_LEAN_TAIL=-1"
-echo "== bls 2^14"; bash tools/ab_env.sh 2 "--steps 40 --curve bls12_381 --log-n 14" "APK_MSM_LEAN_TAIL=0" "APK_MSM_LEAN_TAIL=-1"
-echo "== bls 2^21"; bash tools/ab_env.sh 1 "--curve bls12_381 --log-n 21 --bsb22 1 --steps 4 --warmup 1 --inflight 2" "APK_MSM_LEAN_TAIL=0" "APK_MSM_LEAN_TAIL=-1"
-echo "== bn254 2^20"; bash tools/ab_env.sh 1 "--log-n 20 --steps 6 --warmup 1 --inflight 8" "APK_MSM_LEAN_TAIL=0" "APK_MSM_LEAN_TAIL=-1"
+python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "run_time_variants" 2>&1 | tail -3
+echo "== bls 2^21 window sweep"
+bash tools/ab_env.sh 1 "--curve bls12_381 --log-n 21 --bsb22 1 --steps 5 --warmup 1 --inflight 2" "APK_MSM_WINDOW=16" "APK_MSM_WINDOW=15" "APK_MSM_WINDOW=17"
+echo "== bls 2^21 inflight 3/4"
+bash tools/ab_args.sh 1 "--curve bls12_381 --log-n 21 --bsb22 1 --steps 5 --warmup 1 --inflight 3" "--curve bls12_381 --log-n 21 --bsb22 1 --steps 4 --warmup 1 --inflight 4"
