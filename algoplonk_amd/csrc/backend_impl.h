@@ -710,6 +710,11 @@ class CurveBackend : public Backend {
         if (c_ == 0) {
             c_ = log_size - 2; if (c_ < 8) c_ = 8; if (c_ > 15) c_ = 15;
             if (log_size >= 21 || (log_size >= 17 && slots > 2)) c_ = 16;
+            // throughput contexts below 2^17, re-measured with the lean tail kernels (round 3, same-box sweeps): fewer windows
+            // pay again - BLS12-381 2^14: c = 12 -> 1 176, 13 -> 1 207, 14 -> 1 147 proofs/s; BN254 2^16: 14 -> 800, 15 -> 839,
+            // 16 -> 825; BN254 2^15: 13 -> 1 274, 14 -> 1 224, 15 -> 1 274 (and the lower latency)
+            else if (slots > 2 && log_size == 14) c_ = 13;
+            else if (slots > 2 && (log_size == 15 || log_size == 16)) c_ = 15;
         }
         if (c_ < 7 || c_ > 17) { set_error("msm_window %d out of [7,17]", c_); return APK_ERR_ARG; }
         // c = 17 counts in packed 16-bit halves: a sort slice (at most msm_G_max_ of them) must stay below 2^16 entries
