@@ -353,6 +353,14 @@ class CurveBackend : public Backend {
         return APK_OK;
     }
 
+    // Measurement aid (tools/knockout.sh, -DAPK_DEBUG_KNOCKOUT builds only): APK_DEBUG_SKIP is a bit mask of MSM phases NOT to
+    // launch - 1 count pass + column scan, 32 the three scan launches, 64 scatter pass (the previous batch's sort stays in
+    // place), 2 accumulate, 4 merge, 8 row/column sums, 16 bit sums + final.  The results are garbage; what it shows is what each phase costs at saturation.
+#ifdef APK_DEBUG_KNOCKOUT
+#define APK_PHASE(bit) ((env_int("APK_DEBUG_SKIP", 0, 0, 127) & (bit)) == 0)
+#else
+#define APK_PHASE(bit) true
+#endif
     // results land in slot.result (device) and are copied to h_out (host, batch points) - caller syncs the stream
     int run_msm_body(Slot& s, const MsmTables& T, const MsmBatchArgs& a, Aff* h_out) {
         hipStream_t st = s.stream;
@@ -404,11 +412,13 @@ class CurveBackend : public Backend {
         dim3 gd(G, a.batch);
         const size_t lds = digits_lds_bytes();
         static const int dth = env_int("APK_MSM_DIGITS_THREADS", MSM_DIGITS_THREADS, 64, MSM_DIGITS_THREADS) & ~63;   // whole waves, <= the launch bound
+        if (APK_PHASE(1)) {
         msm_digits_kernel<FRP, false><<<gd, dth, lds, st>>>(a, win_, NB_, T.n_bases, G, ptr<uint32_t>(s.counts), nullptr, nullptr);
         KCHK();
         msm_colscan_kernel<0><<<cdiv(total_buckets, 256), 256, 0, st>>>(ptr<uint32_t>(s.counts), NB_, G, total_buckets, ptr<uint32_t>(s.hist));
         KCHK();
-        {
+        }
+        if (APK_PHASE(32)) {
             const uint32_t nblk = cdiv(total_buckets, MSM_SCAN_BLOCK);   // <= 1024: total_buckets <= 4 * 2^15... checked at init
             uint32_t* blk_tot = ptr<uint32_t>(s.scan_blk);
             uint32_t* blk_bins = blk_tot + 3 * nblk;
@@ -424,10 +434,13 @@ class CurveBackend : public Backend {
                                                                       ptr<uint32_t>(s.full_off), ptr<uint32_t>(s.rem_list));
             KCHK();
         }
+        if (APK_PHASE(64)) {
         msm_digits_kernel<FRP, true><<<gd, dth, lds, st>>>(a, win_, NB_, T.n_bases, G, ptr<uint32_t>(s.counts), ptr<uint32_t>(s.offsets),
                                                             ptr<uint32_t>(s.sorted));
         KCHK();
+        }
         if (stats_on_) HIPCHK(hipEventRecord(s.ev2, st));
+        if (APK_PHASE(2))
         msm_accumulate_kernel<FPP><<<cdiv(max_units, 128), 128, 0, st>>>(ptr<Aff>(T.table), ptr<uint32_t>(s.sorted), ptr<uint32_t>(s.offsets),
                                                                         ptr<uint32_t>(s.unit_off), ptr<uint32_t>(s.full_off), ptr<uint32_t>(s.rem_list),
                                                                         total_buckets, max_units, unit, ptr<PtU>(s.partial));
@@ -460,6 +473,7 @@ class CurveBackend : public Backend {
         }
         {   // light and heavy merge in one launch (the heavy blocks return at once when no bucket is skewed)
             const uint32_t normal_blocks = cdiv((uint64_t)total_buckets << lanes_log, 256);
+            if (APK_PHASE(4))
             msm_combine_kernel<FPP><<<normal_blocks + MSM_HEAVY_BLOCKS, 256, 0, st>>>(
                 ptr<PtU>(s.partial), ptr<uint32_t>(s.unit_off), total_buckets, lanes_log, normal_blocks, ptr<PtU>(s.bucket_sum));
             KCHK();
@@ -483,7 +497,8 @@ class CurveBackend : public Backend {
         static const int serial_env = env_int("APK_MSM_ROWCOL_SERIAL", -1, -1, 1);
         bool serial = false;
         if (quad_env < 0 && !graphs_on && rows % 4 == 0 && cols % 4 == 0) serial = serial_env >= 0 ? serial_env != 0 : lean;
-        if (serial)
+        if (!APK_PHASE(8)) {
+        } else if (serial)
             msm_rowcol_serial_kernel<FPP><<<dim3((rows + cols + 15) / 16, a.batch), 256, 0, st>>>(ptr<PtU>(s.bucket_sum), NB_, rows, cols, ptr<PtU>(s.rowcol));
         else if (quad & 1)
             msm_rowcol_quad_kernel<FPP><<<dim3(rows + cols, a.batch), 4 * lt, lt * sizeof(PtU), st>>>(ptr<PtU>(s.bucket_sum), NB_, rows, cols, ptr<PtU>(s.rowcol));
@@ -494,7 +509,8 @@ class CurveBackend : public Backend {
         KCHK();
         // the sums leave the device in XYZZ form: the one field inversion of the affine conversion takes a lone GPU lane
         // ~100 us and the host a few; sync_results() finishes them into h_out (= the slot's pinned buffer)
-        if ((quad & 6) == 6) {
+        if (!APK_PHASE(16)) {
+        } else if ((quad & 6) == 6) {
             // bit sums + final scaling in ONE launch (the last workgroup to finish an MSM's bit sums runs its final phase)
             const uint32_t threads = 4 * lt > 256 ? 4 * lt : 256;
             const size_t lds = (size_t)(lt > 64 ? lt : 64) * sizeof(PtU);
