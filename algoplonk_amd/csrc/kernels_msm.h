@@ -164,6 +164,151 @@ __global__ void __launch_bounds__(256) msm_colscan_kernel(uint32_t* __restrict__
     hist[kk] = run;
 }
 
+// ---- two-level counting sort (run_msm_body, APK_MSM_SORT2) ----------------------------------------------------------------
+// The one-level sort above scatters every (digit, point) pair straight to its bucket: a slice of 2 048 scalars has one entry per
+// bucket on average, so its 32 k stores are 32 k isolated 4-byte writes, and tools/knockout.py prices that pass at 8 % of an MSM
+// at saturation for 1 % of its instructions.  Here the pairs are first dealt to PARTITIONS of 256 neighbouring buckets
+// (msm_part_kernel: a slice writes ~250 pairs per partition, side by side), then one workgroup per partition counting-sorts its
+// ~16 k pairs in LDS order and writes them out (msm_part_sort_kernel: all stores into one 64 KiB window, from one XCD).  The
+// second level also produces the per-bucket counts, so the column scan goes.  Intermediate pairs carry their bucket id
+// (8 bytes); both levels use the same compact numbering, so a partition's pairs occupy the same index range before and after.
+constexpr uint32_t MSM_PART_BUCKETS = 256;
+constexpr uint32_t MSM_PART_MAX = 512;      // partitions per MSM (nb <= 2^17)
+
+template <class FR, bool SCATTER>
+__global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part_kernel(MsmBatchArgs a, MsmWindows win, uint32_t nb, uint32_t n_max, uint32_t G,
+                                                                     uint32_t* __restrict__ pcounts,         // [batch][G][P]   (!SCATTER: out)
+                                                                     const uint32_t* __restrict__ runstart,  // [batch][G][P]   (SCATTER: in)
+                                                                     uint2* __restrict__ tmp) {
+    wave_priority<APK_PRIO_SORT>();
+    using Fr = Fe<FR>;
+    __shared__ uint32_t cur[MSM_PART_MAX];
+    const uint32_t g = blockIdx.x, b = blockIdx.y;
+    const uint32_t P = nb / MSM_PART_BUCKETS;
+    const size_t row = ((size_t)b * G + g) * P;
+    for (uint32_t k = threadIdx.x; k < P; k += blockDim.x) cur[k] = SCATTER ? runstart[row + k] : 0u;
+    __syncthreads();
+    const uint32_t len = a.len[b];
+    const uint32_t per = (len + G - 1) / G;
+    const uint32_t lo = min(g * per, len), hi = min(lo + per, len);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+#ifndef APK_MSM_NO_RINV
+        Fr s = reinterpret_cast<const Fr*>(a.scalars[b])[i];      // Montgomery form as it is: the tables hold R^-1 * P
+#else
+        Fr s = Fr::from_mont(reinterpret_cast<const Fr*>(a.scalars[b])[i]);
+#endif
+        uint32_t carry = 0;
+        const uint32_t base_idx = a.offset[b] + i;
+        uint64_t buf = 0;
+        int avail = 0, j = 0;
+#pragma unroll
+        for (int li = 0; li < Fr::N; li++) {
+            buf |= (uint64_t)s.l[li] << avail;
+            avail += 32;
+            while (j < win.W && (avail >= (int)win.width[j] || li == Fr::N - 1)) {
+                const int c = win.width[j];
+                const uint32_t half = 1u << (c - 1);
+                uint32_t d = ((uint32_t)buf & ((1u << c) - 1u)) + carry;
+                buf >>= c;
+                avail -= c;
+                uint32_t neg = 0;
+                if (d > half) { d = (1u << c) - d; neg = 1; carry = 1; }
+                else carry = 0;
+                if (d != 0) {
+                    const uint32_t k = d - 1;
+                    if (!SCATTER) atomicAdd(&cur[k / MSM_PART_BUCKETS], 1u);
+                    else {
+                        const uint32_t pos = atomicAdd(&cur[k / MSM_PART_BUCKETS], 1u);
+                        tmp[pos] = make_uint2(((uint32_t)j * n_max + base_idx) | (neg << 31), k);
+                    }
+                }
+                j++;
+            }
+        }
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < P; k += blockDim.x) pcounts[row + k] = cur[k];
+    }
+}
+
+// one workgroup: first slot of every (msm, partition, slice) run in the order (msm, partition, slice), and the partition totals
+template <int DUMMY>
+__global__ void __launch_bounds__(1024) msm_part_scan_kernel(const uint32_t* __restrict__ pcounts, uint32_t* __restrict__ runstart,
+                                                            uint32_t* __restrict__ ptot, uint32_t batch, uint32_t G, uint32_t P) {
+    wave_priority<APK_PRIO_SORT>();
+    __shared__ uint32_t s_sum[1024];
+    const uint32_t t = threadIdx.x, n = batch * P;          // n <= 2048: two (msm, partition) pairs per thread
+    uint32_t tot[2] = {0, 0};
+    for (int h = 0; h < 2; h++) {
+        const uint32_t q = 2 * t + h;
+        if (q < n) {
+            const uint32_t b = q / P, p = q % P;
+            uint32_t run = 0;
+            for (uint32_t g = 0; g < G; g++) run += pcounts[((size_t)b * G + g) * P + p];
+            tot[h] = run;
+            ptot[q] = run;
+        }
+    }
+    s_sum[t] = tot[0] + tot[1];
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t v = t >= d ? s_sum[t - d] : 0u;
+        __syncthreads();
+        s_sum[t] += v;
+        __syncthreads();
+    }
+    uint32_t base = s_sum[t] - (tot[0] + tot[1]);            // exclusive
+    for (int h = 0; h < 2; h++) {
+        const uint32_t q = 2 * t + h;
+        if (q < n) {
+            const uint32_t b = q / P, p = q % P;
+            uint32_t run = base;
+            for (uint32_t g = 0; g < G; g++) {
+                const size_t at = ((size_t)b * G + g) * P + p;
+                runstart[at] = run;
+                run += pcounts[at];
+            }
+        }
+        base += tot[h];
+    }
+}
+
+// grid (P, batch): counting sort of one partition's pairs by bucket; hist[b*nb + k] = entries of bucket k
+template <int DUMMY>
+__global__ void __launch_bounds__(512) msm_part_sort_kernel(const uint2* __restrict__ tmp, const uint32_t* __restrict__ runstart,
+                                                           const uint32_t* __restrict__ ptot, uint32_t G, uint32_t P, uint32_t nb,
+                                                           uint32_t* __restrict__ hist, uint32_t* __restrict__ sorted) {
+    wave_priority<APK_PRIO_SORT>();
+    __shared__ uint32_t cnt[MSM_PART_BUCKETS], cur[MSM_PART_BUCKETS];
+    const uint32_t p = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const uint32_t first = runstart[(size_t)b * G * P + p];          // slice 0's run opens the partition
+    const uint32_t n = ptot[b * P + p];
+    if (t < MSM_PART_BUCKETS) cnt[t] = 0u;
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += blockDim.x) atomicAdd(&cnt[tmp[first + i].y % MSM_PART_BUCKETS], 1u);
+    __syncthreads();
+    uint32_t mine = 0;
+    if (t < MSM_PART_BUCKETS) { mine = cnt[t]; cur[t] = mine; }
+    __syncthreads();
+    for (uint32_t d = 1; d < MSM_PART_BUCKETS; d <<= 1) {
+        uint32_t v = 0;
+        if (t < MSM_PART_BUCKETS && t >= d) v = cur[t - d];
+        __syncthreads();
+        if (t < MSM_PART_BUCKETS) cur[t] += v;
+        __syncthreads();
+    }
+    if (t < MSM_PART_BUCKETS) {
+        hist[(size_t)b * nb + p * MSM_PART_BUCKETS + t] = mine;
+        cur[t] = first + cur[t] - mine;                              // exclusive prefix inside the partition
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += blockDim.x) {
+        const uint2 e = tmp[first + i];
+        sorted[atomicAdd(&cur[e.y % MSM_PART_BUCKETS], 1u)] = e.x;
+    }
+}
+
 // ---- exclusive scans of the bucket counts: entry offsets and work-unit offsets ------------------------------------------
 // A bucket of h entries is cut into floor(h/unit) FULL work units and, if h % unit != 0, one REMAINDER unit.
 //   offsets[k]  = sum_{i<k} hist[i]                 (entries)

@@ -657,12 +657,13 @@ print("SHA", hashlib.sha256(MarshalProof(plonk.Prove(ccs, pk, w, blinding(cv, 3)
 
 @pytest.mark.parametrize("cname,log_n,window,variants", [
     ("bn254", 12, 16, [{"APK_MSM_LEAN_TAIL": "1"}, {"APK_MSM_LEAN_TAIL": "0", "APK_TAIL_FILL": "0"}, {"APK_TAIL_FILL": "2"},
-                       {"APK_NTT_RADIX4": "1"}, {"APK_NTT_RADIX4": "1", "APK_NTT_THREADS": "64"}]),
-    ("bls12-381", 10, 12, [{"APK_MSM_LEAN_TAIL": "1", "APK_NTT_RADIX4": "1"}]),
+                       {"APK_NTT_RADIX4": "1"}, {"APK_NTT_RADIX4": "1", "APK_NTT_THREADS": "64"}, {"APK_MSM_SORT2": "1"}]),
+    ("bls12-381", 10, 12, [{"APK_MSM_LEAN_TAIL": "1", "APK_NTT_RADIX4": "1"}, {"APK_MSM_SORT2": "1"}]),
 ])
 def test_run_time_variants_give_the_same_bytes(gpu, cname, log_n, window, variants):
     """The forms the library picks at run time - lean tail kernels when other proofs are in flight (sixteen-lane row/column
-    sums, one lane per bucket in the merge), the tail-filling side stream of a lone proof, radix-4 NTT steps above 2^19 - are
+    sums, one lane per bucket in the merge), the tail-filling side stream of a lone proof, radix-4 NTT steps above 2^19, the
+    two-level counting sort that is built but off by default - are
     scheduling choices: every one of them, forced through its environment knob in a process of its own (the knobs are read
     once), must produce the proof bytes of the default build.  c = 16 at BN254 so the merge kernel's lean form (>= 32 k buckets)
     is really taken."""
