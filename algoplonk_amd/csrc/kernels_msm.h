@@ -98,6 +98,9 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_digits_kernel(MsmBatch
         // a run-time window offset costs a compare-select chain per window).  j is uniform across the wave.
         uint64_t buf = 0;
         int avail = 0, j = 0;
+#if defined(APK_DEBUG_SCATTER)
+        uint32_t dbg = 0;
+#endif
 #pragma unroll
         for (int li = 0; li < Fr::N; li++) {
             buf |= (uint64_t)s.l[li] << avail;
@@ -123,13 +126,25 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_digits_kernel(MsmBatch
                     } else if (!SCATTER) {
                         atomicAdd(&lds[k], 1u);
                     } else {
+#if !defined(APK_DEBUG_SCATTER)
                         uint32_t pos = atomicAdd(&lds[k], 1u);
                         sorted[pos] = ((uint32_t)j * n_max + base_idx) | (neg << 31);
+#elif APK_DEBUG_SCATTER == 1      /* measurement builds: the atomics without the stores ... */
+                        dbg ^= atomicAdd(&lds[k], 1u);
+#elif APK_DEBUG_SCATTER == 2      /* ... the atomics with stores next to each other ... */
+                        dbg ^= atomicAdd(&lds[k], 1u);
+                        sorted[((size_t)b * n_max + i) * win.W + j] = ((uint32_t)j * n_max + base_idx) | (neg << 31);
+#else                             /* ... the scattered stores without the atomics */
+                        sorted[(k * 64u + (i & 63u)) % (nb * 64u) + b * nb * 64u] = ((uint32_t)j * n_max + base_idx) | (neg << 31);
+#endif
                     }
                 }
                 j++;
             }
         }
+#if defined(APK_DEBUG_SCATTER)
+        if (SCATTER && dbg == 0xdeadbeefu) sorted[i] = dbg;   // keeps the atomics' results alive
+#endif
     }
     if (!SCATTER) {
         __syncthreads();
