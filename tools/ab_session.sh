@@ -1,4 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -2
-echo "== scatter pass with the stores two windows behind the atomics: bn254 2^17 (value, latency, acc launch, saturated MSM, ntt)"
-bash tools/ab_libs.sh 3 "--steps 40" algoplonk_amd/libapk_nopipe.so algoplonk_amd/libapk.so
+for L in knockout sc1 sc2 sc3; do
+  echo "== $L"
+  APK_LIB=$PWD/algoplonk_amd/libapk_$L.so timeout 300 python tools/knockout.py 17 16 30 2>&1 | grep -E "skip +(0|64|97) "
+done
