@@ -412,26 +412,49 @@ class CurveBackend : public Backend {
         dim3 gd(G, a.batch);
         const size_t lds = digits_lds_bytes();
         static const int dth = env_int("APK_MSM_DIGITS_THREADS", MSM_DIGITS_THREADS, 64, MSM_DIGITS_THREADS) & ~63;   // whole waves, <= the launch bound
+        // Are other proofs keeping the GPU busy?  Then nobody waits for this batch's reduction chain and the instruction-lean
+        // forms of the tail kernels win (fewer, longer chains: every lane of a wave does useful additions); a lone proof keeps
+        // the short-chain forms.
+        bool others_busy = false;
+        if (slots_.size() > 2) {
+            std::lock_guard<std::mutex> lk(mu_);
+            int busy = 0;
+            for (Slot* t : slots_) busy += t->busy ? 1 : 0;
+            others_busy = busy > 1;
+        }
+        static const int graphs_on = env_int("APK_MSM_GRAPH", 0, 0, 1);   // a captured batch must not depend on the moment of capture
+        if (graphs_on) others_busy = false;
+        static const int lean_env = env_int("APK_MSM_LEAN_TAIL", -1, -1, 1);
+        const bool lean = lean_env >= 0 ? lean_env != 0 : others_busy;
         // two-level sort (kernels_msm.h): partitions of 256 buckets, then a counting sort per partition - the stores of both
         // levels are neighbours of each other instead of 2 M isolated 4-byte writes per MSM
-        // Measured (round 3, same box): BN254 2^17 saturated MSM rate 672 -> 690 Mscalar/s, proofs/s 470 -> 471, a lone proof
-        // 3.53 -> 3.63 ms (three more launches per batch); BLS12-381 2^14 -1.5 %, 2^21 -1 %: built, byte-identical, OFF by default.
-        static const int sort2_env = env_int("APK_MSM_SORT2", 0, 0, 1);
+        // Measured (round 3, same box, every scatter of both levels inside an LDS tile): BN254 2^17 463.5 -> 485.0 proofs/s (+4.6 %);
+        // a lone proof 3.54 -> 3.61 ms (one more launch per batch) and BLS12-381 2^14 1 183 -> 1 154: so it is taken when other
+        // proofs are in flight and the MSM has >= 2^16 bases (APK_MSM_SORT2: -1 that rule, 0 never, 1 whenever it applies).
+        // A first version with the second level's stores still scattered (inside 64 KiB windows) gained nothing: DESIGN section 5.
+        static const int sort2_env = env_int("APK_MSM_SORT2", -1, -1, 1);
+        const bool sort2_want = sort2_env >= 0 ? sort2_env != 0 : (lean && T.n_bases >= 65536u);
         const uint32_t P = NB_ / MSM_PART_BUCKETS;
-        const bool sort2 = sort2_env && NB_ >= 4 * MSM_PART_BUCKETS && NB_ < MSM_PACKED_NB && P <= MSM_PART_MAX && s.sort_tmp.p &&
+        const bool sort2 = sort2_want && NB_ >= 4 * MSM_PART_BUCKETS && NB_ < MSM_PACKED_NB && P <= MSM_PART_MAX && s.sort_tmp.p &&
+                           (uint64_t)T.n_bases * W_ <= (1ull << MSM_PART_IDX_BITS) &&
                            (uint64_t)a.batch * G * P * 2 + (uint64_t)a.batch * P <= (uint64_t)total_buckets * msm_G_max_;
         uint32_t* pcounts = ptr<uint32_t>(s.counts);
         uint32_t* runstart = pcounts + (size_t)a.batch * G * P;
         uint32_t* ptot = runstart + (size_t)a.batch * G * P;
         if (sort2) {
-            msm_part_kernel<FRP, false><<<gd, dth, 0, st>>>(a, win_, NB_, T.n_bases, G, pcounts, nullptr, nullptr);
+            // LDS stage of the first level: a slice's entries (<= slice x W words; slices that do not fit scatter in HBM)
+            const uint32_t per_slice = cdiv(maxlen, G);
+            uint32_t stage_cap = per_slice * (uint32_t)W_;
+            if (stage_cap > 36864u) stage_cap = 36864u;                      // 144 KiB of the CU's 160
+            msm_part_kernel<FRP, false><<<gd, dth, 0, st>>>(a, win_, NB_, T.n_bases, G, pcounts, nullptr, nullptr, 0);
             KCHK();
             msm_part_scan_kernel<0><<<1, 1024, 0, st>>>(pcounts, runstart, ptot, a.batch, G, P);
             KCHK();
-            msm_part_kernel<FRP, true><<<gd, dth, 0, st>>>(a, win_, NB_, T.n_bases, G, nullptr, runstart, reinterpret_cast<uint2*>(s.sort_tmp.p));
+            msm_part_kernel<FRP, true><<<gd, dth, (size_t)stage_cap * 4, st>>>(a, win_, NB_, T.n_bases, G, pcounts, runstart, ptr<uint32_t>(s.sort_tmp),
+                                                                               stage_cap);
             KCHK();
-            msm_part_sort_kernel<0><<<dim3(P, a.batch), 512, 0, st>>>(reinterpret_cast<const uint2*>(s.sort_tmp.p), runstart, ptot, G, P, NB_,
-                                                                       ptr<uint32_t>(s.hist), ptr<uint32_t>(s.sorted));
+            msm_part_sort_kernel<0><<<dim3(P, a.batch), 512, (size_t)MSM_PART_TILE * 4, st>>>(ptr<uint32_t>(s.sort_tmp), runstart, ptot, G, P, NB_,
+                                                                                               ptr<uint32_t>(s.hist), ptr<uint32_t>(s.sorted));
             KCHK();
         } else if (APK_PHASE(1)) {
         msm_digits_kernel<FRP, false><<<gd, dth, lds, st>>>(a, win_, NB_, T.n_bases, G, ptr<uint32_t>(s.counts), nullptr, nullptr);
@@ -468,22 +491,8 @@ class CurveBackend : public Backend {
         KCHK();
         if (stats_on_) HIPCHK(hipEventRecord(s.ev3, st));
         if (s.mark_acc == 1) HIPCHK(hipEventRecord(s.ev_acc, st));
-        // Are other proofs keeping the GPU busy?  Then nobody waits for this batch's reduction chain and the instruction-lean
-        // forms of the tail kernels win (fewer, longer chains: every lane of a wave does useful additions); a lone proof keeps
-        // the short-chain forms.
-        bool others_busy = false;
-        if (slots_.size() > 2) {
-            std::lock_guard<std::mutex> lk(mu_);
-            int busy = 0;
-            for (Slot* t : slots_) busy += t->busy ? 1 : 0;
-            others_busy = busy > 1;
-        }
-        static const int graphs_on = env_int("APK_MSM_GRAPH", 0, 0, 1);   // a captured batch must not depend on the moment of capture
-        if (graphs_on) others_busy = false;
         // lanes per bucket: ~5 unit partials per lane, so the sequential part and the shuffle tree are balanced; one lane walks up
         // to 32 partials when the GPU has other work (a shuffle level costs every lane of the group an addition, useful or not)
-        static const int lean_env = env_int("APK_MSM_LEAN_TAIL", -1, -1, 1);
-        const bool lean = lean_env >= 0 ? lean_env != 0 : others_busy;
         int lanes_log = 0;
         {
             const uint64_t upb = (entries / unit) / total_buckets + 1;  // unit partials per bucket (estimate)
@@ -684,8 +693,9 @@ class CurveBackend : public Backend {
         CHK(s.full_off.alloc((size_t)(tb + 1) * 4)); CHK(s.rem_rank.alloc((size_t)(tb + 1) * 4)); CHK(s.rem_list.alloc((size_t)(tb + 1) * 4));
         CHK(s.counts.alloc((size_t)tb * msm_G_max_ * 4));
         CHK(s.sorted.alloc(entries * 4));
-        if (env_int("APK_MSM_SORT2", 0, 0, 1) && NB_ >= 4 * MSM_PART_BUCKETS && NB_ < MSM_PACKED_NB)
-            CHK(s.sort_tmp.alloc(entries * 8));   // two-level sort: (entry, bucket) pairs
+        if (env_int("APK_MSM_SORT2", -1, -1, 1) != 0 && NB_ >= 4 * MSM_PART_BUCKETS && NB_ < MSM_PACKED_NB &&
+            (uint64_t)msm_bases_ * W_ <= (1ull << MSM_PART_IDX_BITS) && (msm_bases_ >= 65536u || env_int("APK_MSM_SORT2", -1, -1, 1) == 1))
+            CHK(s.sort_tmp.alloc(entries * 4));   // two-level sort: packed entries between the levels
         CHK(s.partial.alloc((entries / MSM_UNIT_MIN + tb) * sizeof(PtU)));
         CHK(s.bucket_sum.alloc((size_t)tb * sizeof(PtU)));
         {
@@ -800,6 +810,8 @@ class CurveBackend : public Backend {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)digits_lds_bytes()));
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)digits_lds_bytes()));
         }
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 36864 * 4));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_sort_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_TILE * 4));
         DevBuf srs;
         CHK(srs.alloc(count * sizeof(Aff)));
         HIPCHK(hipMemcpy(srs.p, bases, count * sizeof(Aff), hipMemcpyHostToDevice));
@@ -897,6 +909,8 @@ class CurveBackend : public Backend {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)digits_lds_bytes()));
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)digits_lds_bytes()));
         }
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 36864 * 4));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_sort_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_TILE * 4));
         // proving slots
         int nslots = d->slots > 0 ? d->slots : 1;
         // more than 16 concurrently active streams collapse the throughput (24: -25 %, 32: -40 %, 48: -55 % at 2^17); callers

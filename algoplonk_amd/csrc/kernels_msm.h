@@ -189,19 +189,43 @@ __global__ void __launch_bounds__(256) msm_colscan_kernel(uint32_t* __restrict__
 // (8 bytes); both levels use the same compact numbering, so a partition's pairs occupy the same index range before and after.
 constexpr uint32_t MSM_PART_BUCKETS = 256;
 constexpr uint32_t MSM_PART_MAX = 512;      // partitions per MSM (nb <= 2^17)
+// Every scatter of the two levels happens INSIDE an LDS tile, and whole lines leave the tile (a wave store whose lanes hit 64
+// different lines costs 64 L2 requests however near the lines are: DESIGN section 5).  Intermediate entries are packed words:
+// bits 0..21 the table index j * n_max + i, bits 22..29 the bucket's low 8 bits, bit 31 the sign - which limits the form to
+// W * n_max <= 2^22 (2^17 bases at 16 windows); larger MSMs keep the one-level sort.
+constexpr uint32_t MSM_PART_IDX_BITS = 22;
+constexpr uint32_t MSM_PART_TILE = 24576;   // entries of a partition sorted in LDS (96 KiB); larger (skewed) partitions scatter in HBM
 
 template <class FR, bool SCATTER>
 __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part_kernel(MsmBatchArgs a, MsmWindows win, uint32_t nb, uint32_t n_max, uint32_t G,
-                                                                     uint32_t* __restrict__ pcounts,         // [batch][G][P]   (!SCATTER: out)
+                                                                     uint32_t* __restrict__ pcounts,         // [batch][G][P]   (!SCATTER: out, SCATTER: in)
                                                                      const uint32_t* __restrict__ runstart,  // [batch][G][P]   (SCATTER: in)
-                                                                     uint2* __restrict__ tmp) {
+                                                                     uint32_t* __restrict__ tmp,
+                                                                     uint32_t stage_cap) {                   // SCATTER: entries the LDS stage holds
     wave_priority<APK_PRIO_SORT>();
     using Fr = Fe<FR>;
-    __shared__ uint32_t cur[MSM_PART_MAX];
+    __shared__ uint32_t cur[MSM_PART_MAX], lstart[MSM_PART_MAX + 1];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t* stage = reinterpret_cast<uint32_t*>(smem_raw);
     const uint32_t g = blockIdx.x, b = blockIdx.y;
     const uint32_t P = nb / MSM_PART_BUCKETS;
     const size_t row = ((size_t)b * G + g) * P;
-    for (uint32_t k = threadIdx.x; k < P; k += blockDim.x) cur[k] = SCATTER ? runstart[row + k] : 0u;
+    bool staged = false;
+    if (SCATTER) {
+        // slice-local exclusive prefix of this slice's partition counts (the count pass left them in pcounts)
+        for (uint32_t k = threadIdx.x; k < P; k += blockDim.x) cur[k] = pcounts[row + k];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (uint32_t k = 0; k < P; k++) { lstart[k] = run; run += cur[k]; }
+            lstart[P] = run;
+        }
+        __syncthreads();
+        staged = lstart[P] <= stage_cap;                     // uniform
+        for (uint32_t k = threadIdx.x; k < P; k += blockDim.x) cur[k] = staged ? lstart[k] : runstart[row + k];
+    } else {
+        for (uint32_t k = threadIdx.x; k < P; k += blockDim.x) cur[k] = 0u;
+    }
     __syncthreads();
     const uint32_t len = a.len[b];
     const uint32_t per = (len + G - 1) / G;
@@ -234,7 +258,8 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part_kernel(MsmBatchAr
                     if (!SCATTER) atomicAdd(&cur[k / MSM_PART_BUCKETS], 1u);
                     else {
                         const uint32_t pos = atomicAdd(&cur[k / MSM_PART_BUCKETS], 1u);
-                        tmp[pos] = make_uint2(((uint32_t)j * n_max + base_idx) | (neg << 31), k);
+                        const uint32_t e = ((uint32_t)j * n_max + base_idx) | ((k % MSM_PART_BUCKETS) << MSM_PART_IDX_BITS) | (neg << 31);
+                        if (staged) stage[pos] = e; else tmp[pos] = e;
                     }
                 }
                 j++;
@@ -244,6 +269,18 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part_kernel(MsmBatchAr
     if (!SCATTER) {
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < P; k += blockDim.x) pcounts[row + k] = cur[k];
+    } else if (staged) {
+        // the stage holds the slice's entries in partition order: copy each partition's run to its place, neighbours together
+        __syncthreads();
+        const uint32_t total = lstart[P];
+        for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
+            uint32_t lo_p = 0, hi_p = P;                      // last p with lstart[p] <= idx
+            while (hi_p - lo_p > 1) {
+                const uint32_t mid = (lo_p + hi_p) >> 1;
+                if (lstart[mid] <= idx) lo_p = mid; else hi_p = mid;
+            }
+            tmp[runstart[row + lo_p] + (idx - lstart[lo_p])] = stage[idx];
+        }
     }
 }
 
@@ -289,19 +326,23 @@ __global__ void __launch_bounds__(1024) msm_part_scan_kernel(const uint32_t* __r
     }
 }
 
-// grid (P, batch): counting sort of one partition's pairs by bucket; hist[b*nb + k] = entries of bucket k
+// grid (P, batch): counting sort of one partition's entries by bucket inside an LDS tile, whole lines out;
+// hist[b*nb + k] = entries of bucket k
 template <int DUMMY>
-__global__ void __launch_bounds__(512) msm_part_sort_kernel(const uint2* __restrict__ tmp, const uint32_t* __restrict__ runstart,
+__global__ void __launch_bounds__(512) msm_part_sort_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ runstart,
                                                            const uint32_t* __restrict__ ptot, uint32_t G, uint32_t P, uint32_t nb,
                                                            uint32_t* __restrict__ hist, uint32_t* __restrict__ sorted) {
     wave_priority<APK_PRIO_SORT>();
     __shared__ uint32_t cnt[MSM_PART_BUCKETS], cur[MSM_PART_BUCKETS];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t* tile = reinterpret_cast<uint32_t*>(smem_raw);
     const uint32_t p = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
     const uint32_t first = runstart[(size_t)b * G * P + p];          // slice 0's run opens the partition
     const uint32_t n = ptot[b * P + p];
+    constexpr uint32_t KEEP = ((1u << MSM_PART_IDX_BITS) - 1u) | 0x80000000u;
     if (t < MSM_PART_BUCKETS) cnt[t] = 0u;
     __syncthreads();
-    for (uint32_t i = t; i < n; i += blockDim.x) atomicAdd(&cnt[tmp[first + i].y % MSM_PART_BUCKETS], 1u);
+    for (uint32_t i = t; i < n; i += blockDim.x) atomicAdd(&cnt[(tmp[first + i] >> MSM_PART_IDX_BITS) % MSM_PART_BUCKETS], 1u);
     __syncthreads();
     uint32_t mine = 0;
     if (t < MSM_PART_BUCKETS) { mine = cnt[t]; cur[t] = mine; }
@@ -313,14 +354,20 @@ __global__ void __launch_bounds__(512) msm_part_sort_kernel(const uint2* __restr
         if (t < MSM_PART_BUCKETS) cur[t] += v;
         __syncthreads();
     }
+    const bool in_lds = n <= MSM_PART_TILE;                          // uniform
     if (t < MSM_PART_BUCKETS) {
         hist[(size_t)b * nb + p * MSM_PART_BUCKETS + t] = mine;
-        cur[t] = first + cur[t] - mine;                              // exclusive prefix inside the partition
+        cur[t] = (in_lds ? 0u : first) + cur[t] - mine;              // exclusive prefix inside the partition
     }
     __syncthreads();
     for (uint32_t i = t; i < n; i += blockDim.x) {
-        const uint2 e = tmp[first + i];
-        sorted[atomicAdd(&cur[e.y % MSM_PART_BUCKETS], 1u)] = e.x;
+        const uint32_t e = tmp[first + i];
+        const uint32_t pos = atomicAdd(&cur[(e >> MSM_PART_IDX_BITS) % MSM_PART_BUCKETS], 1u);
+        if (in_lds) tile[pos] = e & KEEP; else sorted[pos] = e & KEEP;
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (uint32_t i = t; i < n; i += blockDim.x) sorted[first + i] = tile[i];
     }
 }
 
