@@ -435,7 +435,7 @@ class CurveBackend : public Backend {
         static const int sort2_env = env_int("APK_MSM_SORT2", -1, -1, 1);
         const bool sort2_want = sort2_env >= 0 ? sort2_env != 0 : (lean && T.n_bases >= 65536u);
         const uint32_t P = NB_ / MSM_PART_BUCKETS;
-        const bool sort2 = sort2_want && NB_ >= 4 * MSM_PART_BUCKETS && NB_ < MSM_PACKED_NB && P <= MSM_PART_MAX && s.sort_tmp.p &&
+        const bool sort2 = sort2_want && NB_ >= 4 * MSM_PART_BUCKETS && P <= MSM_PART_MAX && s.sort_tmp.p &&
                            (uint64_t)T.n_bases * W_ <= (1ull << MSM_PART_IDX_BITS) &&
                            (uint64_t)a.batch * G * P * 2 + (uint64_t)a.batch * P <= (uint64_t)total_buckets * msm_G_max_;
         uint32_t* pcounts = ptr<uint32_t>(s.counts);
@@ -693,7 +693,7 @@ class CurveBackend : public Backend {
         CHK(s.full_off.alloc((size_t)(tb + 1) * 4)); CHK(s.rem_rank.alloc((size_t)(tb + 1) * 4)); CHK(s.rem_list.alloc((size_t)(tb + 1) * 4));
         CHK(s.counts.alloc((size_t)tb * msm_G_max_ * 4));
         CHK(s.sorted.alloc(entries * 4));
-        if (env_int("APK_MSM_SORT2", -1, -1, 1) != 0 && NB_ >= 4 * MSM_PART_BUCKETS && NB_ < MSM_PACKED_NB &&
+        if (env_int("APK_MSM_SORT2", -1, -1, 1) != 0 && NB_ >= 4 * MSM_PART_BUCKETS &&
             (uint64_t)msm_bases_ * W_ <= (1ull << MSM_PART_IDX_BITS) && (msm_bases_ >= 65536u || env_int("APK_MSM_SORT2", -1, -1, 1) == 1))
             CHK(s.sort_tmp.alloc(entries * 4));   // two-level sort: packed entries between the levels
         CHK(s.partial.alloc((entries / MSM_UNIT_MIN + tb) * sizeof(PtU)));
