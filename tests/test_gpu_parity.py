@@ -683,3 +683,48 @@ def test_run_time_variants_give_the_same_bytes(gpu, cname, log_n, window, varian
     want = sha({})
     for v in variants:
         assert sha(v) == want, v
+
+
+_SKEWED_SORT2_SCRIPT = r"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+from algoplonk_amd import setup
+from algoplonk_amd._lib import lib, check
+from oracle import plonk as oplonk
+from oracle.prng import SplitMix64, tau_from_seed
+from helpers import CURVES
+cv, ov = CURVES["bn254"]
+n = 1 << 16
+tau = tau_from_seed(3, cv.r)
+srs = setup.unsafe_srs(cv, n, tau, device=0)
+ctx = C.c_void_p()
+check(lib.apk_msm_ctx_create(cv.abi, 0, srs.g1, n + 3, 0, C.byref(ctx)))
+out = C.create_string_buffer(64)
+g = SplitMix64(1)
+uniform = [g.fr(cv.r) for _ in range(n)]
+cases = {"uniform": uniform, "ones": [1] * n, "minus_one": [cv.r - 1] * n, "zeros_and_uniform": [0 if i % 8 else uniform[i] for i in range(n)],
+         "two_values": [uniform[i & 1] for i in range(n)]}
+d = C.c_void_p()
+check(lib.apk_device_alloc(ctx, 32 * n, C.byref(d)))
+for name, sc in cases.items():
+    buf = cv.fr_vector(sc)
+    check(lib.apk_device_upload(ctx, d, buf, len(buf)))
+    check(lib.apk_msm_g1_device(ctx, 0, d, n, out))
+    assert cv.g1_from_bytes(out.raw) == ov.mul(ov.g1, oplonk.poly_eval(sc, tau, cv.r)), name
+print("SKEWED_OK")
+"""
+
+
+def test_two_level_sort_with_skewed_scalars(gpu):
+    """The two-level sort's overflow paths: all-equal scalars put a whole MSM's entries into W buckets, so the partitions that
+    hold them are far larger than the LDS tile of the second level (it then scatters in HBM) and every other partition is
+    empty.  Forced on (it is only picked under load) in a process of its own, with the lean tail forms; checked against the
+    known-tau shortcut like the one-level test above."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.update({"APK_MSM_SORT2": "1", "APK_MSM_LEAN_TAIL": "1"})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    out = subprocess.run([sys.executable, "-c", _SKEWED_SORT2_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "SKEWED_OK" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
