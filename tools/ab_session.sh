@@ -1,4 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-echo "== window 16 vs 17 with the two-level sort: bn254 2^17 (value, latency, acc launch, saturated MSM)"
-bash tools/ab_env.sh 2 "--steps 40" "APK_MSM_WINDOW=16" "APK_MSM_WINDOW=17" "APK_MSM_WINDOW=17 APK_MSM_SORT2=1"
-python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "window_sizes" 2>&1 | tail -2
+echo "== one-level sort"; APK_MSM_SORT2=0 APK_LIB=$PWD/algoplonk_amd/libapk_knockout.so timeout 300 python tools/knockout.py 17 16 30 2>&1 | tail -13
+echo "== two-level sort (skip 1/32/64 have no effect on it: the sort is not skipped)"; APK_MSM_SORT2=1 APK_LIB=$PWD/algoplonk_amd/libapk_knockout.so timeout 300 python tools/knockout.py 17 16 30 2>&1 | grep -E "skip +(0|2|28|125) "
