@@ -1,3 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-echo "== one-level sort"; APK_MSM_SORT2=0 APK_LIB=$PWD/algoplonk_amd/libapk_knockout.so timeout 300 python tools/knockout.py 17 16 30 2>&1 | tail -13
-echo "== two-level sort (skip 1/32/64 have no effect on it: the sort is not skipped)"; APK_MSM_SORT2=1 APK_LIB=$PWD/algoplonk_amd/libapk_knockout.so timeout 300 python tools/knockout.py 17 16 30 2>&1 | grep -E "skip +(0|2|28|125) "
+echo "== NTT tile / stages under load: bn254 2^17 (value, latency, acc launch, saturated MSM)"
+bash tools/ab_env.sh 2 "--steps 40" "APK_NTT_TILE_LOG=9 APK_NTT_STAGES=7" "APK_NTT_TILE_LOG=10 APK_NTT_STAGES=7" "APK_NTT_TILE_LOG=10 APK_NTT_STAGES=9" "APK_NTT_TILE_LOG=11 APK_NTT_STAGES=10"
