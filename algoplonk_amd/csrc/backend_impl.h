@@ -428,12 +428,13 @@ class CurveBackend : public Backend {
         const bool lean = lean_env >= 0 ? lean_env != 0 : others_busy;
         // two-level sort (kernels_msm.h): partitions of 256 buckets, then a counting sort per partition - the stores of both
         // levels are neighbours of each other instead of 2 M isolated 4-byte writes per MSM
-        // Measured (round 3, same box, every scatter of both levels inside an LDS tile): BN254 2^17 463.5 -> 485.0 proofs/s (+4.6 %);
-        // a lone proof 3.54 -> 3.61 ms (one more launch per batch) and BLS12-381 2^14 1 183 -> 1 154: so it is taken when other
-        // proofs are in flight and the MSM has >= 2^16 bases (APK_MSM_SORT2: -1 that rule, 0 never, 1 whenever it applies).
-        // A first version with the second level's stores still scattered (inside 64 KiB windows) gained nothing: DESIGN section 5.
+        // Measured (round 3, same box, every scatter of both levels inside an LDS tile, a wave per run in the copy-out): BN254 2^17
+        // 468 -> 497 proofs/s (+6 %) and a lone proof 3.57 -> 3.53 ms; 2^16 847 -> 872; 2^15 flat (+1.3 % latency); BN254 2^14
+        // 1 746 -> 1 678 and BLS12-381 2^14 1 200 -> 1 140: taken from 2^16 bases up (APK_MSM_SORT2: -1 that rule, 0 never, 1
+        // whenever it applies).  A first version with the second level's stores still scattered (inside 64 KiB windows) gained
+        // nothing: DESIGN section 5.
         static const int sort2_env = env_int("APK_MSM_SORT2", -1, -1, 1);
-        const bool sort2_want = sort2_env >= 0 ? sort2_env != 0 : (lean && T.n_bases >= 65536u);
+        const bool sort2_want = sort2_env >= 0 ? sort2_env != 0 : T.n_bases >= 65536u;
         const uint32_t P = NB_ / MSM_PART_BUCKETS;
         const bool sort2 = sort2_want && NB_ >= 4 * MSM_PART_BUCKETS && P <= MSM_PART_MAX && s.sort_tmp.p &&
                            (uint64_t)T.n_bases * W_ <= (1ull << MSM_PART_IDX_BITS) &&
@@ -453,7 +454,7 @@ class CurveBackend : public Backend {
             msm_part_kernel<FRP, true><<<gd, dth, (size_t)stage_cap * 4, st>>>(a, win_, NB_, T.n_bases, G, pcounts, runstart, ptr<uint32_t>(s.sort_tmp),
                                                                                stage_cap);
             KCHK();
-            msm_part_sort_kernel<0><<<dim3(P, a.batch), 512, (size_t)MSM_PART_TILE * 4, st>>>(ptr<uint32_t>(s.sort_tmp), runstart, ptot, G, P, NB_,
+            msm_part_sort_kernel<0><<<dim3(P, a.batch), 1024, (size_t)MSM_PART_TILE * 4, st>>>(ptr<uint32_t>(s.sort_tmp), runstart, ptot, G, P, NB_,
                                                                                                ptr<uint32_t>(s.hist), ptr<uint32_t>(s.sorted));
             KCHK();
         } else if (APK_PHASE(1)) {

@@ -272,14 +272,11 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part_kernel(MsmBatchAr
     } else if (staged) {
         // the stage holds the slice's entries in partition order: copy each partition's run to its place, neighbours together
         __syncthreads();
-        const uint32_t total = lstart[P];
-        for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
-            uint32_t lo_p = 0, hi_p = P;                      // last p with lstart[p] <= idx
-            while (hi_p - lo_p > 1) {
-                const uint32_t mid = (lo_p + hi_p) >> 1;
-                if (lstart[mid] <= idx) lo_p = mid; else hi_p = mid;
-            }
-            tmp[runstart[row + lo_p] + (idx - lstart[lo_p])] = stage[idx];
+        const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, waves = blockDim.x >> 6;
+        for (uint32_t pp = wave; pp < P; pp += waves) {       // a wave per partition run: its lanes write neighbours
+            const uint32_t from = lstart[pp], cnt = lstart[pp + 1] - from;
+            uint32_t* dst = tmp + runstart[row + pp];
+            for (uint32_t l = lane; l < cnt; l += 64u) dst[l] = stage[from + l];
         }
     }
 }
@@ -329,7 +326,7 @@ __global__ void __launch_bounds__(1024) msm_part_scan_kernel(const uint32_t* __r
 // grid (P, batch): counting sort of one partition's entries by bucket inside an LDS tile, whole lines out;
 // hist[b*nb + k] = entries of bucket k
 template <int DUMMY>
-__global__ void __launch_bounds__(512) msm_part_sort_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ runstart,
+__global__ void __launch_bounds__(1024) msm_part_sort_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ runstart,
                                                            const uint32_t* __restrict__ ptot, uint32_t G, uint32_t P, uint32_t nb,
                                                            uint32_t* __restrict__ hist, uint32_t* __restrict__ sorted) {
     wave_priority<APK_PRIO_SORT>();

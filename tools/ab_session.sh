@@ -1,3 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-echo "== NTT tile / stages under load: bn254 2^17 (value, latency, acc launch, saturated MSM)"
-bash tools/ab_env.sh 2 "--steps 40" "APK_NTT_TILE_LOG=9 APK_NTT_STAGES=7" "APK_NTT_TILE_LOG=10 APK_NTT_STAGES=7" "APK_NTT_TILE_LOG=10 APK_NTT_STAGES=9" "APK_NTT_TILE_LOG=11 APK_NTT_STAGES=10"
+echo "== bn254 2^16"; bash tools/ab_env.sh 1 "--steps 40 --log-n 16" "APK_MSM_SORT2=0" "APK_MSM_SORT2=1"
+echo "== bn254 2^15"; bash tools/ab_env.sh 1 "--steps 40 --log-n 15" "APK_MSM_SORT2=0" "APK_MSM_SORT2=1"
+echo "== bls 2^14"; bash tools/ab_env.sh 2 "--steps 40 --curve bls12_381 --log-n 14" "APK_MSM_SORT2=0" "APK_MSM_SORT2=1"
+echo "== bn254 2^14"; bash tools/ab_env.sh 1 "--steps 40 --log-n 14" "APK_MSM_SORT2=0" "APK_MSM_SORT2=1"
