@@ -456,8 +456,13 @@ class CurveBackend : public Backend {
             msm_part_kernel<FRP, true><<<gd, dth, (size_t)stage_cap * 4, st>>>(a, win_, NB_, T.n_bases, G, pcounts, runstart, ptr<uint32_t>(s.sort_tmp),
                                                                                stage_cap);
             KCHK();
-            msm_part_sort_kernel<0><<<dim3(P, a.batch), 1024, (size_t)MSM_PART_TILE * 4, st>>>(ptr<uint32_t>(s.sort_tmp), runstart, ptot, G, P, NB_,
-                                                                                               ptr<uint32_t>(s.hist), ptr<uint32_t>(s.sorted));
+            // tile of the second level: the mean partition + 15 % (uniform scalars stay within 2 %); at 2^17 that is 74 KiB, so two
+            // workgroups share a CU and the 384 partitions of a three-MSM batch run in one round instead of two.  Partitions
+            // above it (skewed scalars) scatter in HBM.
+            uint32_t tile_cap = (uint32_t)(entries / ((uint64_t)a.batch * P)) + (uint32_t)(entries / ((uint64_t)a.batch * P)) / 7u + 256u;
+            if (tile_cap > MSM_PART_TILE) tile_cap = MSM_PART_TILE;
+            msm_part_sort_kernel<0><<<dim3(P, a.batch), 1024, (size_t)tile_cap * 4, st>>>(ptr<uint32_t>(s.sort_tmp), runstart, ptot, G, P, NB_,
+                                                                                          ptr<uint32_t>(s.hist), ptr<uint32_t>(s.sorted), tile_cap);
             KCHK();
         } else if (APK_PHASE(1)) {
         msm_digits_kernel<FRP, false><<<gd, dth, lds, st>>>(a, win_, NB_, T.n_bases, G, ptr<uint32_t>(s.counts), nullptr, nullptr);

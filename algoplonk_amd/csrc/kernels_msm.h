@@ -353,7 +353,8 @@ __global__ void __launch_bounds__(1024) msm_part_scan_kernel(const uint32_t* __r
 template <int DUMMY>
 __global__ void __launch_bounds__(1024) msm_part_sort_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ runstart,
                                                            const uint32_t* __restrict__ ptot, uint32_t G, uint32_t P, uint32_t nb,
-                                                           uint32_t* __restrict__ hist, uint32_t* __restrict__ sorted) {
+                                                           uint32_t* __restrict__ hist, uint32_t* __restrict__ sorted,
+                                                           uint32_t tile_cap) {              // entries the LDS tile of this launch holds
     wave_priority<APK_PRIO_SORT>();
     __shared__ uint32_t cnt[MSM_PART_BUCKETS], cur[MSM_PART_BUCKETS];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -376,7 +377,7 @@ __global__ void __launch_bounds__(1024) msm_part_sort_kernel(const uint32_t* __r
         if (t < MSM_PART_BUCKETS) cur[t] += v;
         __syncthreads();
     }
-    const bool in_lds = n <= MSM_PART_TILE;                          // uniform
+    const bool in_lds = n <= tile_cap;                               // uniform
     if (t < MSM_PART_BUCKETS) {
         hist[(size_t)b * nb + p * MSM_PART_BUCKETS + t] = mine;
         cur[t] = (in_lds ? 0u : first) + cur[t] - mine;              // exclusive prefix inside the partition
