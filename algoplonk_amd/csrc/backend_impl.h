@@ -434,9 +434,9 @@ class CurveBackend : public Backend {
         // whenever it applies).  A first version with the second level's stores still scattered (inside 64 KiB windows) gained
         // nothing: DESIGN section 5.
         static const int sort2_env = env_int("APK_MSM_SORT2", -1, -1, 1);
-        // (a lone single MSM keeps the one-level sort: 0.47 against 0.49 ms at 2^17 - four launches instead of three and too few
-        // workgroups in the second level to hide them)
-        const bool sort2_want = sort2_env >= 0 ? sort2_env != 0 : (T.n_bases >= 65536u && (a.batch >= 2 || lean));
+        // (a lone single MSM was 0.49 against 0.47 ms with the first version - and 0.468 against 0.473 once the partition scan
+        // ran eight lanes per pair and the second-level tile let two partitions share a CU: no exception for it any more)
+        const bool sort2_want = sort2_env >= 0 ? sort2_env != 0 : T.n_bases >= 65536u;
         const uint32_t P = NB_ / MSM_PART_BUCKETS;
         const bool sort2 = sort2_want && NB_ >= 4 * MSM_PART_BUCKETS && P <= MSM_PART_MAX && s.sort_tmp.p &&
                            (uint64_t)T.n_bases * W_ <= (1ull << MSM_PART_IDX_BITS) &&

@@ -1,4 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python -m pytest tests -x -q -m gpu 2>&1 | tail -2
-echo "== previous / new second-level tile (value, latency, acc, sat MSM, ntt)"
-bash tools/ab_libs.sh 2 "--steps 30" algoplonk_amd/libapk_prev.so algoplonk_amd/libapk.so
+echo "== default rule / two-level sort for every batch size (value, latency, acc, sat MSM, then msm_ms)"
+for i in 1 2; do for E in "APK_MSM_SORT2=-1" "APK_MSM_SORT2=1"; do
+  v=$(env $E timeout 300 python bench.py --no-pmc --no-cpu-baseline --steps 12 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['proof_latency_ms'], d['msm_ms'], d['msm_mscalar_per_s_saturated'])")
+  echo "[$E] $v"; done; done
