@@ -33,7 +33,7 @@ SYMBOLS = [
     "apk_ctx_set_wire_hook", "apk_coset_ntt_device",
     "apk_comm_create", "apk_comm_destroy", "apk_comm_rank", "apk_comm_world", "apk_comm_barrier", "apk_comm_max_f64", "apk_comm_bind",
     "apk_comm_transport", "apk_msm_g1_sharded", "apk_comm_split_begin", "apk_comm_split_end", "apk_comm_serve", "apk_comm_set_compute",
-    "apk_comm_commit", "apk_comm_wires",
+    "apk_comm_commit", "apk_comm_wires", "apk_comm_rccl_ranks", "apk_comm_rccl_selftest",
 ]
 
 
@@ -174,6 +174,8 @@ def _load() -> C.CDLL:
     lib.apk_comm_max_f64.argtypes = [vp, C.POINTER(C.c_double)]
     lib.apk_comm_bind.argtypes = [vp, vp]
     lib.apk_comm_transport.argtypes = [vp]; lib.apk_comm_transport.restype = C.c_char_p
+    lib.apk_comm_rccl_ranks.argtypes = [vp]
+    lib.apk_comm_rccl_selftest.argtypes = [i32, C.POINTER(i32)]
     lib.apk_msm_g1_sharded.argtypes = [vp, vp, u64, vp]
     lib.apk_comm_split_begin.argtypes = [vp]
     lib.apk_comm_split_end.argtypes = [vp]

@@ -16,6 +16,7 @@
 #include <errno.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
 #include <string.h>
 #include <sys/socket.h>
 #include <sys/time.h>
@@ -82,6 +83,24 @@ static int recv_all(int fd, void* buf, size_t n) {
     }
     return APK_OK;
 }
+// An idle worker waits for the leader's next step as long as it takes (a proving service, host-side witness work): the failure
+// timeout (APK_COMM_TIMEOUT_S, SO_RCVTIMEO) applies inside a step only, once its header has started to arrive.
+static int wait_readable(int fd) {
+    for (;;) {
+        struct pollfd pf = {fd, POLLIN, 0};
+        const int r = ::poll(&pf, 1, -1);
+        if (r > 0) return APK_OK;                       // data, or a hang-up that the following recv reports
+        if (r < 0 && errno != EINTR) { set_error("comm: poll failed: %s", strerror(errno)); return APK_ERR_STATE; }
+    }
+}
+// FNV-1a of APK_COMM_TOKEN (0 when unset): a shared secret of one launch, exchanged in the hello so that a stray connection to
+// rank 0's port is refused (algoplonk_amd/parallel.py draws it at random and hands it to the ranks through the rendezvous file)
+static uint64_t launch_token() {
+    const char* t = getenv("APK_COMM_TOKEN");
+    uint64_t h = 0;
+    if (t && *t) { h = 1469598103934665603ull; for (; *t; t++) { h ^= (uint8_t)*t; h *= 1099511628211ull; } if (!h) h = 1; }
+    return h;
+}
 static void tune(int fd, int timeout_s) {
     int one = 1;
     setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
@@ -99,6 +118,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
@@ -112,6 +132,7 @@ struct Rccl {
         if (!h) return false;
 #define SYM(f, name) f = reinterpret_cast<decltype(f)>(dlsym(h, name)); if (!f) { dlclose(h); h = nullptr; return false; }
         SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+        SYM(CommCount, "ncclCommCount")
         SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(AllGather, "ncclAllGather") SYM(GroupStart, "ncclGroupStart")
         SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
@@ -125,6 +146,7 @@ static Rccl g_rccl;
 
 enum : int32_t { OP_COMMIT = 1, OP_WIRES = 2, OP_STOP = 3 };
 struct Header { int32_t op, basis; uint32_t count; uint32_t lens[4]; };
+struct Hello { int32_t rank; int32_t pad; uint64_t token; };
 
 }  // namespace apk
 
@@ -157,6 +179,9 @@ struct apk_comm {
     void* d_wire_in = nullptr; size_t wire_in_cap = 0;   // workers: a canonical polynomial
     void* d_wire_out = nullptr; size_t wire_out_cap = 0; // workers: its 4n evaluations
     std::vector<uint8_t> h_stage;
+    void* d_ag = nullptr; size_t ag_cap = 0;             // RCCL: device staging of the partial-sum all-gather (hipMalloc on `device`)
+    bool step_synced = false;       // the current step's status reached every rank of it (serve() keeps serving) - or the transport
+                                    // broke mid-step and the stream to the leader is no longer aligned (serve() leaves)
     bool split_on = false;
     uint64_t steps = 0;
     std::mutex step_mu;             // leader: one step at a time (a context with several slots proves concurrently, and every
@@ -284,6 +309,29 @@ static int ctl_allgather(apk_comm* c, const void* mine, void* all, size_t n) {
     return recv_all(c->peer[0], all, n * c->world);
 }
 
+// The ONE exchange of a sharded MSM / a dealt commitment batch: `n` bytes (status word + 64/96-byte partial sums) from every
+// rank to every rank.  north_star: "RCCL-over-xGMI ... for the final bucket-sum of a single MSM" - ncclAllGather on the
+// communicator's stream when RCCL is the data plane (a numeric all-reduce cannot add curve points: the ranks add the gathered
+// points themselves, apk_g1_sum); the TCP star otherwise (CPU tier, ranks sharing a GPU, APK_COMM_RCCL=0).
+static int sums_allgather(apk_comm* c, const void* mine, void* all, size_t n) {
+    if (!c->rccl || c->world == 1) return ctl_allgather(c, mine, all, n);
+    HCHK(hipSetDevice(c->device));
+    const size_t need = n * ((size_t)c->world + 1);
+    if (c->ag_cap < need) {
+        if (c->d_ag) (void)hipFree(c->d_ag);
+        c->d_ag = nullptr; c->ag_cap = 0;
+        HCHK(hipMalloc(&c->d_ag, need * 2 + 4096));
+        c->ag_cap = need * 2 + 4096;
+    }
+    uint8_t* d_all = (uint8_t*)c->d_ag;
+    uint8_t* d_mine = d_all + n * (size_t)c->world;
+    HCHK(hipMemcpyAsync(d_mine, mine, n, hipMemcpyHostToDevice, c->stream));
+    NCHK(g_rccl.AllGather(d_mine, d_all, n, ncclUint8, c->nccl, c->stream));
+    HCHK(hipMemcpyAsync(all, d_all, n * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
+    HCHK(hipStreamSynchronize(c->stream));
+    return APK_OK;
+}
+
 // ---- data-plane: scatter of per-rank chunks held by rank 0; peer copies between rank 0 and one worker -------------------------
 // d_all (rank 0): world x chunk bytes, rank r's chunk at r * chunk; d_mine: chunk bytes on every rank (rank 0: unused, its share
 // is read in place).
@@ -366,6 +414,7 @@ static int data_p2p(apk_comm* c, int w, bool to_worker, void* d_buf, size_t byte
 static int commit_round(apk_comm* c, int basis, uint32_t count, const uint32_t* lens, const void* const* d_scalars, void* out_points) {
     const size_t nb = c->cp.g1_bytes;
     uint64_t total = 0;
+    c->step_synced = false;
     for (uint32_t i = 0; i < count; i++) total += lens[i];
     const size_t chunk = (size_t)((total + c->world - 1) / c->world) * APK_FR_BYTES;
     // rank 0 reads its own share in place; the workers' slices are packed into the staging buffer and scattered
@@ -403,7 +452,8 @@ static int commit_round(apk_comm* c, int basis, uint32_t count, const uint32_t* 
         else err = apk_last_error();
     }
     memcpy(mine.data(), &status, 4);
-    CHK(ctl_allgather(c, mine.data(), all.data(), rec));
+    CHK(sums_allgather(c, mine.data(), all.data(), rec));
+    c->step_synced = true;                     // from here on every rank knows how the step ended
     for (int r = 0; r < c->world; r++) {
         int32_t st;
         memcpy(&st, all.data() + (size_t)r * rec, 4);
@@ -420,25 +470,33 @@ static int commit_round(apk_comm* c, int basis, uint32_t count, const uint32_t* 
 }
 
 // The 4n-coset evaluations of `count` canonical polynomials, polynomial i on rank i mod world.
+// The wires go out in GROUPS of `world` (one per rank): the leader sends a group's dealt polynomials, transforms its own, collects
+// the group's results, then turns to the next group - so a worker that owns two wires (world = 2, count = 4: wires 1 and 3) has
+// answered the first before the second arrives.  (Sending every dealt wire before collecting any - the first version - crossed
+// the worker's status word with the leader's next payload on the IPC plane and deadlocked Send against Send on RCCL.)
 static int wires_round(apk_comm* c, uint32_t count, const uint32_t* lens, const void* const* d_can, void* const* d_ev) {
     const size_t ev_bytes = (size_t)4 * c->cp.n * APK_FR_BYTES;
+    const uint32_t W = (uint32_t)c->world;
     int32_t status = APK_OK;
+    c->step_synced = false;
     if (c->rank == 0) {
-        // send the dealt polynomials first (their owners start while this rank transforms its own), then collect
-        for (uint32_t i = 0; i < count; i++)
-            if (i % c->world) CHK(data_p2p(c, i % c->world, true, const_cast<void*>(d_can[i]), (size_t)lens[i] * APK_FR_BYTES));
-        for (uint32_t i = 0; i < count; i++)
-            if (i % c->world == 0 && status == APK_OK) status = c->cp.coset_ntt(CP_USER(c, coset_ntt), d_can[i], lens[i], d_ev[i]);
-        for (uint32_t i = 0; i < count; i++)
-            if (i % c->world) {
-                int32_t st = APK_OK;
-                CHK(recv_all(c->peer[i % c->world], &st, 4));
-                if (st != APK_OK) { if (status == APK_OK) { status = st; set_error("comm: rank %u failed the coset evaluation of wire %u (code %d)", i % c->world, i, st); } continue; }
-                CHK(data_p2p(c, i % c->world, false, d_ev[i], ev_bytes));
-            }
+        for (uint32_t base = 0; base < count; base += W) {
+            const uint32_t end = base + W < count ? base + W : count;
+            for (uint32_t i = base; i < end; i++)
+                if (i % W) CHK(data_p2p(c, i % W, true, const_cast<void*>(d_can[i]), (size_t)lens[i] * APK_FR_BYTES));
+            for (uint32_t i = base; i < end; i++)
+                if (i % W == 0 && status == APK_OK) status = c->cp.coset_ntt(CP_USER(c, coset_ntt), d_can[i], lens[i], d_ev[i]);
+            for (uint32_t i = base; i < end; i++)
+                if (i % W) {
+                    int32_t st = APK_OK;
+                    CHK(recv_all(c->peer[i % W], &st, 4));
+                    if (st != APK_OK) { if (status == APK_OK) { status = st; set_error("comm: rank %u failed the coset evaluation of wire %u (code %d)", i % W, i, st); } continue; }
+                    CHK(data_p2p(c, i % W, false, d_ev[i], ev_bytes));
+                }
+        }
     } else {
         for (uint32_t i = 0; i < count; i++)
-            if ((int)(i % c->world) == c->rank) {
+            if ((int)(i % W) == c->rank) {
                 CHK(ensure(c, &c->d_wire_in, &c->wire_in_cap, (size_t)lens[i] * APK_FR_BYTES));
                 CHK(ensure(c, &c->d_wire_out, &c->wire_out_cap, ev_bytes));
                 CHK(data_p2p(c, c->rank, true, c->d_wire_in, (size_t)lens[i] * APK_FR_BYTES));
@@ -448,6 +506,7 @@ static int wires_round(apk_comm* c, uint32_t count, const uint32_t* lens, const 
                 else status = st;
             }
     }
+    c->step_synced = true;                     // every transfer of the step completed: a failed transform was reported to the leader
     c->steps++;
     return status;
 }
@@ -487,9 +546,11 @@ int apk_comm_create(int rank, int world, const char* addr, int port, apk_comm** 
             const int fd = accept(c->listen_fd, nullptr, nullptr);
             if (fd < 0) { set_error("comm: rank 0 waited %d s for %d more rank(s): %s", c->timeout_s, world - i, strerror(errno)); apk_comm_destroy(c); return APK_ERR_STATE; }
             tune(fd, c->timeout_s);
-            int32_t r = -1;
-            if (recv_all(fd, &r, 4) != APK_OK || r <= 0 || r >= world || c->peer[r] != -1) { close(fd); set_error("comm: bad hello from a peer"); apk_comm_destroy(c); return APK_ERR_STATE; }
-            c->peer[r] = fd;
+            Hello hi{};
+            if (recv_all(fd, &hi, sizeof hi) != APK_OK || hi.rank <= 0 || hi.rank >= world || c->peer[hi.rank] != -1 || hi.token != launch_token()) {
+                close(fd); set_error("comm: bad hello from a peer (rank out of range or taken, or another launch's APK_COMM_TOKEN)"); apk_comm_destroy(c); return APK_ERR_STATE;
+            }
+            c->peer[hi.rank] = fd;
         }
     } else {
         c->peer.assign(1, -1);
@@ -503,8 +564,9 @@ int apk_comm_create(int rank, int world, const char* addr, int port, apk_comm** 
             usleep(50 * 1000); waited += 0.05;
         }
         tune(c->peer[0], c->timeout_s);
-        int32_t r = rank;
-        if (send_all(c->peer[0], &r, 4) != APK_OK) { apk_comm_destroy(c); return APK_ERR_STATE; }
+        Hello hi{};
+        hi.rank = rank; hi.token = launch_token();
+        if (send_all(c->peer[0], &hi, sizeof hi) != APK_OK) { apk_comm_destroy(c); return APK_ERR_STATE; }
     }
     *out = c;
     return APK_OK;
@@ -514,6 +576,7 @@ void apk_comm_destroy(apk_comm* c) {
     if (!c) return;
     if (c->split_on && c->rank == 0) (void)apk_comm_split_end(c);
     release_buffers(c);
+    if (c->d_ag) { (void)hipSetDevice(c->device); (void)hipFree(c->d_ag); }
     if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (int fd : c->peer) if (fd >= 0) close(fd);
@@ -569,13 +632,40 @@ int apk_comm_bind(apk_comm* c, apk_ctx* ctx) {
         for (int q = 0; q < r; q++) if (devs[q] == devs[r]) all_can = false;   // RCCL refuses two ranks on one device (single node)
     }
     if (all_can && !c->nccl) {
+        // Nothing here may strand a peer: a rank that fails a step still takes part in the agreement that follows it, and one
+        // refusal sends every rank to the next tier (IPC, then the TCP star) instead of failing the bind.
         ncclUniqueId id{};
-        if (c->rank == 0) NCHK(g_rccl.GetUniqueId(&id));
-        CHK(ctl_bcast(c, &id, sizeof id));
-        c->device = dev;
-        HCHK(hipSetDevice(dev));
-        HCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        NCHK(g_rccl.CommInitRank(&c->nccl, c->world, id, c->rank));
+        int32_t ok = 1;
+        if (c->rank == 0 && g_rccl.GetUniqueId(&id) != ncclSuccess) ok = 0;
+        CHK(ctl_bcast(c, &ok, 4));
+        if (ok) {
+            CHK(ctl_bcast(c, &id, sizeof id));
+            c->device = dev;
+            if (hipSetDevice(dev) != hipSuccess || (!c->stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)) { (void)hipGetLastError(); ok = 0; }
+            std::vector<int32_t> oks(c->world);
+            CHK(ctl_allgather(c, &ok, oks.data(), 4));
+            for (int32_t v : oks) ok = ok && v;
+            if (ok) {
+                const ncclResult_t r = g_rccl.CommInitRank(&c->nccl, c->world, id, c->rank);
+                ok = r == ncclSuccess && c->nccl ? 1 : 0;
+                if (!ok) set_error("comm: ncclCommInitRank failed on rank %d: %s", c->rank, g_rccl.GetErrorString(r));
+                CHK(ctl_allgather(c, &ok, oks.data(), 4));
+                for (int32_t v : oks) ok = ok && v;
+            }
+            if (ok) {
+                // first use before first need: the partial-sum exchange itself, on rank numbers
+                c->rccl = true;
+                std::vector<int32_t> ids(c->world, -1);
+                const int32_t me = c->rank;
+                int32_t good = sums_allgather(c, &me, ids.data(), 4) == APK_OK ? 1 : 0;
+                for (int r = 0; r < c->world && good; r++) good = ids[r] == r;
+                c->rccl = false;
+                CHK(ctl_allgather(c, &good, oks.data(), 4));
+                for (int32_t v : oks) ok = ok && v;
+            }
+            if (!ok && c->nccl) { (void)g_rccl.CommDestroy(c->nccl); c->nccl = nullptr; }
+        }
+        all_can = ok != 0;
     }
     c->rccl = all_can && c->nccl;
     // HIP IPC when RCCL is not in use and every rank holds device memory: each rank exports its buffer once and the next rank
@@ -626,7 +716,7 @@ int apk_msm_g1_sharded(apk_comm* c, const void* d_scalars, uint64_t len, void* o
         if (status != APK_OK) err = apk_last_error();
     }
     memcpy(mine.data(), &status, 4);
-    CHK(ctl_allgather(c, mine.data(), all.data(), rec));       // the ONE exchange step: a 64/96-byte point per rank
+    CHK(sums_allgather(c, mine.data(), all.data(), rec));      // the ONE exchange step: a 64/96-byte point per rank (ncclAllGather on RCCL)
     std::vector<uint8_t> pts((size_t)c->world * nb);
     for (int r = 0; r < c->world; r++) {
         int32_t st;
@@ -682,18 +772,85 @@ int apk_comm_serve(apk_comm* c, uint64_t* steps_served) {
     if (!c || c->rank == 0) { set_error("comm: serve is the workers' call"); return APK_ERR_ARG; }
     for (;;) {
         Header h{};
+        // between steps the leader may be idle for any length of time: no timeout until the next header starts to arrive
+        CHK(wait_readable(c->peer[0]));
         CHK(ctl_bcast(c, &h, sizeof h));
         if (h.op == OP_STOP) break;
         if (h.count == 0 || h.count > 4) { set_error("comm: malformed header"); return APK_ERR_STATE; }
         int rc;
+        c->step_synced = false;
         if (h.op == OP_COMMIT) rc = commit_round(c, h.basis, h.count, h.lens, nullptr, nullptr);
         else if (h.op == OP_WIRES) rc = wires_round(c, h.count, h.lens, nullptr, nullptr);
         else { set_error("comm: unknown step %d", h.op); return APK_ERR_STATE; }
-        // a failed step was reported to every rank of the step; the worker stays in the loop for the leader's next call
-        (void)rc;
+        // A step that failed AFTER its status reached every rank (a rank's MSM or transform failed) leaves the streams aligned: the
+        // worker stays in the loop for the leader's next call.  A step that broke on the transport (socket, RCCL, IPC) or on a
+        // local allocation did not: the next bytes from the leader are not a header, so the worker leaves with the error.
+        if (rc != APK_OK && !c->step_synced) return rc;
     }
     if (steps_served) *steps_served = c->steps;
     return APK_OK;
+}
+
+int apk_comm_rccl_ranks(const apk_comm* c) {
+    if (!c || !c->rccl || !c->nccl) return 0;
+    int n = 0;
+    if (g_rccl.CommCount(c->nccl, &n) != ncclSuccess) return -1;
+    return n;
+}
+
+// A world-1 RCCL communicator on `device`, driven through every call the multi-GPU data plane makes (ncclGetUniqueId,
+// ncclCommInitRank, grouped ncclSend/ncclRecv to itself on a non-blocking stream, ncclAllGather, ncclCommCount,
+// ncclCommDestroy): the one-GPU boxes of this build cannot run two RCCL ranks (RCCL refuses two ranks per device), so this is how
+// init, stream use and teardown of that branch execute on hardware at all.  Returns APK_OK and the communicator's size in *ranks.
+int apk_comm_rccl_selftest(int device, int* ranks) {
+    if (ranks) *ranks = 0;
+    if (!g_rccl.load()) { set_error("comm: librccl could not be loaded: %s", dlerror() ? dlerror() : "not found"); return APK_ERR_STATE; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { (void)hipGetLastError(); set_error("no HIP device available; libapk has no CPU fallback"); return APK_ERR_HIP; }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (%d devices)", device, ndev); return APK_ERR_ARG; }
+    HCHK(hipSetDevice(device));
+    hipStream_t st = nullptr;
+    ncclComm_t comm = nullptr;
+    uint8_t *d_a = nullptr, *d_b = nullptr;
+    constexpr size_t N = 96 + 8;                // a status word + one BLS12-381 point: the size of the real exchange
+    uint8_t h_a[N], h_b[N], h_c[N];
+    for (size_t i = 0; i < N; i++) { h_a[i] = (uint8_t)(i * 7 + 3); h_b[i] = 0; h_c[i] = 0; }
+    int rc = APK_OK, count = 0;
+    auto fail = [&](const char* what, const char* why) { set_error("comm: RCCL self-test: %s: %s", what, why); rc = APK_ERR_HIP; };
+#define ST_H(x) if (rc == APK_OK) { hipError_t e_ = (x); if (e_ != hipSuccess) fail(#x, hipGetErrorString(e_)); }
+#define ST_N(x) if (rc == APK_OK) { ncclResult_t r_ = (x); if (r_ != ncclSuccess) fail(#x, g_rccl.GetErrorString(r_)); }
+    ncclUniqueId id{};
+    ST_N(g_rccl.GetUniqueId(&id));
+    ST_H(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    ST_N(g_rccl.CommInitRank(&comm, 1, id, 0));
+    ST_N(g_rccl.CommCount(comm, &count));
+    ST_H(hipMalloc((void**)&d_a, N));
+    ST_H(hipMalloc((void**)&d_b, N));
+    ST_H(hipMemcpyAsync(d_a, h_a, N, hipMemcpyHostToDevice, st));
+    ST_H(hipMemsetAsync(d_b, 0, N, st));
+    // the scatter / peer-copy pattern of data_scatter and data_p2p: Send and Recv in ONE group (to itself here)
+    ST_N(g_rccl.GroupStart());
+    ST_N(g_rccl.Send(d_a, N, ncclUint8, 0, comm, st));
+    ST_N(g_rccl.Recv(d_b, N, ncclUint8, 0, comm, st));
+    ST_N(g_rccl.GroupEnd());
+    ST_H(hipMemcpyAsync(h_b, d_b, N, hipMemcpyDeviceToHost, st));
+    ST_H(hipStreamSynchronize(st));
+    if (rc == APK_OK && memcmp(h_a, h_b, N) != 0) fail("send to self", "the received bytes differ from the sent ones");
+    // the partial-sum exchange of sums_allgather
+    ST_H(hipMemsetAsync(d_b, 0, N, st));
+    ST_N(g_rccl.AllGather(d_a, d_b, N, ncclUint8, comm, st));
+    ST_H(hipMemcpyAsync(h_c, d_b, N, hipMemcpyDeviceToHost, st));
+    ST_H(hipStreamSynchronize(st));
+    if (rc == APK_OK && memcmp(h_a, h_c, N) != 0) fail("all-gather", "the gathered bytes differ from the contribution");
+#undef ST_H
+#undef ST_N
+    if (comm) (void)g_rccl.CommDestroy(comm);
+    if (d_a) (void)hipFree(d_a);
+    if (d_b) (void)hipFree(d_b);
+    if (st) (void)hipStreamDestroy(st);
+    if (rc != APK_OK) (void)hipGetLastError();
+    if (ranks) *ranks = count;
+    return rc;
 }
 
 }  // extern "C"

@@ -60,6 +60,14 @@ def g1_add(curve: ecc.ID, P: bytes, Q: bytes) -> bytes:
     return out.raw
 
 
+def rccl_selftest(device: int = 0) -> int:
+    """World-1 RCCL communicator on `device` through every RCCL call of the data plane (apk_comm_rccl_selftest); returns
+    ncclCommCount (1) or raises."""
+    n = C.c_int32(0)
+    check(lib.apk_comm_rccl_selftest(device, C.byref(n)))
+    return n.value
+
+
 def free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -88,11 +96,32 @@ class Comm:
         addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
         # the ranks of one launch share their parent (the launcher's agent): its pid keeps a stale file of an earlier, crashed
         # launch on the same MASTER_PORT from being read
-        path = "/tmp/apk_rdzv_%s_%s_%s%s" % (os.getuid(), os.environ.get("MASTER_PORT", "0"), os.getppid(), tag)
+        # The file carries the port AND a random token of this launch (APK_COMM_TOKEN: libapk sends its hash in every hello and
+        # rank 0 refuses connections without it).  It lives in a directory of its own (mode 0700, owner checked) and is created
+        # with O_EXCL | O_NOFOLLOW, so a planted symlink or a pre-created file is an error, never followed.
+        rdir = "/tmp/apk_rdzv_%s" % os.getuid()
+        try:
+            os.mkdir(rdir, 0o700)
+        except FileExistsError:
+            pass
+        st = os.lstat(rdir)
+        import stat as _stat
+        if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise RuntimeError("rendezvous directory %s is not a private directory of this user" % rdir)
+        path = os.path.join(rdir, "%s_%s%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid(), tag))
         if rank == 0:
+            token = os.environ.get("APK_COMM_TOKEN") or os.urandom(16).hex()
+            os.environ["APK_COMM_TOKEN"] = token
+            # rank 0 binds the port itself: picked free, then bound by apk_comm_create a moment later - a race with another
+            # process taking it in between fails the create loudly (no silent cross-talk: the token guards the hello)
             port = free_port()
-            with open(path + ".tmp", "w") as f:
-                f.write(str(port))
+            try:
+                os.unlink(path)                      # a stale file of a crashed launch with the same parent pid
+            except OSError:
+                pass
+            fd = os.open(path + ".tmp", os.O_WRONLY | os.O_CREAT | os.O_EXCL | os.O_NOFOLLOW, 0o600)
+            with os.fdopen(fd, "w") as f:
+                f.write("%d %s" % (port, token))
             os.replace(path + ".tmp", path)
             try:
                 return cls(0, world, addr, port)
@@ -106,7 +135,11 @@ class Comm:
             if time.time() > deadline:
                 raise RuntimeError("rank %d: no rendezvous file %s from rank 0" % (rank, path))
             time.sleep(0.02)
-        return cls(rank, world, addr, int(open(path).read()))
+        fd = os.open(path, os.O_RDONLY | os.O_NOFOLLOW)
+        with os.fdopen(fd) as f:
+            port_s, token = f.read().split()
+        os.environ["APK_COMM_TOKEN"] = token
+        return cls(rank, world, addr, int(port_s))
 
     def bind(self, ctx) -> "Comm":
         check(lib.apk_comm_bind(self._c, ctx))
@@ -115,6 +148,11 @@ class Comm:
     @property
     def transport(self) -> str:
         return lib.apk_comm_transport(self._c).decode()
+
+    @property
+    def rccl_ranks(self) -> int:
+        """ncclCommCount of the data plane's RCCL communicator (0 unless the transport is "rccl")."""
+        return lib.apk_comm_rccl_ranks(self._c)
 
     def barrier(self) -> None:
         check(lib.apk_comm_barrier(self._c))

@@ -188,7 +188,11 @@ int apk_coset_ntt_device(apk_ctx* ctx, const void* d_canonical, uint64_t len, vo
  *                        canonical polynomial out and of the evaluations back).
  * Every rank holds the circuit context (apk_ctx_create with the same inputs), so any rank can commit any index range.
  * Errors on one rank are reported on all ranks of the step (status words travel with the partial sums); a peer that stops
- * answering fails the call after APK_COMM_TIMEOUT_S seconds (default 300). */
+ * answering INSIDE a step fails the call after APK_COMM_TIMEOUT_S seconds (default 300); between steps a worker in apk_comm_serve
+ * waits for the leader's next header without a timeout (the leader may be idle for any length of time).  When APK_COMM_TOKEN is
+ * set, its hash travels in every rank's hello and rank 0 refuses connections that do not carry it.
+ * With RCCL as the data plane the partial sums of a sharded MSM / a dealt commitment batch are exchanged with ncclAllGather
+ * (north_star: "RCCL-over-xGMI ... for the final bucket-sum of a single MSM"); the ranks add the gathered points themselves. */
 typedef struct apk_comm apk_comm;
 int apk_comm_create(int rank, int world, const char* addr, int port, apk_comm** out);   /* rank 0 listens on addr:port */
 void apk_comm_destroy(apk_comm* comm);
@@ -201,6 +205,13 @@ int apk_comm_max_f64(apk_comm* comm, double* value);       /* in place: maximum 
  * must outlive the binding: apk_comm_bind(comm, NULL) (not collective) or apk_comm_destroy BEFORE apk_ctx_destroy. */
 int apk_comm_bind(apk_comm* comm, apk_ctx* ctx);
 const char* apk_comm_transport(const apk_comm* comm);      /* "rccl", "ipc" or "tcp" (after apk_comm_bind) */
+/* Size of the RCCL communicator behind the data plane (ncclCommCount): `world` when the transport is "rccl", 0 otherwise. */
+int apk_comm_rccl_ranks(const apk_comm* comm);
+/* A world-1 RCCL communicator on `device` driven through every RCCL call of the data plane (unique id, ncclCommInitRank, a grouped
+ * ncclSend / ncclRecv to itself on a non-blocking stream, ncclAllGather, ncclCommCount, ncclCommDestroy), results checked byte for
+ * byte.  One-GPU boxes cannot run two RCCL ranks (RCCL refuses two ranks per device): this is how that branch's init, stream
+ * use and teardown execute on hardware there.  *ranks receives ncclCommCount (1). */
+int apk_comm_rccl_selftest(int device, int* ranks);
 int apk_msm_g1_sharded(apk_comm* comm, const void* d_scalars, uint64_t len, void* out);
 int apk_comm_split_begin(apk_comm* comm);
 int apk_comm_split_end(apk_comm* comm);

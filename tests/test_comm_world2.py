@@ -155,6 +155,68 @@ def _split_worker(rank, world, port, q):
         q.put((rank, "FAIL: %r %s" % (e, traceback.format_exc()[-800:])))
 
 
+def _wires4_idle_worker(rank, world, port, q):
+    """Two findings of the round-3 review, on the CPU tier: (1) FOUR wires at world 2 deal wires 1 and 3 to the one worker - the
+    schedule must answer the first before the second arrives; (2) a leader that is idle for longer than APK_COMM_TIMEOUT_S between
+    two steps must find its worker still serving (the timeout guards a step, not the wait for one)."""
+    _setup_paths()
+    try:
+        os.environ["APK_COMM_TIMEOUT_S"] = "1"
+        import time
+        from algoplonk_amd import ecc, parallel
+        from oracle import c_oracle, curves as oc, plonk as oplonk
+        from oracle.prng import SplitMix64
+        clib = c_oracle.load()
+        cv, ov = ecc.BN254, oc.BN254
+        n = 8
+        tau = 0x5151
+        pts = cv.g1_vector([ov.mul(ov.g1, pow(tau, i, cv.r)) for i in range(n + 3)])
+        g = SplitMix64(11)
+        vectors = [[g.fr(cv.r) for _ in range(m)] for m in (10, 9, 11, 10)]
+        comm = parallel.Comm(rank, world, "127.0.0.1", port)
+        table, keep = _compute_table(cv, clib, pts, n=n)
+        comm.set_compute(table, keep)
+        comm.bind(None)
+        if rank == 0:
+            host = [C.create_string_buffer(cv.fr_vector(v)) for v in vectors]
+            ptr = [C.addressof(b) for b in host]
+            w4 = ov.omega(4 * n)
+            for rep in range(2):
+                evs = [C.create_string_buffer(4 * n * 32) for _ in range(4)]
+                comm.wires(ptr, [len(v) for v in vectors], [C.addressof(e) for e in evs])
+                for i in range(4):
+                    want = [oplonk.poly_eval(vectors[i], ov.coset_shift * pow(w4, j, cv.r) % cv.r, cv.r) for j in range(4 * n)]
+                    assert cv.fr_vector_decode(evs[i].raw) == want, ("wire", i, rep)
+                if rep == 0:
+                    time.sleep(2.5)              # idle for 2.5 x the step timeout
+            got = comm.commit(cv, 0, [ptr[0]], [10])
+            assert cv.g1_from_bytes(got[0]) == ov.mul(ov.g1, oplonk.poly_eval(vectors[0], tau, cv.r))
+            comm.split_end()
+        else:
+            assert comm.serve() == 3
+        comm.close()
+        q.put((rank, "ok"))
+    except Exception as e:
+        import traceback
+        q.put((rank, "FAIL: %r %s" % (e, traceback.format_exc()[-800:])))
+
+
+def _token_worker(rank, world, port, q):
+    """A hello that does not carry the launch's APK_COMM_TOKEN is refused by rank 0."""
+    _setup_paths()
+    try:
+        os.environ["APK_COMM_TOKEN"] = "launch-A" if rank == 0 else "launch-B"
+        os.environ["APK_COMM_TIMEOUT_S"] = "5"
+        from algoplonk_amd import _lib, parallel
+        with pytest.raises(_lib.ApkError):
+            c = parallel.Comm(rank, world, "127.0.0.1", port)
+            c.barrier()                          # the refused worker finds its connection closed here at the latest
+        q.put((rank, "ok"))
+    except Exception as e:
+        import traceback
+        q.put((rank, "FAIL: %r %s" % (e, traceback.format_exc()[-800:])))
+
+
 def _run(target, world, extra_ports=1):
     from algoplonk_amd.parallel import free_port
     ctx = mp.get_context("spawn")
@@ -177,6 +239,25 @@ def test_sharded_msm_over_the_c_communicator(world):
 def test_split_proof_schedule_over_the_c_communicator(world):
     """commitment batches dealt by index range + wires dealt by polynomial; leader / worker loop."""
     _run(_split_worker, world)
+
+
+def test_four_wires_at_world_2_and_an_idle_leader():
+    _run(_wires4_idle_worker, 2)
+
+
+def test_hello_without_the_launch_token_is_refused():
+    _run(_token_worker, 2)
+
+
+def test_from_env_rendezvous_file_is_private(tmp_path, monkeypatch):
+    """Comm.from_env publishes port + token in a 0600 file inside a 0700 directory of the user; world 1 needs none."""
+    sys.path.insert(0, ROOT)
+    from algoplonk_amd import parallel
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    c = parallel.Comm.from_env()
+    assert c.world == 1 and c.rccl_ranks == 0
+    c.close()
 
 
 def test_world_1_needs_no_peer():
