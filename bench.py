@@ -179,7 +179,38 @@ class Ranks:
         self.fence()
         return self.comm.max(time.perf_counter() - t1)
 
+    def data_plane_probe(self, ctx, timeout_s: float = 120.0) -> dict:
+        """Independent proofs exchange no data, so the timed region of `prove` mode never touches the data plane.  AFTER the
+        measurements every rank binds the communicator to its context once (collective): RCCL when every rank owns a GPU
+        (ncclCommInitRank + one ncclAllGather of the rank numbers, checked), else HIP IPC, else TCP - and the line reports what
+        came up (`rccl_ranks` = ncclCommCount).  A watchdog bounds it: a bind that does not return is reported as such and the
+        process leaves without the library's teardown (the line is already complete)."""
+        if self.world == 1:
+            return {"transport": "none (single process)", "rccl_ranks": 0}
+        res = {}
+
+        def go():
+            try:
+                self.comm.bind(ctx)
+                res["transport"], res["rccl_ranks"] = self.comm.transport, self.comm.rccl_ranks
+                self.comm.bind(None)
+            except Exception as e:  # reported, never fatal for a line that is already measured
+                res["transport"], res["rccl_ranks"], res["error"] = "unavailable", 0, str(e)[:200]
+
+        t = threading.Thread(target=go, daemon=True)
+        t.start()
+        t.join(timeout_s)
+        if t.is_alive():
+            self.hung = True
+            return {"transport": "unknown", "rccl_ranks": 0, "error": "apk_comm_bind did not return within %d s" % timeout_s}
+        return res
+
+    hung = False
+
     def close(self):
+        if self.hung:
+            sys.stdout.flush()
+            os._exit(0)
         self.comm.close()
 
 
@@ -327,7 +358,8 @@ def bench_prove_split(args, cv, rk) -> None:
             "config": {"workload": wl.name + ", one proof at a time", "log_n": args.log_n, "curve": cv.name,
                        "parallelism": "commitment batches dealt by index range x%d (scatter + all-gather of partial sums)%s, transcript on rank 0"
                                       % (rk.world, ", wires dealt by polynomial" if os.environ.get("APK_SPLIT_WIRES") == "1" else ""),
-                       "world_size": rk.world, "backend": "libapk comm: tcp control plane, %s data plane" % rk.comm.transport},
+                       "world_size": rk.world, "backend": "libapk comm: tcp control plane, %s data plane" % rk.comm.transport,
+                       "rccl_ranks": rk.comm.rccl_ranks},
             "proof_sha256_prefix": hashlib.sha256(got).hexdigest()[:16], "matches_single_gpu_proof": got == want,
         }
     else:
@@ -519,6 +551,7 @@ def bench_prove(args, cv, rk) -> None:
                     cpu_baseline = {"value": None, "unit": "proofs/sec", "cores": 0, "kind": "port", "sample": "unavailable: %s" % e}
             cpu_baseline["go_probe"] = probe
     roofline = roofline_from_stats(args, cv, st, pmc)
+    plane = rk.data_plane_probe(pk.ctx)
 
     if rk.rank == 0:
         import hashlib
@@ -535,7 +568,8 @@ def bench_prove(args, cv, rk) -> None:
                        "stepping": "joined after every step" if (args.step_barrier or args.inflight == 1) else
                                    "%d persistent callers x K proofs each; barriers only around the K steps" % args.inflight,
                        "srs": "synthetic tau=SHA256(seed)", "parallelism": "replicas x%d" % rk.world, "world_size": rk.world,
-                       "backend": "libapk comm (barrier + MAX over TCP only: independent proofs exchange no data)" if rk.world > 1 else "single process"},
+                       "backend": "libapk comm (barrier + MAX over TCP only: independent proofs exchange no data)" if rk.world > 1 else "single process",
+                       "rccl_ranks": plane.get("rccl_ranks", 0), "data_plane": plane},
             "proof_latency_ms": round(lat_ms, 3), "proof_latency_instrumented_ms": round(lat_stats_ms, 3), "msm_mscalar_per_s": round(msm_mscalar, 3),
             "msm_ms": round(msm_s * 1e3, 4), "msm_mscalar_per_s_saturated": round(msm_sat_mscalar, 3), "setup_s": round(setup_s, 2),
             "msm_batch_avg_ms": round(st.msm_total_ms / max(st.msm_batches, 1), 4),
@@ -646,7 +680,8 @@ def bench_sharded_msm(args, cv, rk) -> None:
             "scaling": "strong", "vs_baseline": None, "dtype": "u29x9 Fp (BN254) / u28x14 Fp (BLS12-381) unsaturated Montgomery",
             "data": "synthetic", "config": {"workload": "%s single MSM 2^%d sharded by index range" % (cv.name, args.log_n),
                                             "parallelism": "index-range x%d + all-gather of %d-byte points" % (rk.world, 2 * cv.fp_bytes),
-                                            "world_size": rk.world, "backend": ("libapk comm: tcp control plane, %s data plane" % rk.comm.transport) if rk.world > 1 else "single process"},
+                                            "world_size": rk.world, "backend": ("libapk comm: tcp control plane, %s data plane" % rk.comm.transport) if rk.world > 1 else "single process",
+                                            "rccl_ranks": rk.comm.rccl_ranks},
             "result_sha256_prefix": hashlib.sha256(res[0]).hexdigest()[:16],
             "roofline": roofline_from_stats(args, cv, st, pmc), "cpu_baseline": cpu_baseline}), flush=True)
     rk.close()

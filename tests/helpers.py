@@ -44,3 +44,28 @@ def random_chain_ccs(cv, log_n: int, seed: int, nb_public: int = 2) -> Tuple[fro
     ccs = frontend.ConstraintSystem(r, ["p%d" % i for i in range(nb_public)], ["s0", "s1"], cons, "gates", len(sol))
     w = frontend.Witness(r, sol[:nb_public], sol[nb_public:nb_public + 2])
     return ccs, w, sol
+
+
+def check_bench_line(d: dict, tol: float = 0.01) -> None:
+    """Recompute every derived figure of a bench.py line from the line's OWN inputs (bench.py roofline_from_stats):
+    value from steps / proofs per step / ms_per_step; roofline.achieved = algorithmic bytes per launch / launch time;
+    frac = achieved / peak; hbm_traffic_frac = traffic / launch time / peak; valu.bucket_additions_per_s = pairs x windows /
+    launch time; valu.frac = additions / issue_bound.  Used on live output (GPU tier) and on the committed lines (CPU tier)."""
+    def close(a, b, what):
+        assert abs(a - b) <= tol * max(abs(a), abs(b), 1e-12), (what, a, b)
+
+    if d.get("metric") == "proofs/sec" and "proofs_per_step" in d.get("config", {}):
+        close(d["value"], d["steps"] * d["config"]["proofs_per_step"] * d["n_gpus"] / (d["ms_per_step"] * d["steps"] / 1e3), "value")
+    rf = d["roofline"]
+    assert rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    t = rf["avg_launch_ms"] * 1e-3
+    close(rf["achieved"], rf["pairs_per_launch"] * rf["algorithmic_bytes_per_pair"] / t / 1e9, "roofline.achieved")
+    close(rf["frac"], rf["achieved"] / rf["peak"], "roofline.frac")
+    if rf.get("traffic") is not None and "hbm_traffic_frac" in rf:
+        close(rf["hbm_traffic_frac"], rf["traffic"] / t / 1e9 / rf["peak"], "roofline.hbm_traffic_frac")
+    v = rf.get("valu")
+    if v:
+        close(v["bucket_additions_per_s"], rf["pairs_per_launch"] * v["windows"] / t / 1e9, "valu.bucket_additions_per_s")
+        if "issue_bound" in v:
+            close(v["frac"], v["bucket_additions_per_s"] / v["issue_bound"], "valu.frac")
+            assert v["frac"] <= 1.05, "an addition rate above the kernel's own issue bound means the bound's basis is stale"

@@ -1,0 +1,63 @@
+"""CPU tier: every committed bench line (profiles/rNN_bench_*.json, the driver's BENCH_rNN.json) must follow from its own
+inputs - roofline.frac, hbm_traffic_frac and valu.frac are recomputed by tests/helpers.check_bench_line, the same function the GPU
+tier applies to live output.  And tools/pmc_accumulate.py, which writes profiles/rNN_pmc_msm_accumulate.json, must reproduce the
+summary from the raw per-pass tables."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from helpers import check_bench_line
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lines():
+    out = []
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]_bench_*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]_kernel_trace_*_benchline.json"))):
+        txt = open(p).read().strip()
+        if txt.startswith("{"):
+            out.append((os.path.basename(p), json.loads(txt)))
+    for p in sorted(glob.glob(os.path.join(ROOT, "BENCH_r0[3-9].json"))):
+        d = json.load(open(p))
+        if isinstance(d.get("parsed"), dict):
+            out.append((os.path.basename(p), d["parsed"]))
+    return out
+
+
+@pytest.mark.parametrize("name,line", _lines(), ids=[n for n, _ in _lines()])
+def test_committed_bench_lines_follow_from_their_own_fields(name, line):
+    if "roofline" not in line or not line["roofline"]:
+        pytest.skip("no roofline object in this mode's line")
+    check_bench_line(line)
+
+
+def test_check_bench_line_catches_a_stale_fraction():
+    name, line = next((n, l) for n, l in _lines() if l.get("roofline"))
+    bad = json.loads(json.dumps(line))
+    bad["roofline"]["frac"] *= 1.5
+    with pytest.raises(AssertionError):
+        check_bench_line(bad)
+    bad = json.loads(json.dumps(line))
+    bad["roofline"]["avg_launch_ms"] *= 0.5
+    with pytest.raises(AssertionError):
+        check_bench_line(bad)
+
+
+def test_pmc_accumulate_summary_is_reproducible_from_the_raw_passes(tmp_path):
+    """profiles/rNN_pmc_msm_accumulate.json is generator output: tools/pmc_accumulate.py over the per-pass JSON tables
+    (tools/pmc_summary.py --json) of the same round gives the committed file again."""
+    done = 0
+    for summary in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[4-9]_pmc_msm_accumulate.json"))):
+        tag = os.path.basename(summary)[:3]
+        out = tmp_path / "again.json"
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_accumulate.py"), os.path.join(ROOT, "profiles"), tag, str(out)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert json.load(open(out)) == json.load(open(summary)), summary
+        done += 1
+    if not done:
+        pytest.skip("no round >= 4 PMC summary committed yet")

@@ -157,3 +157,14 @@ def test_bench_line_carries_the_contract_fields(gpu):
     assert cb["kind"] in ("port", "reference") and cb["unit"] == "proofs/sec" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert cb["matches_gpu_proof"] is True
     assert len(d["round_ms"]) == 4 and d["witness_bits"]["proof_verifies"] is True
+
+
+@pytest.mark.gpu
+def test_rccl_branch_runs_on_hardware_world_1(gpu):
+    """The RCCL data plane needs one GPU per rank, and these boxes have one GPU: a world-1 RCCL communicator is how
+    ncclGetUniqueId / ncclCommInitRank / grouped ncclSend + ncclRecv on libapk's non-blocking stream / ncclAllGather /
+    ncclCommCount / ncclCommDestroy execute on hardware at all (apk_comm_rccl_selftest; results compared byte for byte inside)."""
+    sys.path.insert(0, ROOT)
+    from algoplonk_amd import parallel
+    assert parallel.rccl_selftest(0) == 1
+    assert parallel.rccl_selftest(0) == 1          # init and teardown are repeatable in one process

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Small driver for profiler runs: one context at BN254 2^log_n, then a few single MSMs and proofs.
-usage: python tools/prof_msm.py [log_n] [msms] [proofs] [bn254|bls12_381]"""
+usage: python tools/prof_msm.py [log_n] [msms] [proofs] [bn254|bls12_381]
+APK_PROF_FACTS=file: what the run did (sizes, MSMs, pairs, window, table bytes) as JSON, for tools/pmc_summary.py --json."""
 import ctypes as C
+import json
 import os
 import sys
 
@@ -31,4 +33,12 @@ for _ in range(n_msm):
 pr = _lib.Proof()
 for _ in range(n_proofs):
     check(lib.apk_prove_device(pk.ctx, d[0], d[1], d[2], cv.fr_vector(wl.witness.public), cv.fr_vector(wl.blinding), None, C.byref(pr)))
+if os.environ.get("APK_PROF_FACTS"):
+    # a default (one-slot, latency) context: window = backend_impl.h choose_window unless APK_MSM_WINDOW says otherwise
+    c = int(os.environ.get("APK_MSM_WINDOW", "0")) or (16 if log_n >= 21 else min(15, max(8, log_n - 2)))
+    windows = (cv.r.bit_length() + 1 + c - 1) // c
+    msms = 8 + n_msm + 9 * n_proofs           # Setup's 8 VK commitments + the single MSMs + 9 commitments per proof
+    json.dump({"curve": cv.name, "log_n": log_n, "n": n, "single_msms": n_msm, "proofs": n_proofs, "msms_total": msms,
+               "pairs_total": msms * (n + 2), "window_bits": c, "windows": windows, "table_bytes": (n + 3) * windows * 2 * cv.fp_bytes},
+              open(os.environ["APK_PROF_FACTS"], "w"))
 print("done")

@@ -17,16 +17,27 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_kt24 -o r -- python be
 python tools/rocprof_summary.py $O/${TAG}_kt24/r_results.db > $O/${TAG}_kernel_trace_bn254_2p17_saturated.txt
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_ktbls -o r -- python bench.py --curve bls12_381 --log-n 14 --inflight 1 --steps 8 --warmup 2 --no-cpu-baseline --no-pmc > $O/${TAG}_ktbls.log 2>&1
 python tools/rocprof_summary.py $O/${TAG}_ktbls/r_results.db > $O/${TAG}_kernel_trace_bls12381_2p14.txt
-# PMC passes (one counter group per pass, kernel trace only: no other trace domains)
+# PMC passes (one counter group per pass, kernel trace only: no other trace domains).  Every pass leaves its per-kernel table as
+# text AND as JSON (with prof_msm.py's facts about the run); tools/pmc_accumulate.py writes the summary FROM those.
+pmc_pass() {   # config-name  counters  prof_msm args...   (extra environment through PMC_ENV)
+  local CFG=$1 C=$2; shift 2
+  local N=$(echo $C | tr ' ' '_')
+  env $PMC_ENV APK_PROF_FACTS=$O/${TAG}_facts_${CFG}.json timeout 400 rocprofv3 --kernel-trace --pmc $C -d $O/${TAG}_pmc_${CFG}_$N -o p -- python tools/prof_msm.py "$@" > $O/${TAG}_pmc_${CFG}_$N.log 2>&1
+  python tools/pmc_summary.py $O/${TAG}_pmc_${CFG}_$N/p_results.db --json $O/${TAG}_pmc_${CFG}_$N.json $O/${TAG}_facts_${CFG}.json > $O/${TAG}_pmc_${CFG}_$N.txt
+  rm -rf $O/${TAG}_pmc_${CFG}_$N/
+}
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES"; do
-  N=$(echo $C | tr ' ' '_')
-  timeout 300 rocprofv3 --kernel-trace --pmc $C -d $O/${TAG}_pmc_$N -o p -- python tools/prof_msm.py 17 4 2 > $O/${TAG}_pmc_$N.log 2>&1
-  python tools/pmc_summary.py $O/${TAG}_pmc_$N/p_results.db > $O/${TAG}_pmc_bn254_2p17_$N.txt
+  PMC_ENV= pmc_pass bn254_2p17 "$C" 17 4 2
 done
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do
-  N=$(echo $C | tr ' ' '_')
-  timeout 300 rocprofv3 --kernel-trace --pmc $C -d $O/${TAG}_pmcbls_$N -o p -- python tools/prof_msm.py 14 4 2 bls12_381 > $O/${TAG}_pmcbls_$N.log 2>&1
-  python tools/pmc_summary.py $O/${TAG}_pmcbls_$N/p_results.db > $O/${TAG}_pmc_bls12381_2p14_$N.txt
+  PMC_ENV= pmc_pass bls12381_2p14 "$C" 14 4 2 bls12_381
 done
-rm -rf $O/${TAG}_kt1 $O/${TAG}_kt24 $O/${TAG}_ktbls $O/${TAG}_pmc_*/ $O/${TAG}_pmcbls_*/
+# the Infinity Cache question: the same passes with a table LARGER than the 256 MiB cache (2^19 bases x 16
+# windows x 64 B = 537 MB) - what FETCH_SIZE reads there is HBM traffic, whatever it was at 2^17 (134-143 MB table)
+for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do
+  PMC_ENV=APK_MSM_WINDOW=16 pmc_pass bn254_2p19_c16 "$C" 19 4 0
+  PMC_ENV=APK_MSM_WINDOW=16 pmc_pass bn254_2p17_c16 "$C" 17 4 0
+done
+python tools/pmc_accumulate.py $O $TAG $O/${TAG}_pmc_msm_accumulate.json > $O/${TAG}_pmc_accumulate.log 2>&1
+rm -rf $O/${TAG}_kt1 $O/${TAG}_kt24 $O/${TAG}_ktbls $O/${TAG}_facts_*.json
 ls -la $O | grep ${TAG} | tail -40
