@@ -142,7 +142,7 @@ class CurveBackend : public Backend {
         DevBuf scratch_in;  // upload staging for primitives
         DevBuf ntt_wide;    // NTT_MAX_BATCH transforms of 4n unsaturated-limb elements: the NTT's inter-pass form
         // MSM workspace
-        DevBuf sort_tmp, counts, hist, offsets, unit_off, full_off, rem_rank, rem_list, scan_blk, sorted, partial, bucket_sum, rowcol, bit_partial, result, result_xyzz, done_count;
+        DevBuf sort_tmp, counts, hist, offsets, unit_off, full_off, rem_rank, rem_list, merge_rank, merge_list, scan_blk, sorted, partial, bucket_sum, rowcol, bit_partial, result, result_xyzz, done_count;
         void* h_pinned = nullptr;  // small pinned staging for results: [0,1024) affine, [1024,2048) XYZZ, [2048,4096) scalars
         uint32_t pending_pts = 0;  // MSM sums waiting in h_pinned for their affine conversion (sync_results)
         std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;   // APK_MSM_GRAPH
@@ -476,14 +476,15 @@ class CurveBackend : public Backend {
             uint32_t* blk_bins = blk_tot + 3 * nblk;
             msm_scan_local_kernel<0><<<nblk, MSM_SCAN_BLOCK, 0, st>>>(ptr<uint32_t>(s.hist), total_buckets, unit, ptr<uint32_t>(s.offsets),
                                                                        ptr<uint32_t>(s.unit_off), ptr<uint32_t>(s.full_off), ptr<uint32_t>(s.rem_rank),
-                                                                       blk_tot, blk_bins, nblk);
+                                                                       ptr<uint32_t>(s.merge_rank), blk_tot, blk_bins, nblk);
             KCHK();
             msm_scan_totals_kernel<0><<<1, MSM_SCAN_BLOCK, 0, st>>>(blk_tot, blk_bins, nblk, total_buckets, ptr<uint32_t>(s.offsets),
                                                                      ptr<uint32_t>(s.unit_off), ptr<uint32_t>(s.full_off));
             KCHK();
-            msm_scan_apply_kernel<0><<<nblk, MSM_SCAN_BLOCK, 0, st>>>(blk_tot, blk_bins, ptr<uint32_t>(s.hist), ptr<uint32_t>(s.rem_rank), nblk,
+            msm_scan_apply_kernel<0><<<nblk, MSM_SCAN_BLOCK, 0, st>>>(blk_tot, blk_bins, ptr<uint32_t>(s.hist), ptr<uint32_t>(s.rem_rank),
+                                                                      ptr<uint32_t>(s.merge_rank), nblk,
                                                                       total_buckets, unit, ptr<uint32_t>(s.offsets), ptr<uint32_t>(s.unit_off),
-                                                                      ptr<uint32_t>(s.full_off), ptr<uint32_t>(s.rem_list));
+                                                                      ptr<uint32_t>(s.full_off), ptr<uint32_t>(s.rem_list), ptr<uint32_t>(s.merge_list));
             KCHK();
         }
         if (!sort2 && APK_PHASE(64)) {
@@ -511,9 +512,12 @@ class CurveBackend : public Backend {
         }
         {   // light and heavy merge in one launch (the heavy blocks return at once when no bucket is skewed)
             const uint32_t normal_blocks = cdiv((uint64_t)total_buckets << lanes_log, 256);
+            // the buckets in the order of their partial counts (merge_list): a wave's lanes run the same number of additions
+            static const int sorted_merge = env_int("APK_MSM_SORTED_MERGE", 1, 0, 1);
             if (APK_PHASE(4))
             msm_combine_kernel<FPP><<<normal_blocks + MSM_HEAVY_BLOCKS, 256, 0, st>>>(
-                ptr<PtU>(s.partial), ptr<uint32_t>(s.unit_off), total_buckets, lanes_log, normal_blocks, ptr<PtU>(s.bucket_sum));
+                ptr<PtU>(s.partial), ptr<uint32_t>(s.unit_off), sorted_merge ? ptr<uint32_t>(s.merge_list) : nullptr, total_buckets, lanes_log,
+                normal_blocks, ptr<PtU>(s.bucket_sum));
             KCHK();
         }
         // sum_k k*B_k: row/column sums of the bucket array, bit-wise weighted sums of those, final scaling + affine
@@ -536,8 +540,14 @@ class CurveBackend : public Backend {
         bool serial = false;
         if (quad_env < 0 && !graphs_on && rows % 4 == 0 && cols % 4 == 0) serial = serial_env >= 0 ? serial_env != 0 : lean;
         if (!APK_PHASE(8)) {
-        } else if (serial)
-            msm_rowcol_serial_kernel<FPP><<<dim3((rows + cols + 15) / 16, a.batch), 256, 0, st>>>(ptr<PtU>(s.bucket_sum), NB_, rows, cols, ptr<PtU>(s.rowcol));
+        } else if (serial) {
+            // lanes per line: 16 (19 / 11 addition-times per wave of four rows / columns at c = 16) or 8 (34 / 18 per eight)
+            static const int lpl = env_int("APK_MSM_ROWCOL_LANES", 16, 8, 16);
+            if (lpl == 8 && rows % 8 == 0 && cols % 8 == 0)
+                msm_rowcol_serial_kernel<FPP, 8><<<dim3((rows + cols + 31) / 32, a.batch), 256, 0, st>>>(ptr<PtU>(s.bucket_sum), NB_, rows, cols, ptr<PtU>(s.rowcol));
+            else
+                msm_rowcol_serial_kernel<FPP, 16><<<dim3((rows + cols + 15) / 16, a.batch), 256, 0, st>>>(ptr<PtU>(s.bucket_sum), NB_, rows, cols, ptr<PtU>(s.rowcol));
+        }
         else if (quad & 1)
             msm_rowcol_quad_kernel<FPP><<<dim3(rows + cols, a.batch), 4 * lt, lt * sizeof(PtU), st>>>(ptr<PtU>(s.bucket_sum), NB_, rows, cols, ptr<PtU>(s.rowcol));
         else if (quad & 8)
@@ -697,7 +707,8 @@ class CurveBackend : public Backend {
         const uint32_t tb = batch * NB_;
         CHK(s.hist.alloc((size_t)(tb + 1) * 4)); CHK(s.offsets.alloc((size_t)(tb + 1) * 4));
         CHK(s.unit_off.alloc((size_t)(tb + 1) * 4));
-        CHK(s.scan_blk.alloc((size_t)(3 + MSM_UNIT_MAX) * (cdiv(tb, MSM_SCAN_BLOCK) + 1) * 4));
+        CHK(s.scan_blk.alloc((size_t)(3 + MSM_BINS) * (cdiv(tb, MSM_SCAN_BLOCK) + 1) * 4));
+        CHK(s.merge_rank.alloc((size_t)(tb + 1) * 4)); CHK(s.merge_list.alloc((size_t)(tb + 1) * 4));
         CHK(s.full_off.alloc((size_t)(tb + 1) * 4)); CHK(s.rem_rank.alloc((size_t)(tb + 1) * 4)); CHK(s.rem_list.alloc((size_t)(tb + 1) * 4));
         CHK(s.counts.alloc((size_t)tb * msm_G_max_ * 4));
         CHK(s.sorted.alloc(entries * 4));

@@ -406,23 +406,31 @@ __global__ void __launch_bounds__(1024) msm_part_sort_kernel(const uint32_t* __r
 // scans the totals -> blocks add their base.
 constexpr int MSM_SCAN_BLOCK = 1024;
 constexpr int MSM_SCAN_MAX_BLOCKS = 256;   // MSM_MAX_BATCH * 2^16 buckets / MSM_SCAN_BLOCK
+// The same counting sort orders ALL buckets by their number of unit partials (merge_list, most partials first; counts from
+// MSM_MERGE_BINS - 1 up share the last bin): msm_combine_kernel walks the buckets in that order, so the lanes of a wave merge the
+// same number of partials.  In bucket order a wave waited for its bucket with the most partials (3..6 at c = 16: 73 % lane
+// efficiency, round 3 PMC) - the merge is 7 % of a proof's instructions.
+constexpr int MSM_MERGE_BINS = 16;
+constexpr int MSM_BINS = MSM_UNIT_MAX + MSM_MERGE_BINS;   // [0, MSM_UNIT_MAX): remainder lengths, then the unit counts
 
 template <int DUMMY>
 __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_local_kernel(const uint32_t* __restrict__ hist, uint32_t total, uint32_t unit,
                                                                          uint32_t* __restrict__ offsets, uint32_t* __restrict__ unit_off,
                                                                          uint32_t* __restrict__ full_off, uint32_t* __restrict__ rem_rank,
+                                                                         uint32_t* __restrict__ merge_rank,
                                                                          uint32_t* __restrict__ block_tot /* [3][nblocks] */,
-                                                                         uint32_t* __restrict__ block_bins /* [nblocks][MSM_UNIT_MAX] */, uint32_t nblocks) {
+                                                                         uint32_t* __restrict__ block_bins /* [nblocks][MSM_BINS] */, uint32_t nblocks) {
     wave_priority<APK_PRIO_SORT>();
     __shared__ uint32_t s_cnt[MSM_SCAN_BLOCK];
     __shared__ uint32_t s_unit[MSM_SCAN_BLOCK];
     __shared__ uint32_t s_full[MSM_SCAN_BLOCK];
-    __shared__ uint32_t s_bins[MSM_UNIT_MAX];
+    __shared__ uint32_t s_bins[MSM_BINS];
     const uint32_t t = threadIdx.x, i = blockIdx.x * MSM_SCAN_BLOCK + t;
-    if (t < MSM_UNIT_MAX) s_bins[t] = 0;
+    if (t < MSM_BINS) s_bins[t] = 0;
     __syncthreads();
     const uint32_t h = i < total ? hist[i] : 0u, hf = h / unit, rem = h - hf * unit, hu = hf + (rem ? 1u : 0u);
     if (rem) rem_rank[i] = atomicAdd(&s_bins[rem], 1u);   // rank of this bucket among the block's buckets with the same remainder
+    if (i < total) merge_rank[i] = atomicAdd(&s_bins[MSM_UNIT_MAX + min(hu, (uint32_t)MSM_MERGE_BINS - 1u)], 1u);   // ... with the same number of partials
     s_cnt[t] = h; s_unit[t] = hu; s_full[t] = hf;
     __syncthreads();
     for (uint32_t d = 1; d < MSM_SCAN_BLOCK; d <<= 1) {
@@ -436,11 +444,11 @@ __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_local_kernel(const ui
     if (t == MSM_SCAN_BLOCK - 1) {
         block_tot[blockIdx.x] = s_cnt[t]; block_tot[nblocks + blockIdx.x] = s_unit[t]; block_tot[2 * nblocks + blockIdx.x] = s_full[t];
     }
-    if (t < MSM_UNIT_MAX) block_bins[blockIdx.x * MSM_UNIT_MAX + t] = s_bins[t];
+    if (t < MSM_BINS) block_bins[blockIdx.x * MSM_BINS + t] = s_bins[t];
 }
 
 // one block: exclusive scan of the (<= 1024) block totals in place; grand totals to offsets[total] / unit_off[total] /
-// full_off[total]; block_bins[blk][r] becomes the first rem_list position of block blk's buckets with remainder r
+// full_off[total]; block_bins[blk][r] becomes the first rem_list (merge_list) position of block blk's buckets with remainder r (unit count r - MSM_UNIT_MAX)
 template <int DUMMY>
 __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_totals_kernel(uint32_t* __restrict__ block_tot, uint32_t* __restrict__ block_bins,
                                                                           uint32_t nblocks, uint32_t total, uint32_t* __restrict__ offsets,
@@ -449,17 +457,17 @@ __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_totals_kernel(uint32_
     __shared__ uint32_t s_cnt[MSM_SCAN_BLOCK];
     __shared__ uint32_t s_unit[MSM_SCAN_BLOCK];
     __shared__ uint32_t s_full[MSM_SCAN_BLOCK];
-    __shared__ uint32_t s_bintot[MSM_UNIT_MAX];
-    __shared__ uint16_t s_bins[MSM_SCAN_MAX_BLOCKS * MSM_UNIT_MAX];   // per-block remainder histograms (<= 1024 each): 32 KB
+    __shared__ uint32_t s_bintot[MSM_BINS];
+    __shared__ uint16_t s_bins[MSM_SCAN_MAX_BLOCKS * MSM_BINS];   // per-block remainder / unit-count histograms (<= 1024 each): 40 KB
     const uint32_t t = threadIdx.x;
     const uint32_t h = t < nblocks ? block_tot[t] : 0u, hu = t < nblocks ? block_tot[nblocks + t] : 0u,
                    hf = t < nblocks ? block_tot[2 * nblocks + t] : 0u;
     s_cnt[t] = h; s_unit[t] = hu; s_full[t] = hf;
-    for (uint32_t i = t; i < nblocks * MSM_UNIT_MAX; i += MSM_SCAN_BLOCK) s_bins[i] = (uint16_t)block_bins[i];
+    for (uint32_t i = t; i < nblocks * MSM_BINS; i += MSM_SCAN_BLOCK) s_bins[i] = (uint16_t)block_bins[i];
     __syncthreads();
-    if (t < MSM_UNIT_MAX) {   // per remainder length: the total over the blocks
+    if (t < MSM_BINS) {   // per remainder length / unit count: the total over the blocks
         uint32_t run = 0;
-        for (uint32_t blk = 0; blk < nblocks; blk++) run += s_bins[blk * MSM_UNIT_MAX + t];
+        for (uint32_t blk = 0; blk < nblocks; blk++) run += s_bins[blk * MSM_BINS + t];
         s_bintot[t] = run;
     }
     __syncthreads();
@@ -472,12 +480,13 @@ __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_totals_kernel(uint32_
     }
     if (t < nblocks) { block_tot[t] = s_cnt[t] - h; block_tot[nblocks + t] = s_unit[t] - hu; block_tot[2 * nblocks + t] = s_full[t] - hf; }
     if (t == MSM_SCAN_BLOCK - 1) { offsets[total] = s_cnt[t]; unit_off[total] = s_unit[t]; full_off[total] = s_full[t]; }
-    if (t < MSM_UNIT_MAX) {   // longest remainders first: base of length t, then the exclusive prefix over the blocks
+    if (t < MSM_BINS) {   // longest remainders (most partials) first: base of bin t in its list, then the exclusive prefix over the blocks
         uint32_t run = 0;
-        for (uint32_t r = MSM_UNIT_MAX - 1; r > t; r--) run += s_bintot[r];
+        const uint32_t top = t < (uint32_t)MSM_UNIT_MAX ? MSM_UNIT_MAX : MSM_BINS;
+        for (uint32_t r = top - 1; r > t; r--) run += s_bintot[r];
         for (uint32_t blk = 0; blk < nblocks; blk++) {
-            const uint32_t v = s_bins[blk * MSM_UNIT_MAX + t];
-            block_bins[blk * MSM_UNIT_MAX + t] = run;
+            const uint32_t v = s_bins[blk * MSM_BINS + t];
+            block_bins[blk * MSM_BINS + t] = run;
             run += v;
         }
     }
@@ -486,17 +495,20 @@ __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_totals_kernel(uint32_
 template <int DUMMY>
 __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_apply_kernel(const uint32_t* __restrict__ block_tot, const uint32_t* __restrict__ block_bins,
                                                                          const uint32_t* __restrict__ hist, const uint32_t* __restrict__ rem_rank,
+                                                                         const uint32_t* __restrict__ merge_rank,
                                                                          uint32_t nblocks, uint32_t total, uint32_t unit,
                                                                          uint32_t* __restrict__ offsets, uint32_t* __restrict__ unit_off,
-                                                                         uint32_t* __restrict__ full_off, uint32_t* __restrict__ rem_list) {
+                                                                         uint32_t* __restrict__ full_off, uint32_t* __restrict__ rem_list,
+                                                                         uint32_t* __restrict__ merge_list) {
     wave_priority<APK_PRIO_SORT>();
     const uint32_t i = blockIdx.x * MSM_SCAN_BLOCK + threadIdx.x;
     if (i >= total) return;
     offsets[i] += block_tot[blockIdx.x];
     unit_off[i] += block_tot[nblocks + blockIdx.x];
     full_off[i] += block_tot[2 * nblocks + blockIdx.x];
-    const uint32_t rem = hist[i] % unit;
-    if (rem) rem_list[block_bins[blockIdx.x * MSM_UNIT_MAX + rem] + rem_rank[i]] = i;
+    const uint32_t h = hist[i], hf = h / unit, rem = h - hf * unit, hu = hf + (rem ? 1u : 0u);
+    if (rem) rem_list[block_bins[blockIdx.x * MSM_BINS + rem] + rem_rank[i]] = i;
+    merge_list[block_bins[blockIdx.x * MSM_BINS + MSM_UNIT_MAX + min(hu, (uint32_t)MSM_MERGE_BINS - 1u)] + merge_rank[i]] = i;
 }
 
 // ---- bucket accumulation: one lane per work unit ---------------------------------------------------------
@@ -595,7 +607,9 @@ __device__ __forceinline__ void msm_combine_heavy_body(const XYZZ<FP, FeU<FP>>* 
 
 template <class FP>
 __global__ void __launch_bounds__(256) msm_combine_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ partial,
-                                                          const uint32_t* __restrict__ unit_off, uint32_t total_buckets,
+                                                          const uint32_t* __restrict__ unit_off,
+                                                          const uint32_t* __restrict__ merge_list,   // buckets by number of partials, or null: bucket order
+                                                          uint32_t total_buckets,
                                                           int lanes_log,  // lanes per bucket = 2^lanes_log <= MSM_COMBINE_LANES
                                                           uint32_t normal_blocks,
                                                           XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum) {
@@ -607,11 +621,13 @@ __global__ void __launch_bounds__(256) msm_combine_kernel(const XYZZ<FP, FeU<FP>
     }
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t LANES = 1u << lanes_log;
-    const uint32_t k = gid >> lanes_log;
+    const uint32_t slot = gid >> lanes_log;
     const uint32_t lane = gid & (LANES - 1);
+    uint32_t k = slot;
+    if (merge_list && slot < total_buckets) k = merge_list[slot];
     PT acc = PT::inf();
     uint32_t beg = 0, end = 0;
-    if (k < total_buckets) { beg = unit_off[k]; end = unit_off[k + 1]; }
+    if (slot < total_buckets) { beg = unit_off[k]; end = unit_off[k + 1]; }
     if (end - beg > MSM_HEAVY_UNITS) end = beg;   // skewed bucket: left to msm_combine_heavy_kernel
     for (uint32_t u = beg + lane; u < end; u += LANES) acc.add_lazy(partial[u]);
     // all lanes of the wave take part in every shuffle; groups with nothing to add see infinities
@@ -623,7 +639,7 @@ __global__ void __launch_bounds__(256) msm_combine_kernel(const XYZZ<FP, FeU<FP>
             if (lane < (uint32_t)d && n_units > (uint32_t)d) acc.add_lazy(o);
         }
     }
-    if (k < total_buckets && lane == 0 && unit_off[k + 1] - unit_off[k] <= MSM_HEAVY_UNITS) bucket_sum[k] = acc;
+    if (slot < total_buckets && lane == 0 && unit_off[k + 1] - unit_off[k] <= MSM_HEAVY_UNITS) bucket_sum[k] = acc;
 }
 
 // Skewed inputs (e.g. a Lagrange-basis commitment of a witness full of ones): a bucket with more than MSM_HEAVY_UNITS unit
@@ -803,24 +819,25 @@ __global__ void __launch_bounds__(256) msm_rowcol_hybrid_kernel(const XYZZ<FP, F
 // handful of lanes of a wave are live (255 additions cost ~20 k wave-instructions per row); here a wave of four lines does 19
 // addition-times for 4 x 255 additions (~14 k per row, ~8 k per column).  The chain is twice as long (19 dependent additions
 // instead of 3 + 5 short ones), so a lone proof keeps the tree form - the host picks per batch (run_msm_body).
-template <class FP>
+template <class FP, int LPL>   // LPL = lanes per line (16 or 8): fewer lanes = fewer idle shuffle levels, longer chains
 __global__ void __launch_bounds__(256) msm_rowcol_serial_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum, uint32_t nb, uint32_t rows,
                                                                 uint32_t cols, XYZZ<FP, FeU<FP>>* __restrict__ rc) {
     wave_priority<APK_PRIO_TAIL>();
     using PT = XYZZ<FP, FeU<FP>>;
+    constexpr uint32_t LINES = 256 / LPL;
     const uint32_t m = blockIdx.y;
-    const uint32_t line = blockIdx.x * 16 + (threadIdx.x >> 4);   // rows first, then columns; a wave holds four lines of one kind
-    const uint32_t j = threadIdx.x & 15;
+    const uint32_t line = blockIdx.x * LINES + (threadIdx.x / LPL);   // rows first, then columns; a wave holds 64 / LPL lines of one kind
+    const uint32_t j = threadIdx.x % LPL;
     const PT* src = bucket_sum + (size_t)m * nb;
     PT acc = PT::inf();
     if (line < rows) {
-        for (uint32_t lo = j; lo < cols; lo += 16) acc.add_lazy(src[line * cols + lo]);
+        for (uint32_t lo = j; lo < cols; lo += LPL) acc.add_lazy(src[line * cols + lo]);
     } else if (line < rows + cols) {
         const uint32_t col = line - rows;
-        for (uint32_t hi = j; hi < rows; hi += 16) acc.add_lazy(src[hi * cols + col]);
+        for (uint32_t hi = j; hi < rows; hi += LPL) acc.add_lazy(src[hi * cols + col]);
     }
-    for (int d = 8; d >= 1; d >>= 1) {
-        PT o = shfl_down_point<PT>(acc, d, 16);
+    for (int d = LPL / 2; d >= 1; d >>= 1) {
+        PT o = shfl_down_point<PT>(acc, d, LPL);
         if (j < (uint32_t)d) acc.add_lazy(o);
     }
     if (j == 0 && line < rows + cols) rc[(size_t)m * (rows + cols) + line] = acc;
