@@ -165,6 +165,7 @@ class CurveBackend : public Backend {
     uint32_t cci_[APK_MAX_COMMITMENTS] = {0, 0};
     int c_ = 0, W_ = 0;
     MsmWindows win_{};
+    MsmPartCfg part_cfg_{};   // two-level sort: bit layout of the packed entries, partition count (choose_window)
     uint32_t msm_G_max_ = 256;
     bool msm_only_ = false;
     uint32_t msm_bases_ = 0;  // bases the MSM workspaces are sized for
@@ -409,7 +410,7 @@ class CurveBackend : public Backend {
         uint32_t G = cdiv(maxlen, slice_eff ? slice_eff : 2048u);
         if (G < 1) G = 1;
         if (G > msm_G_max_) G = msm_G_max_;
-        dim3 gd(G, a.batch);
+        dim3 gd(G, a.batch);   // (the two-level sort re-cuts its slices below)
         const size_t lds = digits_lds_bytes();
         static const int dth = env_int("APK_MSM_DIGITS_THREADS", MSM_DIGITS_THREADS, 64, MSM_DIGITS_THREADS) & ~63;   // whole waves, <= the launch bound
         // Are other proofs keeping the GPU busy?  Then nobody waits for this batch's reduction chain and the instruction-lean
@@ -437,23 +438,54 @@ class CurveBackend : public Backend {
         // (a lone single MSM was 0.49 against 0.47 ms with the first version - and 0.468 against 0.473 once the partition scan
         // ran eight lanes per pair and the second-level tile let two partitions share a CU: no exception for it any more)
         const bool sort2_want = sort2_env >= 0 ? sort2_env != 0 : T.n_bases >= 65536u;
-        const uint32_t P = NB_ / MSM_PART_BUCKETS;
-        const bool sort2 = sort2_want && NB_ >= 4 * MSM_PART_BUCKETS && P <= MSM_PART_MAX && s.sort_tmp.p &&
-                           (uint64_t)T.n_bases * W_ <= (1ull << MSM_PART_IDX_BITS) &&
-                           (uint64_t)a.batch * G * P * 2 + (uint64_t)a.batch * P <= (uint64_t)total_buckets * msm_G_max_;
+        // Round 4: the packed entry's layout follows the context (MsmPartCfg, part_cfg_): the table index takes the bits it needs
+        // and the partitions shrink until one fits the second level's LDS tile - BLS12-381 2^21 x 16 windows (26 index bits,
+        // 2 048 partitions of 16 buckets) sorts in two levels as well.  The first level's slices are cut so that a slice's entries
+        // fit its LDS stage.
+        const MsmPartCfg& pc = part_cfg_;
+        const uint32_t P = pc.P;
+        uint32_t G2 = G;
+        {
+            uint32_t sl2 = slice_eff ? slice_eff : 2048u;
+            if ((uint64_t)sl2 * W_ > MSM_PART_STAGE) sl2 = MSM_PART_STAGE / (uint32_t)W_;
+            G2 = cdiv(maxlen, sl2);
+            if (G2 < 1) G2 = 1;
+        }
+        static const int small_scan_env = env_int("APK_MSM_PART_SMALL_SCAN", 1, 0, 1);   // 0: always the three-launch scan (tests)
+        const bool small_scan = small_scan_env && a.batch * P <= 2048u && G2 <= 128u;
+        const bool sort2 = sort2_want && P >= 4 && s.sort_tmp.p && G2 <= 1024u &&
+                           (uint64_t)a.batch * G2 * P * 2 + (uint64_t)a.batch * P * (1 + MSM_PART_CHUNKS) <= (uint64_t)total_buckets * msm_G_max_;
+        if (sort2) { G = G2; gd = dim3(G, a.batch); }
         uint32_t* pcounts = ptr<uint32_t>(s.counts);
         uint32_t* runstart = pcounts + (size_t)a.batch * G * P;
         uint32_t* ptot = runstart + (size_t)a.batch * G * P;
+        uint32_t* csum = ptot + (size_t)a.batch * P;
         if (sort2) {
             // LDS stage of the first level: a slice's entries (<= slice x W words; slices that do not fit scatter in HBM)
             const uint32_t per_slice = cdiv(maxlen, G);
             uint32_t stage_cap = per_slice * (uint32_t)W_;
-            if (stage_cap > 36864u) stage_cap = 36864u;                      // 144 KiB of the CU's 160
-            msm_part_kernel<FRP, false><<<gd, dth, 0, st>>>(a, win_, NB_, T.n_bases, G, pcounts, nullptr, nullptr, 0);
+            if (stage_cap > MSM_PART_STAGE) stage_cap = MSM_PART_STAGE;
+            msm_part_kernel<FRP, false><<<gd, dth, 0, st>>>(a, win_, pc, NB_, T.n_bases, G, pcounts, nullptr, nullptr, 0);
             KCHK();
-            msm_part_scan_kernel<0><<<1, 1024, 0, st>>>(pcounts, runstart, ptot, a.batch, G, P);
-            KCHK();
-            msm_part_kernel<FRP, true><<<gd, dth, (size_t)stage_cap * 4, st>>>(a, win_, NB_, T.n_bases, G, pcounts, runstart, ptr<uint32_t>(s.sort_tmp),
+            if (small_scan) {
+                msm_part_scan_kernel<0><<<1, 1024, 0, st>>>(pcounts, runstart, ptot, a.batch, G, P);
+                KCHK();
+            } else {
+                const dim3 sg(cdiv(a.batch * P, 64), MSM_PART_CHUNKS / 4);
+                msm_part_tot_kernel<0><<<sg, 256, 0, st>>>(pcounts, csum, a.batch, G, P);
+                KCHK();
+                msm_part_base_kernel<0><<<1, 1024, 0, st>>>(csum, ptot, a.batch * P);
+                KCHK();
+                msm_part_runs_kernel<0><<<sg, 256, 0, st>>>(pcounts, csum, runstart, a.batch, G, P);
+                KCHK();
+            }
+            MsmPartCfg pc1 = pc;
+            {   // lanes per run of the copy-out: the power of two at or above the mean run, 8..64
+                const uint32_t mean_run = stage_cap / P + 1;
+                pc1.run_lanes = 8;
+                while (pc1.run_lanes < 64 && pc1.run_lanes < mean_run) pc1.run_lanes <<= 1;
+            }
+            msm_part_kernel<FRP, true><<<gd, dth, (size_t)stage_cap * 4, st>>>(a, win_, pc1, NB_, T.n_bases, G, pcounts, runstart, ptr<uint32_t>(s.sort_tmp),
                                                                                stage_cap);
             KCHK();
             // tile of the second level: the mean partition + 15 % (uniform scalars stay within 2 %); at 2^17 that is 74 KiB, so two
@@ -461,7 +493,7 @@ class CurveBackend : public Backend {
             // above it (skewed scalars) scatter in HBM.
             uint32_t tile_cap = (uint32_t)(entries / ((uint64_t)a.batch * P)) + (uint32_t)(entries / ((uint64_t)a.batch * P)) / 7u + 256u;
             if (tile_cap > MSM_PART_TILE) tile_cap = MSM_PART_TILE;
-            msm_part_sort_kernel<0><<<dim3(P, a.batch), 1024, (size_t)tile_cap * 4, st>>>(ptr<uint32_t>(s.sort_tmp), runstart, ptot, G, P, NB_,
+            msm_part_sort_kernel<0><<<dim3(P, a.batch), 1024, (size_t)tile_cap * 4, st>>>(ptr<uint32_t>(s.sort_tmp), runstart, ptot, pc, G, NB_,
                                                                                           ptr<uint32_t>(s.hist), ptr<uint32_t>(s.sorted), tile_cap);
             KCHK();
         } else if (APK_PHASE(1)) {
@@ -712,8 +744,7 @@ class CurveBackend : public Backend {
         CHK(s.full_off.alloc((size_t)(tb + 1) * 4)); CHK(s.rem_rank.alloc((size_t)(tb + 1) * 4)); CHK(s.rem_list.alloc((size_t)(tb + 1) * 4));
         CHK(s.counts.alloc((size_t)tb * msm_G_max_ * 4));
         CHK(s.sorted.alloc(entries * 4));
-        if (env_int("APK_MSM_SORT2", -1, -1, 1) != 0 && NB_ >= 4 * MSM_PART_BUCKETS &&
-            (uint64_t)msm_bases_ * W_ <= (1ull << MSM_PART_IDX_BITS) && (msm_bases_ >= 65536u || env_int("APK_MSM_SORT2", -1, -1, 1) == 1))
+        if (env_int("APK_MSM_SORT2", -1, -1, 1) != 0 && part_cfg_.P >= 4 && (msm_bases_ >= 65536u || env_int("APK_MSM_SORT2", -1, -1, 1) == 1))
             CHK(s.sort_tmp.alloc(entries * 4));   // two-level sort: packed entries between the levels
         CHK(s.partial.alloc((entries / MSM_UNIT_MIN + tb) * sizeof(PtU)));
         CHK(s.bucket_sum.alloc((size_t)tb * sizeof(PtU)));
@@ -805,6 +836,24 @@ class CurveBackend : public Backend {
             win_.off[W_] = (uint16_t)o;
         }
         if ((uint64_t)msm_bases_ * W_ >= (1ull << 31)) { set_error("bases*windows exceeds 2^31 table entries"); return APK_ERR_ARG; }
+        {   // two-level sort (kernels_msm.h MsmPartCfg): index bits as needed; partitions of <= 256 buckets, halved until the mean
+            // partition of a full-length MSM holds <= APK_MSM_PART_TARGET entries (16 Ki: a 64 KiB tile + slack, two workgroups
+            // per CU), and as far as the bits left beside the index allow.  P = 0: the context's MSMs do not take the two-level sort.
+            part_cfg_ = MsmPartCfg{};
+            uint32_t idx_bits = 1;
+            while (((uint64_t)1 << idx_bits) < (uint64_t)msm_bases_ * W_) idx_bits++;
+            const uint32_t target = (uint32_t)env_int("APK_MSM_PART_TARGET", 16384, 1024, MSM_PART_TILE - 4096);
+            const uint64_t per_msm = (uint64_t)msm_bases_ * W_;
+            int pb_log = c_ - 1 < 8 ? c_ - 1 : 8;
+            if (idx_bits < 31 && pb_log > (int)(31 - idx_bits)) pb_log = 31 - idx_bits;
+            while (pb_log > 2 && (NB_ >> pb_log) < MSM_PART_MAX && per_msm / (NB_ >> pb_log) > target) pb_log--;
+            const int pb_env = env_int("APK_MSM_PART_PBLOG", 0, 0, 8);
+            if (pb_env && pb_env < c_ - 1 && idx_bits + pb_env <= 31 && (NB_ >> pb_env) <= MSM_PART_MAX) pb_log = pb_env;
+            if (idx_bits <= 29 && pb_log >= 2 && idx_bits + pb_log <= 31 && (NB_ >> pb_log) >= 4 && (NB_ >> pb_log) <= MSM_PART_MAX &&
+                per_msm / (NB_ >> pb_log) <= MSM_PART_TILE - 2048) {
+                part_cfg_.idx_bits = idx_bits; part_cfg_.pb_log = (uint32_t)pb_log; part_cfg_.P = NB_ >> pb_log; part_cfg_.run_lanes = 64;
+            }
+        }
         return APK_OK;
     }
 
@@ -829,7 +878,7 @@ class CurveBackend : public Backend {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)digits_lds_bytes()));
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)digits_lds_bytes()));
         }
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 36864 * 4));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_STAGE * 4));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_sort_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_TILE * 4));
         DevBuf srs;
         CHK(srs.alloc(count * sizeof(Aff)));
@@ -928,7 +977,7 @@ class CurveBackend : public Backend {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)digits_lds_bytes()));
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)digits_lds_bytes()));
         }
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 36864 * 4));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_STAGE * 4));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_sort_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_TILE * 4));
         // proving slots
         int nslots = d->slots > 0 ? d->slots : 1;

@@ -182,22 +182,29 @@ __global__ void __launch_bounds__(256) msm_colscan_kernel(uint32_t* __restrict__
 // ---- two-level counting sort (run_msm_body, APK_MSM_SORT2) ----------------------------------------------------------------
 // The one-level sort above scatters every (digit, point) pair straight to its bucket: a slice of 2 048 scalars has one entry per
 // bucket on average, so its 32 k stores are 32 k isolated 4-byte writes, and tools/knockout.py prices that pass at 8 % of an MSM
-// at saturation for 1 % of its instructions.  Here the pairs are first dealt to PARTITIONS of 256 neighbouring buckets
-// (msm_part_kernel: a slice writes ~250 pairs per partition, side by side), then one workgroup per partition counting-sorts its
-// ~16 k pairs in LDS order and writes them out (msm_part_sort_kernel: all stores into one 64 KiB window, from one XCD).  The
-// second level also produces the per-bucket counts, so the column scan goes.  Intermediate pairs carry their bucket id
-// (8 bytes); both levels use the same compact numbering, so a partition's pairs occupy the same index range before and after.
-constexpr uint32_t MSM_PART_BUCKETS = 256;
-constexpr uint32_t MSM_PART_MAX = 512;      // partitions per MSM (nb <= 2^17)
+// at saturation for 1 % of its instructions.  Here the pairs are first dealt to PARTITIONS of 2^pb_log neighbouring buckets
+// (msm_part_kernel: a slice writes its pairs of one partition side by side), then one workgroup per partition counting-sorts its
+// ~16 k pairs in LDS order and writes them out (msm_part_sort_kernel).  The second level also produces the per-bucket counts, so
+// the column scan goes.  Both levels use the same compact numbering, so a partition's pairs occupy the same index range before
+// and after.
 // Every scatter of the two levels happens INSIDE an LDS tile, and whole lines leave the tile (a wave store whose lanes hit 64
 // different lines costs 64 L2 requests however near the lines are: DESIGN section 5).  Intermediate entries are packed words:
-// bits 0..21 the table index j * n_max + i, bits 22..29 the bucket's low 8 bits, bit 31 the sign - which limits the form to
-// W * n_max <= 2^22 (2^17 bases at 16 windows); larger MSMs keep the one-level sort.
-constexpr uint32_t MSM_PART_IDX_BITS = 22;
-constexpr uint32_t MSM_PART_TILE = 24576;   // entries of a partition sorted in LDS (96 KiB); larger (skewed) partitions scatter in HBM
+// bits [0, idx_bits) the table index j * n_max + i, bits [idx_bits, idx_bits + pb_log) the bucket's position inside its partition,
+// bit 31 the sign.  Round 3 fixed idx_bits = 22 and pb_log = 8 (2^17 bases at 16 windows); round 4 picks them per context
+// (MsmPartCfg): the index takes the bits it needs (26 for BLS12-381 2^21 x 16 windows - BASELINE configs[4]) and the partition
+// count grows until a partition's entries fit the second level's LDS tile (2 048 partitions of 16 buckets there).
+constexpr uint32_t MSM_PART_MAX = 2048;     // partitions per MSM
+constexpr uint32_t MSM_PART_TILE = 36864;   // most entries of a partition sorted in LDS (144 KiB); larger (skewed) partitions scatter in HBM
+constexpr uint32_t MSM_PART_STAGE = 35584;  // most entries of a slice staged in LDS by the first level (139 KiB beside its 20 KiB of cursors)
+constexpr uint32_t MSM_PART_COUNTERS = 1024; // second level: counters per workgroup (wave-private sets while 2^pb_log <= 64)
+struct MsmPartCfg {
+    uint32_t idx_bits, pb_log;   // idx_bits + pb_log <= 31
+    uint32_t P;                  // nb >> pb_log
+    uint32_t run_lanes;          // first level's copy-out: lanes per (slice, partition) run (8..64, a power of two >= the mean run)
+};
 
 template <class FR, bool SCATTER>
-__global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part_kernel(MsmBatchArgs a, MsmWindows win, uint32_t nb, uint32_t n_max, uint32_t G,
+__global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part_kernel(MsmBatchArgs a, MsmWindows win, MsmPartCfg pc, uint32_t nb, uint32_t n_max, uint32_t G,
                                                                      uint32_t* __restrict__ pcounts,         // [batch][G][P]   (!SCATTER: out, SCATTER: in)
                                                                      const uint32_t* __restrict__ runstart,  // [batch][G][P]   (SCATTER: in)
                                                                      uint32_t* __restrict__ tmp,
@@ -208,17 +215,26 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part_kernel(MsmBatchAr
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t* stage = reinterpret_cast<uint32_t*>(smem_raw);
     const uint32_t g = blockIdx.x, b = blockIdx.y;
-    const uint32_t P = nb / MSM_PART_BUCKETS;
+    const uint32_t P = pc.P, pb_log = pc.pb_log, pb_mask = (1u << pc.pb_log) - 1u;
     const size_t row = ((size_t)b * G + g) * P;
     bool staged = false;
     if (SCATTER) {
-        // slice-local exclusive prefix of this slice's partition counts (the count pass left them in pcounts)
+        // slice-local exclusive prefix of this slice's partition counts (the count pass left them in pcounts): one wave, a
+        // contiguous chunk per lane, a shuffle scan over the lanes' sums
         for (uint32_t k = threadIdx.x; k < P; k += blockDim.x) cur[k] = pcounts[row + k];
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t run = 0;
-            for (uint32_t k = 0; k < P; k++) { lstart[k] = run; run += cur[k]; }
-            lstart[P] = run;
+        if (threadIdx.x < 64) {
+            const uint32_t lane = threadIdx.x, per = (P + 63u) / 64u, k0 = lane * per;
+            uint32_t sum = 0;
+            for (uint32_t i = 0; i < per; i++) if (k0 + i < P) sum += cur[k0 + i];
+            uint32_t inc = sum;
+            for (uint32_t d = 1; d < 64; d <<= 1) {
+                const uint32_t v = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += v;
+            }
+            uint32_t run = inc - sum;
+            for (uint32_t i = 0; i < per; i++) if (k0 + i < P) { lstart[k0 + i] = run; run += cur[k0 + i]; }
+            if (lane == 63) lstart[P] = inc;
         }
         __syncthreads();
         staged = lstart[P] <= stage_cap;                     // uniform
@@ -255,10 +271,10 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part_kernel(MsmBatchAr
                 else carry = 0;
                 if (d != 0) {
                     const uint32_t k = d - 1;
-                    if (!SCATTER) atomicAdd(&cur[k / MSM_PART_BUCKETS], 1u);
+                    if (!SCATTER) atomicAdd(&cur[k >> pb_log], 1u);
                     else {
-                        const uint32_t pos = atomicAdd(&cur[k / MSM_PART_BUCKETS], 1u);
-                        const uint32_t e = ((uint32_t)j * n_max + base_idx) | ((k % MSM_PART_BUCKETS) << MSM_PART_IDX_BITS) | (neg << 31);
+                        const uint32_t pos = atomicAdd(&cur[k >> pb_log], 1u);
+                        const uint32_t e = ((uint32_t)j * n_max + base_idx) | ((k & pb_mask) << pc.idx_bits) | (neg << 31);
                         if (staged) stage[pos] = e; else tmp[pos] = e;
                     }
                 }
@@ -270,13 +286,16 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part_kernel(MsmBatchAr
         __syncthreads();
         for (uint32_t k = threadIdx.x; k < P; k += blockDim.x) pcounts[row + k] = cur[k];
     } else if (staged) {
-        // the stage holds the slice's entries in partition order: copy each partition's run to its place, neighbours together
+        // the stage holds the slice's entries in partition order: copy each partition's run to its place, neighbours together;
+        // run_lanes lanes per run (a wave per run at 2^17: ~250 entries; sixteen lanes at 2^21 x 2 048 partitions: ~17 entries)
         __syncthreads();
+        const uint32_t L = pc.run_lanes, R = 64u / L;
         const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, waves = blockDim.x >> 6;
-        for (uint32_t pp = wave; pp < P; pp += waves) {       // a wave per partition run: its lanes write neighbours
+        const uint32_t sub = lane / L, sl = lane % L;
+        for (uint32_t pp = wave * R + sub; pp < P; pp += waves * R) {
             const uint32_t from = lstart[pp], cnt = lstart[pp + 1] - from;
             uint32_t* dst = tmp + runstart[row + pp];
-            for (uint32_t l = lane; l < cnt; l += 64u) dst[l] = stage[from + l];
+            for (uint32_t l = sl; l < cnt; l += L) dst[l] = stage[from + l];
         }
     }
 }
@@ -284,6 +303,7 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part_kernel(MsmBatchAr
 // one workgroup: first slot of every (msm, partition, slice) run in the order (msm, partition, slice), and the partition totals.
 // Eight lanes share a (msm, partition) pair - each walks an eighth of the slices - so a lane has G/8 loads in flight instead
 // of a serial walk over all G (the first version, one lane per pair, took 38 us of a lone batch's 128 us sort).
+// For batch * P <= 2048 pairs and a few dozen slices (2^16 .. 2^17 bases); larger sorts take the three launches below.
 template <int DUMMY>
 __global__ void __launch_bounds__(1024) msm_part_scan_kernel(const uint32_t* __restrict__ pcounts, uint32_t* __restrict__ runstart,
                                                             uint32_t* __restrict__ ptot, uint32_t batch, uint32_t G, uint32_t P) {
@@ -348,44 +368,138 @@ __global__ void __launch_bounds__(1024) msm_part_scan_kernel(const uint32_t* __r
     }
 }
 
+// The same scan for any size (up to MSM_MAX_BATCH * MSM_PART_MAX pairs, ~1 000 slices: BLS12-381 2^21), in three launches whose
+// lanes stand for 64 consecutive (msm, partition) pairs - so every load and store is a whole 256-byte row of the counter array -
+// and whose waves each walk one of MSM_PART_CHUNKS chunks of the slices:
+//   msm_part_tot_kernel   csum[c][q] = entries of pair q in the slices of chunk c
+//   msm_part_base_kernel  one workgroup: ptot[q], the exclusive scan over q, csum[c][q] := first slot of pair q's chunk c
+//   msm_part_runs_kernel  runstart of every (pair, slice)
+constexpr uint32_t MSM_PART_CHUNKS = 8;
+template <int DUMMY>
+__global__ void __launch_bounds__(256) msm_part_tot_kernel(const uint32_t* __restrict__ pcounts, uint32_t* __restrict__ csum, uint32_t batch,
+                                                           uint32_t G, uint32_t P) {
+    wave_priority<APK_PRIO_SORT>();
+    const uint32_t n = batch * P, q = blockIdx.x * 64u + (threadIdx.x & 63u), c = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (q >= n) return;
+    const uint32_t gper = (G + MSM_PART_CHUNKS - 1u) / MSM_PART_CHUNKS, g0 = min(c * gper, G), g1 = min(g0 + gper, G);
+    const uint32_t b = q / P, p = q % P;
+    const uint32_t* col = pcounts + (size_t)b * G * P + p;
+    uint32_t sum = 0, g = g0;
+    for (; g + 4 <= g1; g += 4) {      // four rows in flight
+        const uint32_t v0 = col[(size_t)g * P], v1 = col[(size_t)(g + 1) * P], v2 = col[(size_t)(g + 2) * P], v3 = col[(size_t)(g + 3) * P];
+        sum += v0 + v1 + v2 + v3;
+    }
+    for (; g < g1; g++) sum += col[(size_t)g * P];
+    csum[(size_t)c * n + q] = sum;
+}
+template <int DUMMY>
+__global__ void __launch_bounds__(1024) msm_part_base_kernel(uint32_t* __restrict__ csum, uint32_t* __restrict__ ptot, uint32_t n) {
+    wave_priority<APK_PRIO_SORT>();
+    __shared__ uint32_t s_sum[1024];
+    const uint32_t t = threadIdx.x;
+    constexpr uint32_t PER = MSM_MAX_BATCH * MSM_PART_MAX / 1024;      // 8 consecutive pairs per thread
+    uint32_t tot[PER], mine = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < PER; i++) {
+        const uint32_t q = t * PER + i;
+        uint32_t v = 0;
+        if (q < n) for (uint32_t c = 0; c < MSM_PART_CHUNKS; c++) v += csum[(size_t)c * n + q];
+        tot[i] = v;
+        mine += v;
+        if (q < n) ptot[q] = v;
+    }
+    s_sum[t] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = t >= d ? s_sum[t - d] : 0u;
+        __syncthreads();
+        s_sum[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_sum[t] - mine;
+#pragma unroll
+    for (uint32_t i = 0; i < PER; i++) {
+        const uint32_t q = t * PER + i;
+        if (q < n) {
+            uint32_t r2 = run;
+            for (uint32_t c = 0; c < MSM_PART_CHUNKS; c++) { const uint32_t v = csum[(size_t)c * n + q]; csum[(size_t)c * n + q] = r2; r2 += v; }
+        }
+        run += tot[i];
+    }
+}
+template <int DUMMY>
+__global__ void __launch_bounds__(256) msm_part_runs_kernel(const uint32_t* __restrict__ pcounts, const uint32_t* __restrict__ csum,
+                                                            uint32_t* __restrict__ runstart, uint32_t batch, uint32_t G, uint32_t P) {
+    wave_priority<APK_PRIO_SORT>();
+    const uint32_t n = batch * P, q = blockIdx.x * 64u + (threadIdx.x & 63u), c = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (q >= n) return;
+    const uint32_t gper = (G + MSM_PART_CHUNKS - 1u) / MSM_PART_CHUNKS, g0 = min(c * gper, G), g1 = min(g0 + gper, G);
+    const uint32_t b = q / P, p = q % P;
+    const size_t col = (size_t)b * G * P + p;
+    uint32_t run = csum[(size_t)c * n + q], g = g0;
+    for (; g + 4 <= g1; g += 4) {
+        const uint32_t v0 = pcounts[col + (size_t)g * P], v1 = pcounts[col + (size_t)(g + 1) * P], v2 = pcounts[col + (size_t)(g + 2) * P],
+                       v3 = pcounts[col + (size_t)(g + 3) * P];
+        runstart[col + (size_t)g * P] = run; run += v0;
+        runstart[col + (size_t)(g + 1) * P] = run; run += v1;
+        runstart[col + (size_t)(g + 2) * P] = run; run += v2;
+        runstart[col + (size_t)(g + 3) * P] = run; run += v3;
+    }
+    for (; g < g1; g++) { runstart[col + (size_t)g * P] = run; run += pcounts[col + (size_t)g * P]; }
+}
+
 // grid (P, batch): counting sort of one partition's entries by bucket inside an LDS tile, whole lines out;
-// hist[b*nb + k] = entries of bucket k
+// hist[b*nb + k] = entries of bucket k.  With few buckets per partition (2^pb_log <= 64: the large sorts) every wave counts into
+// a set of its own - 1 024 lanes on 16 or 32 counters serialise on the LDS atomics otherwise - and the sets are laid out
+// [set][bucket] (a wave's lanes spread over the banks) but scanned bucket-major, so a bucket's entries stay together.
 template <int DUMMY>
 __global__ void __launch_bounds__(1024) msm_part_sort_kernel(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ runstart,
-                                                           const uint32_t* __restrict__ ptot, uint32_t G, uint32_t P, uint32_t nb,
+                                                           const uint32_t* __restrict__ ptot, MsmPartCfg pc, uint32_t G, uint32_t nb,
                                                            uint32_t* __restrict__ hist, uint32_t* __restrict__ sorted,
                                                            uint32_t tile_cap) {              // entries the LDS tile of this launch holds
     wave_priority<APK_PRIO_SORT>();
-    __shared__ uint32_t cnt[MSM_PART_BUCKETS], cur[MSM_PART_BUCKETS];
+    __shared__ uint32_t cnt[MSM_PART_COUNTERS], cur[MSM_PART_COUNTERS];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t* tile = reinterpret_cast<uint32_t*>(smem_raw);
     const uint32_t p = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const uint32_t P = pc.P, PB = 1u << pc.pb_log, pb_mask = PB - 1u;
+    const uint32_t sets_log = pc.pb_log > 6 ? 0u : min(4u, 10u - pc.pb_log);        // sets x buckets <= 1 024; one shared set from 128 buckets up
+    const uint32_t SETS = 1u << sets_log, NC = PB << sets_log;
+    const uint32_t set_base = ((t >> 6) & (SETS - 1u)) << pc.pb_log;                 // this wave's counters
     const uint32_t first = runstart[(size_t)b * G * P + p];          // slice 0's run opens the partition
     const uint32_t n = ptot[b * P + p];
-    constexpr uint32_t KEEP = ((1u << MSM_PART_IDX_BITS) - 1u) | 0x80000000u;
-    if (t < MSM_PART_BUCKETS) cnt[t] = 0u;
+    const uint32_t KEEP = ((1u << pc.idx_bits) - 1u) | 0x80000000u;
+    if (t < NC) cnt[t] = 0u;
     __syncthreads();
-    for (uint32_t i = t; i < n; i += blockDim.x) atomicAdd(&cnt[(tmp[first + i] >> MSM_PART_IDX_BITS) % MSM_PART_BUCKETS], 1u);
+    for (uint32_t i = t; i < n; i += blockDim.x) atomicAdd(&cnt[set_base + ((tmp[first + i] >> pc.idx_bits) & pb_mask)], 1u);
     __syncthreads();
+    // thread t < NC stands for (bucket t / SETS, set t % SETS): inclusive scan in that order
     uint32_t mine = 0;
-    if (t < MSM_PART_BUCKETS) { mine = cnt[t]; cur[t] = mine; }
+    const uint32_t my_at = ((t & (SETS - 1u)) << pc.pb_log) + (t >> sets_log);
+    if (t < NC) { mine = cnt[my_at]; cur[t] = mine; }
     __syncthreads();
-    for (uint32_t d = 1; d < MSM_PART_BUCKETS; d <<= 1) {
+    for (uint32_t d = 1; d < NC; d <<= 1) {
         uint32_t v = 0;
-        if (t < MSM_PART_BUCKETS && t >= d) v = cur[t - d];
+        if (t < NC && t >= d) v = cur[t - d];
         __syncthreads();
-        if (t < MSM_PART_BUCKETS) cur[t] += v;
+        if (t < NC) cur[t] += v;
         __syncthreads();
     }
     const bool in_lds = n <= tile_cap;                               // uniform
-    if (t < MSM_PART_BUCKETS) {
-        hist[(size_t)b * nb + p * MSM_PART_BUCKETS + t] = mine;
-        cur[t] = (in_lds ? 0u : first) + cur[t] - mine;              // exclusive prefix inside the partition
+    uint32_t incl = 0, before = 0;
+    if (t < NC) {
+        incl = cur[t];
+        if ((t & (SETS - 1u)) == SETS - 1u) before = t >= SETS ? cur[t - SETS] : 0u;      // last set of a bucket: the bucket's total
+    }
+    __syncthreads();
+    if (t < NC) {
+        if ((t & (SETS - 1u)) == SETS - 1u) hist[(size_t)b * nb + p * PB + (t >> sets_log)] = incl - before;
+        cnt[my_at] = (in_lds ? 0u : first) + incl - mine;            // exclusive prefix inside the partition: the set's cursor
     }
     __syncthreads();
     for (uint32_t i = t; i < n; i += blockDim.x) {
         const uint32_t e = tmp[first + i];
-        const uint32_t pos = atomicAdd(&cur[(e >> MSM_PART_IDX_BITS) % MSM_PART_BUCKETS], 1u);
+        const uint32_t pos = atomicAdd(&cnt[set_base + ((e >> pc.idx_bits) & pb_mask)], 1u);
         if (in_lds) tile[pos] = e & KEEP; else sorted[pos] = e & KEEP;
     }
     if (in_lds) {

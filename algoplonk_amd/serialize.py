@@ -5,7 +5,8 @@ slices are gnark's `WriteTo` outputs; `DeserializeCompiledCircuit` reverses it. 
 (same names) and the layers underneath.  WHAT IS INTEROPERABLE WITH A GO PROCESS TODAY: the gob envelope and the kzg SRS
 encodings (pinned by the reference's own files).  What is NOT: the plonk Vk / Pk blobs (restated from memory, unpinned - and
 gnark's list very likely also carries the KZG verifying key's precomputed pairing lines `Kzg.Lines` between Kzg.G2[1] and
-CommitmentConstraintIndexes, which this writer does not emit and this reader refuses, loudly, as trailing bytes) and the
+CommitmentConstraintIndexes, which this writer does not emit; the reader skips a block of exactly that size when the key's
+length fits no other way, and says so in `vk.kzg_lines_bytes`) and the
 constraint system (own tagged encoding; gnark's file is CBOR + intcomp-compressed blocks).  Files written
 here are therefore read back HERE; a circuit compiled by Go reaches libapk through the cgo shim, not a file.
 
@@ -249,6 +250,14 @@ def write_plonk_vk(vk: plonk.VerifyingKey) -> bytes:
     return out
 
 
+# kzg.VerifyingKey.Lines (gnark-crypto >= 0.12: the precomputed pairing lines of G2[0] and G2[1], [2][2][len(LoopCounter) - 1]
+# LineEvaluationAff{R0, R1 E2}, written as raw Fp words without a length prefix) [UPSTREAM, sizes from memory: unpinned].  This
+# package neither writes nor uses them (apk_verify derives its own lines); the reader TOLERATES a block of exactly this size
+# between Kzg.G2[1] and CommitmentConstraintIndexes, because a key written by gnark (tools/gnark_dump's vk_write_to) very likely
+# carries it - and only when the key's total length fits that layout exactly; it reports what it did in `vk.kzg_lines_bytes`.
+KZG_LINES_BYTES = {"bn254": 2 * 2 * 65 * 4 * 32, "bls12_381": 2 * 2 * 63 * 4 * 48}
+
+
 def read_plonk_vk(cv: ecc.ID, r: io.BytesIO) -> plonk.VerifyingKey:
     fr = lambda: int.from_bytes(r.read(32), "big")
     g1 = lambda: setup.decompress_g1(cv, r.read(cv.fp_bytes))
@@ -263,12 +272,28 @@ def read_plonk_vk(cv: ecc.ID, r: io.BytesIO) -> plonk.VerifyingKey:
     kg1 = g1()
     w = 2 * cv.fp_bytes
     g2 = _g2_decompress(cv, r.read(w)) + _g2_decompress(cv, r.read(w))
-    (nc,) = struct.unpack(">I", r.read(4))
+    # with or without Kzg.Lines: the layout whose CommitmentConstraintIndexes list (u32 count + count x u64; one index per Qcp)
+    # is well formed at its place.  Without the block the count word sits right here.
+    here = r.tell()
+    lines_bytes = 0
+    head = r.read(4)
+    plain_ok = len(head) == 4 and struct.unpack(">I", head)[0] == nq
+    if not plain_ok:
+        r.seek(here + KZG_LINES_BYTES[cv.name])
+        head2 = r.read(4)
+        if len(head2) == 4 and struct.unpack(">I", head2)[0] == nq:
+            lines_bytes = KZG_LINES_BYTES[cv.name]
+        else:
+            raise ValueError("plonk verifying key: no CommitmentConstraintIndexes list of %d entries after Kzg.G2 (with or without a "
+                             "%d-byte Kzg.Lines block): the plonk key layout here is unpinned" % (nq, KZG_LINES_BYTES[cv.name]))
+    nc = nq
     cci = [struct.unpack(">Q", r.read(8))[0] for _ in range(nc)]
     if size == 0 or size & (size - 1) or size_inv * size % cv.r != 1 or pow(gen, size, cv.r) != 1:
         raise ValueError("plonk verifying key: inconsistent domain fields")
-    return plonk.VerifyingKey(curve=cv, Size=size, SizeInv=size_inv, Generator=gen, CosetShift=shift, NbPublicVariables=nbp, Ql=ql, Qr=qr,
-                              Qm=qm, Qo=qo, Qk=qk, S=S, Qcp=qcp, CommitmentConstraintIndexes=cci, KzgG1=kg1, tau=None, KzgG2=g2)
+    vk = plonk.VerifyingKey(curve=cv, Size=size, SizeInv=size_inv, Generator=gen, CosetShift=shift, NbPublicVariables=nbp, Ql=ql, Qr=qr,
+                            Qm=qm, Qo=qo, Qk=qk, S=S, Qcp=qcp, CommitmentConstraintIndexes=cci, KzgG1=kg1, tau=None, KzgG2=g2)
+    vk.kzg_lines_bytes = lines_bytes          # 0, or the size of the block that was skipped (not interpreted)
+    return vk
 
 
 def write_plonk_pk(vk: plonk.VerifyingKey, srs: setup.SRS) -> bytes:

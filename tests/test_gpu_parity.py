@@ -505,6 +505,19 @@ def test_largest_size_bls12_381_2p21_with_bsb22_proof_verifies(gpu):
     assert not oplonk.verify(ovk, bytes(bad), pib)
     bad = bytearray(pib); bad[-1] ^= 1             # testutils/verifier_integration_test.go:188-228: flipped public input
     assert not oplonk.verify(ovk, blob, bytes(bad))
+    # ONE MSM at this size byte for byte against the C oracle (orc_msm: per-window Pippenger on Jacobian points, all host
+    # threads): configs[4] is not held by properties alone.  n + 3 pairs = the whole canonical SRS, and n pairs.
+    from oracle import c_oracle
+    clib = c_oracle.load()
+    import hashlib
+    raw = bytearray(hashlib.shake_256(b"apk configs[4] msm 0xA193").digest(32 * (n + 3)))      # seeded, 64 MiB in a fraction of a second
+    raw[31::32] = bytes(b & 0x1F for b in raw[31::32])      # little-endian limbs: below 2^253 < r, a valid Montgomery-form scalar
+    sc = bytes(raw)
+    want, got = C.create_string_buffer(2 * cv.fp_bytes), C.create_string_buffer(2 * cv.fp_bytes)
+    for length in (n + 3, n):
+        assert clib.orc_msm(cv.abi, srs.g1, sc, length, os.cpu_count() or 1, want) == 0
+        check(lib.apk_msm_g1(pk.ctx, 0, sc, length, got))
+        assert got.raw == want.raw, ("msm at 2^21", length)
     pk.close()
 
 
@@ -657,8 +670,13 @@ print("SHA", hashlib.sha256(MarshalProof(plonk.Prove(ccs, pk, w, blinding(cv, 3)
 
 @pytest.mark.parametrize("cname,log_n,window,variants", [
     ("bn254", 12, 16, [{"APK_MSM_LEAN_TAIL": "1"}, {"APK_MSM_LEAN_TAIL": "0", "APK_TAIL_FILL": "0"}, {"APK_TAIL_FILL": "2"},
-                       {"APK_NTT_RADIX4": "1"}, {"APK_NTT_RADIX4": "1", "APK_NTT_THREADS": "64"}, {"APK_MSM_SORT2": "1"}]),
-    ("bls12-381", 10, 12, [{"APK_MSM_LEAN_TAIL": "1", "APK_NTT_RADIX4": "1"}, {"APK_MSM_SORT2": "1"}]),
+                       {"APK_NTT_RADIX4": "1"}, {"APK_NTT_RADIX4": "1", "APK_NTT_THREADS": "64"}, {"APK_MSM_SORT2": "1"},
+                       # round 4: the layouts the large sorts take - 2 048 partitions of 16 buckets with wave-private counters,
+                       # sixteen lanes per run in the copy-out, the three-launch partition scan - forced at a size the test can afford
+                       {"APK_MSM_SORT2": "1", "APK_MSM_PART_PBLOG": "4"}, {"APK_MSM_SORT2": "1", "APK_MSM_PART_PBLOG": "6", "APK_MSM_PART_SMALL_SCAN": "0"},
+                       {"APK_MSM_SORTED_MERGE": "0"}, {"APK_MSM_LEAN_TAIL": "1", "APK_MSM_ROWCOL_LANES": "8"}]),
+    ("bls12-381", 10, 12, [{"APK_MSM_LEAN_TAIL": "1", "APK_NTT_RADIX4": "1"}, {"APK_MSM_SORT2": "1"},
+                           {"APK_MSM_SORT2": "1", "APK_MSM_PART_PBLOG": "3", "APK_MSM_PART_SMALL_SCAN": "0"}]),
 ])
 def test_run_time_variants_give_the_same_bytes(gpu, cname, log_n, window, variants):
     """The forms the library picks at run time - lean tail kernels when other proofs are in flight (sixteen-lane row/column
@@ -715,7 +733,8 @@ print("SKEWED_OK")
 """
 
 
-def test_two_level_sort_with_skewed_scalars(gpu):
+@pytest.mark.parametrize("extra", [{}, {"APK_MSM_PART_PBLOG": "4", "APK_MSM_PART_SMALL_SCAN": "0"}], ids=["default-layout", "16-bucket-partitions"])
+def test_two_level_sort_with_skewed_scalars(gpu, extra):
     """The two-level sort's overflow paths: all-equal scalars put a whole MSM's entries into W buckets, so the partitions that
     hold them are far larger than the LDS tile of the second level (it then scatters in HBM) and every other partition is
     empty.  Forced on (it is only picked under load) in a process of its own, with the lean tail forms; checked against the
@@ -724,6 +743,7 @@ def test_two_level_sort_with_skewed_scalars(gpu):
     import sys
     env = dict(os.environ)
     env.update({"APK_MSM_SORT2": "1", "APK_MSM_LEAN_TAIL": "1"})
+    env.update(extra)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
     out = subprocess.run([sys.executable, "-c", _SKEWED_SORT2_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=300)

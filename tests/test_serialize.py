@@ -80,6 +80,16 @@ def test_plonk_vk_and_ccs_round_trip(cname):
     assert back == vk
     with pytest.raises(ValueError, match="inconsistent"):
         ser.read_plonk_vk(cv, io.BytesIO(b[:7] + bytes([b[7] ^ 3]) + b[8:]))
+    # a key written by gnark very likely carries Kzg.Lines between Kzg.G2[1] and the index list: the reader skips a block of
+    # exactly that size (and says so), and still refuses anything else
+    assert back.kzg_lines_bytes == 0
+    tail = 4 + 8 * len(vk.CommitmentConstraintIndexes)
+    nlines = ser.KZG_LINES_BYTES[cv.name]
+    with_lines = b[:-tail] + bytes(range(256)) * (nlines // 256) + bytes(nlines % 256) + b[-tail:]
+    back2 = ser.read_plonk_vk(cv, io.BytesIO(with_lines))
+    assert back2 == vk and back2.kzg_lines_bytes == nlines
+    with pytest.raises(ValueError, match="unpinned"):
+        ser.read_plonk_vk(cv, io.BytesIO(b[:-tail] + bytes(77) + b[-tail:]))
 
     class Sq(frontend.Circuit):
         X = frontend.Public(); Y = frontend.Secret()
