@@ -34,6 +34,7 @@ SYMBOLS = [
     "apk_comm_create", "apk_comm_destroy", "apk_comm_rank", "apk_comm_world", "apk_comm_barrier", "apk_comm_max_f64", "apk_comm_bind",
     "apk_comm_transport", "apk_msm_g1_sharded", "apk_comm_split_begin", "apk_comm_split_end", "apk_comm_serve", "apk_comm_set_compute",
     "apk_comm_commit", "apk_comm_wires", "apk_comm_rccl_ranks", "apk_comm_rccl_selftest",
+    "apk_comm_commit_local", "apk_comm_spmd_begin", "apk_comm_spmd_end",
 ]
 
 
@@ -183,6 +184,9 @@ def _load() -> C.CDLL:
     lib.apk_comm_set_compute.argtypes = [vp, C.POINTER(Compute)]
     lib.apk_comm_commit.argtypes = [vp, i32, C.c_uint32, vp, vp, vp]
     lib.apk_comm_wires.argtypes = [vp, C.c_uint32, vp, vp, vp]
+    lib.apk_comm_commit_local.argtypes = [vp, i32, C.c_uint32, vp, vp, vp]
+    lib.apk_comm_spmd_begin.argtypes = [vp]
+    lib.apk_comm_spmd_end.argtypes = [vp]
     return lib
 
 

@@ -400,6 +400,16 @@ class CurveBackend : public Backend {
         }
         if (unit < (uint32_t)MSM_UNIT_MIN) unit = MSM_UNIT_MIN;
         if (unit > (uint32_t)MSM_UNIT_MAX) unit = MSM_UNIT_MAX;
+        // Small batches (a lone 2^14 MSM: 360 k entries) do not even give every SIMD one wave at 16 entries per lane, and a lone
+        // wave issues a dependent instruction every ~6.5 cycles: the accumulate launch is then 16 additions long whatever the
+        // size (BLS12-381 2^14: 229 of the MSM's 580 us).  Below one wave per SIMD the unit shrinks - down to
+        // APK_MSM_UNIT_SMALL entries - so that the lanes fill the SIMDs once; the merge takes more lanes per bucket instead.
+        static const uint32_t unit_small = (uint32_t)env_int("APK_MSM_UNIT_SMALL", MSM_UNIT_SMALL, MSM_UNIT_SMALL, MSM_UNIT_MIN);
+        if (!unit_env && entries <= MSM_SMALL_ENTRIES && entries / unit < (uint64_t)simds_ * 64) {
+            uint32_t u = (uint32_t)(entries / ((uint64_t)simds_ * 64));
+            if (u < unit_small) u = unit_small;
+            if (u < unit) unit = u;
+        }
         const uint32_t max_units = (uint32_t)(entries / unit) + total_buckets;
         if (stats_on_) HIPCHK(hipEventRecord(s.ev0, st));
         if (s.mark_acc == 2) HIPCHK(hipEventRecord(s.ev_acc, st));
@@ -746,7 +756,11 @@ class CurveBackend : public Backend {
         CHK(s.sorted.alloc(entries * 4));
         if (env_int("APK_MSM_SORT2", -1, -1, 1) != 0 && part_cfg_.P >= 4 && (msm_bases_ >= 65536u || env_int("APK_MSM_SORT2", -1, -1, 1) == 1))
             CHK(s.sort_tmp.alloc(entries * 4));   // two-level sort: packed entries between the levels
-        CHK(s.partial.alloc((entries / MSM_UNIT_MIN + tb) * sizeof(PtU)));
+        {   // unit partials: entries / 16 + a remainder per bucket - or, for small batches, entries / MSM_UNIT_SMALL (run_msm_body)
+            const uint64_t big = entries / MSM_UNIT_MIN + tb;
+            const uint64_t small = (entries < MSM_SMALL_ENTRIES ? entries : MSM_SMALL_ENTRIES) / MSM_UNIT_SMALL + tb;
+            CHK(s.partial.alloc((big > small ? big : small) * sizeof(PtU)));
+        }
         CHK(s.bucket_sum.alloc((size_t)tb * sizeof(PtU)));
         {
             const int m_bits = c_ - 1;
@@ -837,12 +851,14 @@ class CurveBackend : public Backend {
         }
         if ((uint64_t)msm_bases_ * W_ >= (1ull << 31)) { set_error("bases*windows exceeds 2^31 table entries"); return APK_ERR_ARG; }
         {   // two-level sort (kernels_msm.h MsmPartCfg): index bits as needed; partitions of <= 256 buckets, halved until the mean
-            // partition of a full-length MSM holds <= APK_MSM_PART_TARGET entries (16 Ki: a 64 KiB tile + slack, two workgroups
-            // per CU), and as far as the bits left beside the index allow.  P = 0: the context's MSMs do not take the two-level sort.
+            // partition of a full-length MSM holds <= APK_MSM_PART_TARGET entries (what the second level's largest LDS tile takes
+            // with its slack; FEWER, larger partitions measured better for a lone proof at c = 15 - 64 partitions of 35 k entries:
+            // 3.42 ms, 256 of 9 k: 3.49, 512: 3.62 - and c = 16 at 2^17 keeps its 128 partitions of 16 k either way), and as far
+            // as the bits left beside the index allow.  P = 0: the context's MSMs do not take the two-level sort.
             part_cfg_ = MsmPartCfg{};
             uint32_t idx_bits = 1;
             while (((uint64_t)1 << idx_bits) < (uint64_t)msm_bases_ * W_) idx_bits++;
-            const uint32_t target = (uint32_t)env_int("APK_MSM_PART_TARGET", 16384, 1024, MSM_PART_TILE - 4096);
+            const uint32_t target = (uint32_t)env_int("APK_MSM_PART_TARGET", MSM_PART_TILE - 2048, 1024, MSM_PART_TILE - 2048);
             const uint64_t per_msm = (uint64_t)msm_bases_ * W_;
             int pb_log = c_ - 1 < 8 ? c_ - 1 : 8;
             if (idx_bits < 31 && pb_log > (int)(31 - idx_bits)) pb_log = 31 - idx_bits;

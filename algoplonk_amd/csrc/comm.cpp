@@ -411,14 +411,18 @@ static int data_p2p(apk_comm* c, int w, bool to_worker, void* d_buf, size_t byte
 
 // ---- schedules ---------------------------------------------------------------------------------------------------------------------
 // One commitment batch, every rank.  d_scalars only on rank 0.  out_points (count affine points) on rank 0.
-static int commit_round(apk_comm* c, int basis, uint32_t count, const uint32_t* lens, const void* const* d_scalars, void* out_points) {
+// `local` (the replicated prover, apk_comm_spmd_begin): EVERY rank holds the scalar vectors (it ran the same prover on the same
+// inputs), so nothing is scattered - each rank commits its index range straight from its own memory - and every rank adds the
+// gathered partial sums itself: the same `count` points come back on all ranks, and the transcripts stay in lockstep.
+static int commit_round(apk_comm* c, int basis, uint32_t count, const uint32_t* lens, const void* const* d_scalars, void* out_points,
+                        bool local = false) {
     const size_t nb = c->cp.g1_bytes;
     uint64_t total = 0;
     c->step_synced = false;
     for (uint32_t i = 0; i < count; i++) total += lens[i];
     const size_t chunk = (size_t)((total + c->world - 1) / c->world) * APK_FR_BYTES;
     // rank 0 reads its own share in place; the workers' slices are packed into the staging buffer and scattered
-    if (c->world > 1) {
+    if (c->world > 1 && !local) {
         CHK(ensure(c, &c->d_stage, &c->stage_cap, c->rank == 0 ? chunk * c->world : chunk));
         if (c->rank == 0)
             for (int r = 1; r < c->world; r++) {
@@ -442,7 +446,7 @@ static int commit_round(apk_comm* c, int basis, uint32_t count, const uint32_t* 
         size_t at = 0;
         for (size_t i = 0; i < segs.size(); i++) {
             const Seg& s = segs[i];
-            ptrs[i] = c->rank == 0 ? (const uint8_t*)d_scalars[s.k] + s.lo * APK_FR_BYTES : (const uint8_t*)c->d_stage + at;
+            ptrs[i] = (c->rank == 0 || local) ? (const uint8_t*)d_scalars[s.k] + s.lo * APK_FR_BYTES : (const uint8_t*)c->d_stage + at;
             offs[i] = s.lo; ls[i] = s.hi - s.lo;
             at += (size_t)(s.hi - s.lo) * APK_FR_BYTES;
         }
@@ -460,7 +464,7 @@ static int commit_round(apk_comm* c, int basis, uint32_t count, const uint32_t* 
         if (st != APK_OK) { set_error("comm: rank %d failed its share of the commitment batch (code %d)%s%s", r, st, r == c->rank ? ": " : "", r == c->rank ? err.c_str() : ""); return st; }
     }
     c->steps++;
-    if (c->rank != 0) return APK_OK;
+    if (c->rank != 0 && !local) return APK_OK;
     std::vector<uint8_t> col((size_t)c->world * nb);
     for (uint32_t k = 0; k < count; k++) {
         for (int r = 0; r < c->world; r++) memcpy(col.data() + (size_t)r * nb, all.data() + (size_t)r * rec + 8 + k * nb, nb);
@@ -513,6 +517,9 @@ static int wires_round(apk_comm* c, uint32_t count, const uint32_t* lens, const 
 
 static int hook_commit(void* u, int basis, uint32_t count, const void* const* d_scalars, const uint32_t* lens, void* out_points) {
     return apk_comm_commit((apk_comm*)u, basis, count, d_scalars, lens, out_points);
+}
+static int hook_commit_local(void* u, int basis, uint32_t count, const void* const* d_scalars, const uint32_t* lens, void* out_points) {
+    return apk_comm_commit_local((apk_comm*)u, basis, count, d_scalars, lens, out_points);
 }
 static int hook_wires(void* u, uint32_t count, const void* const* d_can, const uint32_t* lens, void* const* d_ev) {
     return apk_comm_wires((apk_comm*)u, count, d_can, lens, d_ev);
@@ -738,6 +745,13 @@ int apk_comm_commit(apk_comm* c, int basis, uint32_t count, const void* const* d
     return commit_round(c, basis, count, h.lens, d_scalars, out_points);
 }
 
+// The replicated prover's commitment step: called on EVERY rank with that rank's own copy of the scalar vectors.
+int apk_comm_commit_local(apk_comm* c, int basis, uint32_t count, const void* const* d_scalars, const uint32_t* lens, void* out_points) {
+    if (!c || !count || count > 4 || !d_scalars || !lens || !out_points) { set_error("comm: commit_local takes 1..4 commitments"); return APK_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(c->step_mu);
+    return commit_round(c, basis, count, lens, d_scalars, out_points, /*local=*/true);
+}
+
 int apk_comm_wires(apk_comm* c, uint32_t count, const void* const* d_can, const uint32_t* lens, void* const* d_ev) {
     if (!c || c->rank != 0 || !count || count > 4 || !d_can || !lens || !d_ev) { set_error("comm: wires is the leader's call (1..4 polynomials)"); return APK_ERR_ARG; }
     std::lock_guard<std::mutex> lk(c->step_mu);
@@ -756,6 +770,24 @@ int apk_comm_split_begin(apk_comm* c) {
         CHK(apk_ctx_set_wire_hook(c->ctx, hook_wires, c));
     }
     c->split_on = true;
+    return APK_OK;
+}
+
+// Replicated prover ("SPMD"): every rank holds the circuit context AND the witness and runs the same apk_prove* call; only the
+// commitments are shared out - rank r commits its index range of every batch from its own copy of the polynomials, one
+// all-gather of the partial sums (ncclAllGather on the RCCL plane), every rank adds them.  Against the leader / worker split
+// (apk_comm_split_begin) nothing is scattered - 604 MB per BLS12-381 2^21 proof stay where they are - and no rank idles through
+// the leader's transforms; the price is that those transforms run on every GPU.  One proof at a time per communicator: the
+// ranks' batches meet in the order they are issued.
+int apk_comm_spmd_begin(apk_comm* c) {
+    if (!c || !c->ctx) { set_error("comm: spmd_begin needs a bound circuit context on every rank"); return APK_ERR_ARG; }
+    CHK(apk_ctx_set_commit_hook(c->ctx, hook_commit_local, c));
+    c->split_on = false;
+    return APK_OK;
+}
+int apk_comm_spmd_end(apk_comm* c) {
+    if (!c) { set_error("null communicator"); return APK_ERR_ARG; }
+    if (c->ctx) (void)apk_ctx_set_commit_hook(c->ctx, nullptr, nullptr);
     return APK_OK;
 }
 

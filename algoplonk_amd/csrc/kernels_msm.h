@@ -27,6 +27,8 @@ constexpr int MSM_UNIT = 16;        // entries per full accumulation work unit; 
                                     // With the remainder units sorted, 2^17: 16 -> 360, 24 -> 357, 32 -> 349, 64 -> 328 proofs/s
                                     // (longer units quantise worse over the 1024 SIMDs and halve the lanes of a lone MSM)
 constexpr int MSM_UNIT_MIN = 16, MSM_UNIT_MAX = 64;
+constexpr int MSM_UNIT_SMALL = 4;                       // shortest unit of a batch that cannot fill the SIMDs at MSM_UNIT_MIN
+constexpr uint64_t MSM_SMALL_ENTRIES = 1ull << 20;      // ... and the most entries such a batch has (16 x 65 536 lanes)
 constexpr int MSM_COMBINE_LANES = 16;
 constexpr uint32_t MSM_HEAVY_UNITS = 512;  // unit partials above which a bucket is merged by a whole workgroup
 

@@ -177,6 +177,21 @@ class Comm:
     def split_end(self) -> None:
         check(lib.apk_comm_split_end(self._c))
 
+    def spmd_begin(self) -> None:
+        """Replicated prover: every rank calls this on its bound circuit context, then the same Prove; the commitments are
+        shared out by index range with nothing scattered (apk_comm_spmd_begin)."""
+        check(lib.apk_comm_spmd_begin(self._c))
+
+    def spmd_end(self) -> None:
+        check(lib.apk_comm_spmd_end(self._c))
+
+    def commit_local(self, curve: ecc.ID, basis: int, d_scalars: Sequence[int], lens: Sequence[int]) -> List[bytes]:
+        """The replicated prover's commitment step (apk_comm_commit_local): EVERY rank calls it with its own copy of the vectors."""
+        k, nb = len(lens), 2 * curve.fp_bytes
+        out = C.create_string_buffer(k * nb)
+        check(lib.apk_comm_commit_local(self._c, basis, k, (C.c_void_p * k)(*d_scalars), (C.c_uint32 * k)(*lens), out))
+        return [out.raw[i * nb:(i + 1) * nb] for i in range(k)]
+
     def serve(self) -> int:
         steps = C.c_uint64(0)
         check(lib.apk_comm_serve(self._c, C.byref(steps)))

@@ -22,6 +22,9 @@ Modes:
                      ranks by index range (algoplonk_amd/parallel.py::SplitCommitter: scatter of scalar slices, per-rank
                      partial MSMs, all-gather of the partial sums), transcript on rank 0; strong scaling - meant for
                      --curve bls12_381 --log-n 21;
+  prove-spmd       : the same proof on every rank (replicated prover, round 4): every rank holds context + witness and proves;
+                     only the commitments are shared out by index range from each rank's own polynomials (one all-gather of
+                     partial sums per batch, nothing scattered); strong scaling;
   launcher-selftest: NOT a measurement - the launcher, rendezvous, barrier / MAX reduction and JSON plumbing with a no-op
                      step (CPU tier test of this file).
 
@@ -71,7 +74,7 @@ def parse_args(argv=None):
                          "workloads.skewed_circuit; the default run reports the bit-heavy rate beside the headline (`witness_bits`)")
     ap.add_argument("--step-barrier", action="store_true",
                     help="join all callers after every step (rounds 1-2); default: persistent callers, barriers only around the K steps")
-    ap.add_argument("--mode", default="prove", choices=["prove", "msm-sharded", "prove-split", "launcher-selftest"])
+    ap.add_argument("--mode", default="prove", choices=["prove", "msm-sharded", "prove-split", "prove-spmd", "launcher-selftest"])
     return ap.parse_args(argv)
 
 
@@ -307,7 +310,62 @@ def main(argv=None) -> None:
         return bench_sharded_msm(args, cv, rk)
     if args.mode == "prove-split":
         return bench_prove_split(args, cv, rk)
+    if args.mode == "prove-spmd":
+        return bench_prove_spmd(args, cv, rk)
     return bench_prove(args, cv, rk)
+
+
+def bench_prove_spmd(args, cv, rk) -> None:
+    """One proof at a time on N GPUs, replicated prover: EVERY rank holds the circuit context and the witness and runs the same
+    apk_prove_device; only the commitments are shared out (rank r commits its index range of every batch from its own copy of the
+    polynomials, one all-gather of the partial sums - apk_comm_spmd_begin, csrc/comm.cpp).  Nothing is scattered and no rank
+    idles.  A step = one proof (the same proof on every rank); value = proofs/s of the whole job (strong)."""
+    import hashlib
+    from algoplonk_amd import frontend, plonk, setup, workloads, MarshalProof
+    from algoplonk_amd._lib import lib, check
+    from algoplonk_amd import _lib
+
+    seed = 0xA190 if args.curve == "bn254" else 0xA193
+    wl = workloads.random_circuit(cv, args.log_n, seed)
+    n = wl.ccs.domain_size()
+    srs = setup.unsafe_srs(cv, n, wl.tau, device=rk.local_rank)
+    pk, vk = plonk.Setup(wl.ccs, srs, device=rk.local_rank, msm_window=args.msm_window, slots=1)
+    rk.comm.bind(pk.ctx)
+    L, R, O = frontend.wire_columns(wl.ccs, wl.solution)
+    dptr = []
+    for v in (L, R, O):
+        b = cv.fr_vector(v)
+        p = C.c_void_p()
+        check(lib.apk_device_alloc(pk.ctx, len(b), C.byref(p)))
+        check(lib.apk_device_upload(pk.ctx, p, b, len(b)))
+        dptr.append(p)
+    pub, bl = cv.fr_vector(wl.witness.public), cv.fr_vector(wl.blinding)
+    proof = _lib.Proof()
+
+    def step():
+        check(lib.apk_prove_device(pk.ctx, dptr[0], dptr[1], dptr[2], pub, bl, None, C.byref(proof)))
+
+    step()                                    # single-GPU reference proof (no hook) for the byte comparison
+    want = MarshalProof(plonk.Proof(cv, proof))
+    rk.comm.spmd_begin()
+    elapsed = rk.timed(step, args.steps, args.warmup)
+    got = MarshalProof(plonk.Proof(cv, proof))
+    rk.comm.spmd_end()
+    same = 1.0 if got == want else 0.0
+    same = -rk.comm.max(-same)                # every rank must hold the single-GPU proof
+    if rk.rank == 0:
+        print(json.dumps({
+            "metric": "proofs/sec", "value": round(args.steps / elapsed, 4), "unit": "proofs/sec", "n_gpus": rk.world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u32x8 Fr / u32x12 Fp (Montgomery)" if cv.name != "bn254" else "u32x8 (Montgomery Fr/Fp)", "data": "synthetic",
+            "config": {"workload": wl.name + ", one proof at a time", "log_n": args.log_n, "curve": cv.name,
+                       "parallelism": "replicated prover x%d: commitments by index range from every rank's own polynomials (all-gather of partial sums), nothing scattered" % rk.world,
+                       "world_size": rk.world, "backend": "libapk comm: tcp control plane, %s data plane" % rk.comm.transport,
+                       "rccl_ranks": rk.comm.rccl_ranks},
+            "proof_sha256_prefix": hashlib.sha256(got).hexdigest()[:16], "matches_single_gpu_proof": same == 1.0}), flush=True)
+    rk.comm.bind(None)
+    pk.close()
+    rk.close()
 
 
 def bench_prove_split(args, cv, rk) -> None:

@@ -235,6 +235,15 @@ int apk_comm_set_compute(apk_comm* comm, const apk_compute* table);
 /* the schedules' entry points as the hooks call them (exposed for the tests of the seam) */
 int apk_comm_commit(apk_comm* comm, int basis, uint32_t count, const void* const* d_scalars, const uint32_t* lens, void* out_points);
 int apk_comm_wires(apk_comm* comm, uint32_t count, const void* const* d_canonical, const uint32_t* lens, void* const* d_evals);
+/* Replicated prover ("SPMD", round 4): every rank holds the circuit context AND the witness and makes the same apk_prove* call
+ * between apk_comm_spmd_begin and apk_comm_spmd_end (both called on every rank).  Only the commitments are shared out: rank r
+ * commits its index range of each batch from its OWN copy of the polynomials, one all-gather of the partial sums, every rank adds
+ * them - nothing is scattered (the leader / worker split above moves 604 MB per BLS12-381 2^21 proof out of rank 0) and the
+ * Fiat-Shamir transcripts of the ranks stay identical, so every rank returns the same proof.  One proof at a time per
+ * communicator.  apk_comm_commit_local is the step the hook runs (exposed for the tests of the seam). */
+int apk_comm_spmd_begin(apk_comm* comm);
+int apk_comm_spmd_end(apk_comm* comm);
+int apk_comm_commit_local(apk_comm* comm, int basis, uint32_t count, const void* const* d_scalars, const uint32_t* lens, void* out_points);
 
 /* ---- the verifier: the host-side mirror of plonk.Verify(proof, vk, publicWitness) (algoplonk.go:93) --------------------
  * (*CompiledCircuit).Verify runs the prover AND gnark's verifier before it hands out a VerifiedProof (algoplonk.go:79-98).

@@ -123,6 +123,7 @@ def _split_worker(rank, world, port, q):
                 want = [ov.mul(ov.g1, oplonk.poly_eval(vectors[i], tau, cv.r)) for i in batch]
                 assert [cv.g1_from_bytes(b) for b in got] == want, batch
                 steps += 1
+            # (the replicated prover's step runs on every rank: below, after the leader / worker steps)
             # per-wire dealing: the 4n-coset evaluations of three canonical polynomials, polynomial i on rank i mod world
             evs = [C.create_string_buffer(4 * n * 32) for _ in range(3)]
             comm.wires([ptr[0], ptr[1], ptr[2]], [10, 10, 10], [C.addressof(e) for e in evs])
@@ -135,6 +136,12 @@ def _split_worker(rank, world, port, q):
             comm.split_end()
         else:
             assert comm.serve() == 4
+        # the replicated prover (apk_comm_spmd_begin): EVERY rank holds the vectors and calls the step; nothing is scattered and the
+        # same sums come back on all ranks
+        host = [C.create_string_buffer(cv.fr_vector(v)) for v in vectors]
+        for batch in ([0, 1, 2], [3], [4, 3]):
+            got = comm.commit_local(cv, 0, [C.addressof(host[i]) for i in batch], [len(vectors[i]) for i in batch])
+            assert [cv.g1_from_bytes(b) for b in got] == [ov.mul(ov.g1, oplonk.poly_eval(vectors[i], tau, cv.r)) for i in batch], ("local", batch)
         comm.close()
         # a rank that fails its share fails the step on EVERY rank, with its rank named
         comm = parallel.Comm(rank, world, "127.0.0.1", port + 1)

@@ -58,6 +58,16 @@ def _worker(rank, world, port, q, cname, split_wires, ipc):
             assert served == 2 * (4 + (1 if split_wires else 0)), served      # {L,R,O} {Z} {H1..3} {W, W'} (+ the wires) per proof
         stage("split proofs")
         comm.barrier()
+        # ---- the replicated prover (apk_comm_spmd_begin): EVERY rank proves, commitments shared out by index range from each
+        # rank's own polynomials, nothing scattered; every rank must return the single-GPU proof
+        plain_here = MarshalProof(ap_plonk.Prove(ccs, pk, w, bl))
+        comm.spmd_begin()
+        for _ in range(2):
+            assert MarshalProof(ap_plonk.Prove(ccs, pk, w, bl)) == plain_here, "replicated-prover proof differs from the single-GPU proof"
+        comm.spmd_end()
+        assert MarshalProof(ap_plonk.Prove(ccs, pk, w, bl)) == plain_here
+        stage("replicated prover")
+        comm.barrier()
         # ---- ONE MSM sharded by index range (BASELINE.json configs[3]): MSM-only context over this rank's slice of the bases
         n = ccs.domain_size()
         g = SplitMix64(0xA192)
@@ -109,6 +119,7 @@ def test_split_proof_and_sharded_msm_between_processes_sharing_the_gpu(gpu, cnam
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,extra", [("prove-split", ["--curve", "bls12_381", "--log-n", "12"]), ("msm-sharded", ["--log-n", "12"]),
+                                        ("prove-spmd", ["--curve", "bls12_381", "--log-n", "12"]),
                                         ("prove", ["--log-n", "12", "--inflight", "2"])])
 def test_bench_py_runs_its_multi_rank_modes_under_the_contract_launcher(gpu, mode, extra):
     """`python bench.py --gpus 2 ...` re-executes itself under torch.distributed.run (the contract's command line), the two ranks
@@ -125,7 +136,7 @@ def test_bench_py_runs_its_multi_rank_modes_under_the_contract_launcher(gpu, mod
     assert len(lines) == 1, r.stdout
     line = lines[0]
     assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["steps"] == 3
-    if mode == "prove-split":
+    if mode in ("prove-split", "prove-spmd"):
         assert line["matches_single_gpu_proof"] is True and line["scaling"] == "strong"
     if mode == "prove":
         assert line["scaling"] == "weak" and line["value"] > 0
