@@ -34,7 +34,8 @@ SYMBOLS = [
     "apk_comm_create", "apk_comm_destroy", "apk_comm_rank", "apk_comm_world", "apk_comm_barrier", "apk_comm_max_f64", "apk_comm_bind",
     "apk_comm_transport", "apk_msm_g1_sharded", "apk_comm_split_begin", "apk_comm_split_end", "apk_comm_serve", "apk_comm_set_compute",
     "apk_comm_commit", "apk_comm_wires", "apk_comm_rccl_ranks", "apk_comm_rccl_selftest",
-    "apk_comm_commit_local", "apk_comm_spmd_begin", "apk_comm_spmd_end",
+    "apk_comm_commit_local", "apk_comm_spmd_begin", "apk_comm_spmd_end", "apk_comm_allgather_device", "apk_comm_subcoset_active",
+    "apk_ctx_set_subcoset",
 ]
 
 
@@ -187,6 +188,9 @@ def _load() -> C.CDLL:
     lib.apk_comm_commit_local.argtypes = [vp, i32, C.c_uint32, vp, vp, vp]
     lib.apk_comm_spmd_begin.argtypes = [vp]
     lib.apk_comm_spmd_end.argtypes = [vp]
+    lib.apk_comm_allgather_device.argtypes = [vp, vp, C.c_size_t]
+    lib.apk_comm_subcoset_active.argtypes = [vp]
+    lib.apk_ctx_set_subcoset.argtypes = [vp, i32, i32, vp, vp]
     return lib
 
 

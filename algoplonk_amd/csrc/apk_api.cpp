@@ -347,6 +347,7 @@ int apk_msm_g1_batch_device(apk_ctx* ctx, int basis, uint32_t count, const void*
 int apk_ctx_set_commit_hook(apk_ctx* ctx, apk_commit_hook hook, void* user) { NEED_CTX(); return ctx->be->set_commit_hook(hook, user); }
 int apk_device_copy(apk_ctx* ctx, void* d, const void* s, size_t b) { NEED_CTX(); return ctx->be->dev_copy(d, s, b); }
 int apk_ctx_set_wire_hook(apk_ctx* ctx, apk_wire_hook hook, void* user) { NEED_CTX(); return ctx->be->set_wire_hook(hook, user); }
+int apk_ctx_set_subcoset(apk_ctx* ctx, int k, int world, apk_gather_hook hook, void* user) { NEED_CTX(); return ctx->be->set_subcoset(k, world, hook, user); }
 int apk_coset_ntt_device(apk_ctx* ctx, const void* d_in, uint64_t len, void* d_out) { NEED_CTX(); return ctx->be->coset_ntt_dev(d_in, len, d_out); }
 int apk_ntt(apk_ctx* ctx, int which, int inverse, int coset, void* data) {
     NEED_CTX(); if (!data) { set_error("null data"); return APK_ERR_ARG; }

@@ -149,6 +149,7 @@ class CurveBackend : public Backend {
         bool hook_pending = false; // a commitment batch handed to the context's commit hook at the next sync_results()
         int hook_basis = 0;
         MsmBatchArgs hook_args{};
+        DevBuf sc_gather;          // sub-coset split: the G parts of the inverse transform (4n elements), all-gathered in place
         DevBuf tail_flag;          // epoch of the last proof whose quotient had a non-zero tail (tail_nonzero_kernel)
         uint32_t epoch = 0;
         // tail filling (a lone proof only, see tail_fill()): the coset transforms that follow a commitment run on `side` from the
@@ -196,6 +197,19 @@ class CurveBackend : public Backend {
     void* hook_user_ = nullptr;
     apk_wire_hook wire_hook_ = nullptr;
     void* wire_hook_user_ = nullptr;
+    // Sub-coset split of round 3 (apk_ctx_set_subcoset): this context stands for the points
+    // i = k (mod G) of the 4n coset - a coset of m = 4n / G points, u w^k <w^G> (w = omega_4n).
+    //   forward   f(u w^k w_m^j) = NTT_m( fold_m( f_i (u w^k)^i ) )        pre[0] = (u w^k)^i;  pre[1]: class (k + 4) mod 8 for Z(omega X) at G = 8
+    //   inverse   part_k[c'] = w^(-k c') * (unscaled inverse NTT_m of the quotient values)[c']        post = w^(-k c')
+    //   merge     h_(c' + m t) = u^-c / (4n) * sum_k rho^(-k t) part_k[c'],  rho = w^m       (subcoset_merge_kernel, after the all-gather)
+    struct SubCoset {
+        int k = 0, G = 1, glog = 0;
+        apk_gather_hook hook = nullptr;
+        void* user = nullptr;
+        DevBuf pre[2], post;
+        Fr rho_inv[8];
+        bool on() const { return G > 1 && hook; }
+    } sc_;
     // stats
     bool stats_on_ = false;
     uint32_t simds_ = 1024;  // SIMDs of the device (4 per CU); set at init
@@ -222,9 +236,10 @@ class CurveBackend : public Backend {
 
     // ---------------------------------------------------------------------------------------------- NTT runner
     // natural in -> natural out; in != out.  which: 0 = size n, 1 = size 4n.  `count` same-size transforms per launch.
+    // sub_log > 0: a transform of 1 / 2^sub_log of the size, on the same twiddle table (sub-coset transforms)
     int run_ntt_batch(hipStream_t st, int which, bool inverse, int count, const Fr* const* ins, Fr* const* outs, const uint32_t* in_lens,
-                      uint32_t out_len, const Fr* pre, const Fr* post, const Fr* scale) {
-        const int log_n = which ? (int)log_n_ + 2 : (int)log_n_;
+                      uint32_t out_len, const Fr* pre, const Fr* post, const Fr* scale, int sub_log = 0) {
+        const int log_n = (which ? (int)log_n_ + 2 : (int)log_n_) - sub_log;
         const Fr* tw = which ? (inverse ? ptr<Fr>(twi_4n_) : ptr<Fr>(tw_4n_)) : (inverse ? ptr<Fr>(twi_n_) : ptr<Fr>(twu_n_));
         // small transforms are latency-bound: 512-element tiles (18 KiB LDS) give >= 256 workgroups at 2^17.  Large ones were
         // assumed bandwidth-bound (2048-element tiles, fewest passes) until round 3 measured them: at 2^21 / 2^23 the 72 KiB tile
@@ -258,6 +273,7 @@ class CurveBackend : public Backend {
             a.log_n = log_n; a.tile_log = tile_log; a.t0 = t0; a.t1 = t0 + s;
             a.first = (p == 0); a.last = (p == passes - 1);
             a.out_len = out_len;
+            a.tw_shift = sub_log;
             const dim3 grid(1u << (log_n - tile_log), count);
             const size_t lds = ((size_t)1 << tile_log) * sizeof(FeU<FRP>);
             // radix 4 (two stages per LDS round trip, one four-element group per lane and step) pays above 2^19 only: kernels_ntt.h
@@ -287,8 +303,14 @@ class CurveBackend : public Backend {
         return APK_OK;
     }
     int run_ntt(hipStream_t st, int which, bool inverse, const Fr* in, Fr* out, uint32_t in_len, uint32_t out_len,
-                const Fr* pre, const Fr* post, const Fr* scale) {
-        return run_ntt_batch(st, which, inverse, 1, &in, &out, &in_len, out_len, pre, post, scale);
+                const Fr* pre, const Fr* post, const Fr* scale, int sub_log = 0) {
+        return run_ntt_batch(st, which, inverse, 1, &in, &out, &in_len, out_len, pre, post, scale, sub_log);
+    }
+    // evaluations of `count` canonical polynomials on the points of the 4n coset this context stands for: all 4n of them, or -
+    // sub-coset split - the m = 4n / G points of class k (cls = 0) or of the class Z(omega X) needs at G = 8 (cls = 1)
+    int coset_eval(hipStream_t st, int count, const Fr* const* ins, const uint32_t* lens, Fr* const* outs, int cls = 0) {
+        if (!sc_.on()) return run_ntt_batch(st, 1, false, count, ins, outs, lens, n4_, ptr<Fr>(coset_pre_), nullptr, nullptr);
+        return run_ntt_batch(st, 1, false, count, ins, outs, lens, n4_ >> sc_.glog, ptr<Fr>(sc_.pre[cls]), nullptr, nullptr, sc_.glog);
     }
     int inv_ntt_n(hipStream_t st, const Fr* in, Fr* out) { return run_ntt(st, 0, true, in, out, n_, n_, nullptr, nullptr, ptr<Fr>(scales_)); }
     // evaluations of a canonical polynomial (len coefficients) on the 4n coset
@@ -664,7 +686,7 @@ class CurveBackend : public Backend {
     int tail_fill(Slot& s) {
         static const int on = env_int("APK_TAIL_FILL", 1, 0, 2);
         static const int graphs = env_int("APK_MSM_GRAPH", 0, 0, 1);
-        if (!on || graphs || hook_ || wire_hook_ || stats_on_ || !qk_direct_) return 0;
+        if (!on || graphs || hook_ || wire_hook_ || stats_on_ || !qk_direct_ || sc_.on()) return 0;
         {
             std::lock_guard<std::mutex> lk(mu_);
             int busy = 0;
@@ -1086,6 +1108,33 @@ class CurveBackend : public Backend {
     }
     int set_commit_hook(apk_commit_hook fn, void* user) override { hook_ = fn; hook_user_ = user; return APK_OK; }
     int set_wire_hook(apk_wire_hook fn, void* user) override { wire_hook_ = fn; wire_hook_user_ = user; return APK_OK; }
+    int set_subcoset(int k, int G, apk_gather_hook fn, void* user) override {
+        if (msm_only_) { set_error("MSM-only context has no quotient to split"); return APK_ERR_STATE; }
+        HIPCHK(hipSetDevice(device_));
+        if (G <= 1 || !fn) { sc_.G = 1; sc_.glog = 0; sc_.hook = nullptr; sc_.user = nullptr; return APK_OK; }
+        if ((G != 2 && G != 4 && G != 8) || k < 0 || k >= G) { set_error("sub-coset split: rank %d of %d (2, 4 or 8 ranks)", k, G); return APK_ERR_ARG; }
+        if (!qk_direct_) { set_error("sub-coset split needs Qk completed inside the quotient kernel (at most %d written rows)", QK_INJECT_MAX); return APK_ERR_STATE; }
+        if ((n4_ >> (G == 2 ? 1 : G == 4 ? 2 : 3)) < 16u) { set_error("sub-coset split: the domain is too small"); return APK_ERR_STATE; }
+        for (Slot* s : slots_) if (s->stream) HIPCHK(hipStreamSynchronize(s->stream));
+        const int glog = G == 2 ? 1 : G == 4 ? 2 : 3;
+        const uint32_t m = n4_ >> glog;
+        const Fr ru = fr_u64(32);   // x R -> x R'
+        hipStream_t st = nullptr;
+        const Fr wk = Fr::pow_u64(omega4_, (uint64_t)k), wk_inv = Fr::pow_u64(omega4_inv_, (uint64_t)k);
+        CHK(sc_.pre[0].alloc((size_t)(n_ + 4) * sizeof(Fr)));
+        CHK(powers(st, ptr<Fr>(sc_.pre[0]), n_ + 4, shift_ * wk, ru));
+        CHK(sc_.pre[1].alloc((size_t)(n_ + 4) * sizeof(Fr)));
+        CHK(powers(st, ptr<Fr>(sc_.pre[1]), n_ + 4, shift_ * Fr::pow_u64(omega4_, (uint64_t)((k + 4) % 8)), ru));
+        CHK(sc_.post.alloc((size_t)m * sizeof(Fr)));
+        CHK(powers(st, ptr<Fr>(sc_.post), m, wk_inv, ru));
+        const Fr rho_inv = Fr::pow_u64(omega4_inv_, (uint64_t)m);
+        Fr cur = ru;
+        for (int e = 0; e < 8; e++) { sc_.rho_inv[e] = cur; cur = cur * rho_inv; }
+        for (Slot* s : slots_) CHK(s->sc_gather.alloc((size_t)n4_ * sizeof(Fr)));
+        HIPCHK(hipDeviceSynchronize());
+        sc_.k = k; sc_.G = G; sc_.glog = glog; sc_.hook = fn; sc_.user = user;
+        return APK_OK;
+    }
     int device_ordinal() override { return device_; }
     uint64_t domain_size() override { return msm_only_ ? 0 : n_; }
     // 4n coset evaluations of a canonical polynomial, device memory in and out; COMPLETE when the call returns.  Inside a hook of
@@ -1373,7 +1422,10 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         a.batch = 1; a.scalars[0] = s.pi2_lag[k].p; a.len[0] = n; a.offset[0] = 0;
         CHK(commit(s, tab_lag_, 1, a, hp));
         CHK(inv_ntt_n(st, ptr<Fr>(s.pi2_lag[k]), ptr<Fr>(s.pi2_can[k])));
-        CHK(coset_ntt_4n(st, ptr<Fr>(s.pi2_can[k]), n, ptr<Fr>(s.epi2[k])));
+        {
+            const Fr* cin = ptr<Fr>(s.pi2_can[k]); Fr* eout = ptr<Fr>(s.epi2[k]);
+            CHK(coset_eval(st, 1, &cin, &n, &eout));
+        }
         CHK(sync_results(s));
         bsb[k] = hp[0];
         g1_raw_bytes(bsb[k], bsb_bytes[k]);
@@ -1414,7 +1466,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     {
         Fr* ev[3] = {ptr<Fr>(s.el), ptr<Fr>(s.er), ptr<Fr>(s.eo)};
         const uint32_t lens[3] = {n + 2, n + 2, n + 2};
-        if (wire_hook_) {
+        if (wire_hook_ && !sc_.on()) {
             // per-wire transforms dealt to other GPUs (csrc/comm.cpp): the hook returns with the three
             // evaluation vectors complete in this context's memory
             HIPCHK(hipStreamSynchronize(st));
@@ -1429,7 +1481,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
             CHK(run_ntt_batch(s.side, 1, false, 3, canon, ev, lens, n4_, ptr<Fr>(coset_pre_), nullptr, nullptr));
             CHK(side_end(s));
         } else {
-            CHK(run_ntt_batch(st, 1, false, 3, canon, ev, lens, n4_, ptr<Fr>(coset_pre_), nullptr, nullptr));
+            CHK(coset_eval(st, 3, canon, lens, ev));
         }
     }
     CHK(sync_results(s));
@@ -1501,7 +1553,13 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         CHK(coset_ntt_4n(s.side, ptr<Fr>(s.cz), n + 3, ptr<Fr>(s.ez)));
         CHK(side_end(s));
     } else {
-        CHK(coset_ntt_4n(st, ptr<Fr>(s.cz), n + 3, ptr<Fr>(s.ez)));
+        const Fr* cin = ptr<Fr>(s.cz); Fr* eout = ptr<Fr>(s.ez);
+        const uint32_t zl = n + 3;
+        CHK(coset_eval(st, 1, &cin, &zl, &eout));
+        if (sc_.on() && sc_.glog == 3) {   // Z(omega X) lives in class (k + 4) mod 8: evaluated there as well (eqk is free: Qk is completed in the kernel)
+            Fr* e2 = ptr<Fr>(s.eqk);
+            CHK(coset_eval(st, 1, &cin, &zl, &e2, 1));
+        }
     }
     CHK(sync_results(s));
     const Aff zcom = hp[0];
@@ -1542,8 +1600,27 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         for (int k = 0; k < 4; k++) q.zh_inv[k] = zh_inv_[k] * c5;
         for (int j = 0; j < q.nb_inject; j++) q.inj_delta[j] = q.inj_delta[j] * c5;
         q.n4 = n4_;
-        quotient_kernel<FRP><<<cdiv(n4_, POLY_THREADS), POLY_THREADS, 0, st>>>(q, ptr<Fr>(s.quot)); KCHK();
-        CHK(run_ntt(st, 1, true, ptr<Fr>(s.quot), ptr<Fr>(s.hcan), n4_, n4_, nullptr, ptr<Fr>(coset_post_inv_), nullptr));
+        if (!sc_.on()) {
+            quotient_kernel<FRP><<<cdiv(n4_, POLY_THREADS), POLY_THREADS, 0, st>>>(q, ptr<Fr>(s.quot)); KCHK();
+            CHK(run_ntt(st, 1, true, ptr<Fr>(s.quot), ptr<Fr>(s.hcan), n4_, n4_, nullptr, ptr<Fr>(coset_post_inv_), nullptr));
+        } else {
+            // sub-coset split: the quotient on this rank's m points, the local part of the inverse transform, ONE all-gather,
+            // the last log2(G) stages on every rank - hcan comes out bit for bit as above
+            const uint32_t m = n4_ >> sc_.glog;
+            q.n4 = m; q.sub_k = (uint32_t)sc_.k; q.sub_glog = (uint32_t)sc_.glog; q.zs = ptr<Fr>(s.eqk);
+            quotient_kernel<FRP><<<cdiv(m, POLY_THREADS), POLY_THREADS, 0, st>>>(q, ptr<Fr>(s.quot)); KCHK();
+            Fr* mine = ptr<Fr>(s.sc_gather) + (size_t)sc_.k * m;
+            CHK(run_ntt(st, 1, true, ptr<Fr>(s.quot), mine, m, m, nullptr, ptr<Fr>(sc_.post), nullptr, sc_.glog));
+            HIPCHK(hipStreamSynchronize(st));
+            hook_slot() = &s;
+            const int grc = sc_.hook(sc_.user, s.sc_gather.p, (size_t)m * sizeof(Fr));
+            hook_slot() = nullptr;
+            if (grc != APK_OK) { set_error("sub-coset gather hook failed with %d", grc); return grc == APK_ERR_ARG ? APK_ERR_ARG : APK_ERR_STATE; }
+            SubMergeArgs<FRP> ma{};
+            for (int e = 0; e < 8; e++) ma.rho_inv[e] = sc_.rho_inv[e];
+            ma.m = m; ma.glog = (uint32_t)sc_.glog;
+            subcoset_merge_kernel<FRP><<<cdiv(m, POLY_THREADS), POLY_THREADS, 0, st>>>(ma, ptr<Fr>(s.sc_gather), ptr<Fr>(coset_post_inv_), ptr<Fr>(s.hcan)); KCHK();
+        }
         // h = h1 + X^(n+2) h2 + X^(2(n+2)) h3   (templateLogicSigBN254.go:79,220-226)
         MsmBatchArgs a{};
         a.batch = 3;

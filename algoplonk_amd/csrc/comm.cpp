@@ -183,6 +183,7 @@ struct apk_comm {
     bool step_synced = false;       // the current step's status reached every rank of it (serve() keeps serving) - or the transport
                                     // broke mid-step and the stream to the leader is no longer aligned (serve() leaves)
     bool split_on = false;
+    bool subcoset_on = false;       // replicated prover: round 3 on sub-cosets (apk_comm_spmd_begin)
     uint64_t steps = 0;
     std::mutex step_mu;             // leader: one step at a time (a context with several slots proves concurrently, and every
                                     // proving thread calls the hooks; the workers serve the steps in the order they are announced)
@@ -521,6 +522,7 @@ static int hook_commit(void* u, int basis, uint32_t count, const void* const* d_
 static int hook_commit_local(void* u, int basis, uint32_t count, const void* const* d_scalars, const uint32_t* lens, void* out_points) {
     return apk_comm_commit_local((apk_comm*)u, basis, count, d_scalars, lens, out_points);
 }
+static int hook_gather(void* u, void* d_all, size_t bytes_per_rank) { return apk_comm_allgather_device((apk_comm*)u, d_all, bytes_per_rank); }
 static int hook_wires(void* u, uint32_t count, const void* const* d_can, const uint32_t* lens, void* const* d_ev) {
     return apk_comm_wires((apk_comm*)u, count, d_can, lens, d_ev);
 }
@@ -773,6 +775,59 @@ int apk_comm_split_begin(apk_comm* c) {
     return APK_OK;
 }
 
+// In-place all-gather of device memory: rank r's part sits at d_all + r * bytes on every rank when the call returns.
+int apk_comm_allgather_device(apk_comm* c, void* d_all, size_t bytes) {
+    if (!c || !d_all) { set_error("comm: allgather_device: null argument"); return APK_ERR_ARG; }
+    if (c->world == 1 || bytes == 0) return APK_OK;
+    uint8_t* all = (uint8_t*)d_all;
+    uint8_t* mine = all + (size_t)c->rank * bytes;
+    if (c->rccl) {
+        HCHK(hipSetDevice(c->device));
+        NCHK(g_rccl.AllGather(mine, all, bytes, ncclUint8, c->nccl, c->stream));     // in place: sendbuff = recvbuff + rank * count
+        HCHK(hipStreamSynchronize(c->stream));
+        return APK_OK;
+    }
+    if (c->ipc) {
+        // every rank exports its staging buffer (the one allocation a peer can map), parks its part there, and pulls the others'
+        void** slot = c->rank == 0 ? &c->d_stage : &c->d_wire_out;
+        size_t* cap = c->rank == 0 ? &c->stage_cap : &c->wire_out_cap;
+        int32_t ok = ensure(c, slot, cap, bytes) == APK_OK && c->cp.copy(CP_USER(c, copy), *slot, mine, bytes, 0) == APK_OK ? 1 : 0;
+        std::vector<IpcMsg> msgs(c->world);
+        IpcMsg m{};
+        m.gen = c->export_gen; m.offset = 0; m.bytes = ok ? bytes : 0; m.h = c->export_handle;
+        CHK(ctl_allgather(c, &m, msgs.data(), sizeof m));
+        hipError_t e = hipSetDevice(c->device);
+        for (int r = 0; r < c->world && ok; r++) {
+            if (r == c->rank) continue;
+            if (msgs[r].bytes != bytes) { ok = 0; break; }
+            apk_comm::Mapping& mp = c->maps[r];
+            if (e == hipSuccess && (mp.gen != msgs[r].gen || !mp.p)) {
+                if (mp.p) (void)hipIpcCloseMemHandle(mp.p);
+                mp.p = nullptr;
+                e = hipIpcOpenMemHandle(&mp.p, msgs[r].h, hipIpcMemLazyEnablePeerAccess);
+                mp.gen = msgs[r].gen;
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(all + (size_t)r * bytes, (const uint8_t*)mp.p + msgs[r].offset, bytes, hipMemcpyDeviceToDevice, c->stream);
+            if (e != hipSuccess) ok = 0;
+        }
+        if (ok && hipStreamSynchronize(c->stream) != hipSuccess) ok = 0;
+        if (!ok) (void)hipGetLastError();
+        // nobody reuses its exported buffer before every peer has pulled from it; and everybody learns how the step went
+        std::vector<int32_t> oks(c->world);
+        CHK(ctl_allgather(c, &ok, oks.data(), 4));
+        for (int r = 0; r < c->world; r++) if (!oks[r]) { set_error("comm: rank %d failed the device all-gather (IPC)", r); return APK_ERR_HIP; }
+        return APK_OK;
+    }
+    // host-staged through the TCP star (CPU tier; IPC off or refused)
+    std::vector<uint8_t> h_all((size_t)c->world * bytes);
+    CHK(c->cp.copy(CP_USER(c, copy), h_all.data() + (size_t)c->rank * bytes, mine, bytes, 2));
+    std::vector<uint8_t> h_mine(h_all.begin() + (size_t)c->rank * bytes, h_all.begin() + (size_t)(c->rank + 1) * bytes);
+    CHK(ctl_allgather(c, h_mine.data(), h_all.data(), bytes));
+    for (int r = 0; r < c->world; r++)
+        if (r != c->rank) CHK(c->cp.copy(CP_USER(c, copy), all + (size_t)r * bytes, h_all.data() + (size_t)r * bytes, bytes, 1));
+    return APK_OK;
+}
+
 // Replicated prover ("SPMD"): every rank holds the circuit context AND the witness and runs the same apk_prove* call; only the
 // commitments are shared out - rank r commits its index range of every batch from its own copy of the polynomials, one
 // all-gather of the partial sums (ncclAllGather on the RCCL plane), every rank adds them.  Against the leader / worker split
@@ -783,13 +838,26 @@ int apk_comm_spmd_begin(apk_comm* c) {
     if (!c || !c->ctx) { set_error("comm: spmd_begin needs a bound circuit context on every rank"); return APK_ERR_ARG; }
     CHK(apk_ctx_set_commit_hook(c->ctx, hook_commit_local, c));
     c->split_on = false;
+    // round 3 of the prover on sub-cosets (apk_ctx_set_subcoset): world 2, 4 or 8, unless APK_SPMD_SUBCOSET=0 - and only when
+    // EVERY rank's context can take it (the ranks agree first: a rank on its own would wait in an all-gather nobody joins)
+    int32_t can = 0;
+    if ((c->world == 2 || c->world == 4 || c->world == 8) && env_int("APK_SPMD_SUBCOSET", 1, 0, 1))
+        can = apk_ctx_set_subcoset(c->ctx, c->rank, c->world, hook_gather, c) == APK_OK ? 1 : 0;
+    std::vector<int32_t> cans(c->world);
+    CHK(ctl_allgather(c, &can, cans.data(), 4));
+    bool all = true;
+    for (int32_t v : cans) all = all && v;
+    if (!all) (void)apk_ctx_set_subcoset(c->ctx, 0, 1, nullptr, nullptr);
+    c->subcoset_on = all;
     return APK_OK;
 }
 int apk_comm_spmd_end(apk_comm* c) {
     if (!c) { set_error("null communicator"); return APK_ERR_ARG; }
-    if (c->ctx) (void)apk_ctx_set_commit_hook(c->ctx, nullptr, nullptr);
+    if (c->ctx) { (void)apk_ctx_set_commit_hook(c->ctx, nullptr, nullptr); (void)apk_ctx_set_subcoset(c->ctx, 0, 1, nullptr, nullptr); }
+    c->subcoset_on = false;
     return APK_OK;
 }
+int apk_comm_subcoset_active(const apk_comm* c) { return c && c->subcoset_on ? 1 : 0; }
 
 int apk_comm_split_end(apk_comm* c) {
     if (!c || c->rank != 0) { set_error("comm: split_end is the leader's call"); return APK_ERR_ARG; }

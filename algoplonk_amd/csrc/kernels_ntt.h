@@ -40,6 +40,7 @@ struct NttPassArgs {
     int first, last;     // first pass gathers bit-reversed + pre-multiplies; last pass post-multiplies
     uint32_t out_len;    // last pass: elements >= out_len are not written
     int radix4;          // two stages per LDS round trip (large transforms; see the kernel)
+    int tw_shift;        // the twiddle table belongs to a transform 2^tw_shift times this size (sub-coset transforms: tw[j << tw_shift])
 };
 
 // Inside the tile the elements are UNSATURATED-limb values (ffu.h, 9 x 29 bits for both scalar fields) handled lazily:
@@ -90,6 +91,18 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, cons
                 Fr raw = in[src];
                 v = Fu::unpack(raw.l);
                 if (pre) { Fr pw = pre[src]; v = Fu::mul_nr(Fu::unpack(pw.l), v); }
+                // a polynomial LONGER than the transform (sub-coset evaluations, backend_impl.h SubCoset: n + 3 coefficients on
+                // a coset of 4n / G points) folds onto its low coefficients: x^N = const on the coset, and the constant is
+                // already inside `pre`.  At most three terms below 2p each, brought back below p for the stage-0 butterfly.
+                if (in_len > (1u << a.log_n)) {
+                    for (uint32_t s2 = src + (1u << a.log_n); s2 < in_len; s2 += 1u << a.log_n) {
+                        Fr raw2 = in[s2];
+                        Fu v2 = Fu::unpack(raw2.l);
+                        if (pre) { Fr pw = pre[s2]; v2 = Fu::mul_nr(Fu::unpack(pw.l), v2); }
+                        v = Fu::add_n(v, v2);
+                    }
+                    v = Fu::template canon<4>(v);
+                }
             } else {
                 v = Fu::zero();
             }
@@ -126,7 +139,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, cons
                 continue;
             }
             if (t != 0) {   // stage t: exponent imod * N / 2^(t+1); stage 0 has unit twiddles and fresh operands (below 2p)
-                Fr w = tw[imod << (a.log_n - 1 - t)];
+                Fr w = tw[(imod << (a.log_n - 1 - t)) << a.tw_shift];
                 const Fu w1 = Fu::unpack(w.l);
                 x1 = Fu::mul_nr(w1, x1);
                 x3 = Fu::mul_nr(w1, x3);
@@ -138,11 +151,11 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, cons
             // stage t+1: exponents imod * N / 2^(t+2) and that + N/4
             const uint32_t k2 = imod << (a.log_n - 2 - t);
             {
-                Fr w = tw[k2 + (1u << (a.log_n - 2))];
+                Fr w = tw[(k2 + (1u << (a.log_n - 2))) << a.tw_shift];
                 y3 = Fu::mul_nr(Fu::unpack(w.l), y3);
             }
             if (t != 0) {
-                Fr w = tw[k2];
+                Fr w = tw[k2 << a.tw_shift];
                 y2 = Fu::mul_nr(Fu::unpack(w.l), y2);
                 sm[e00] = Fu::add_n(y0, y2);
                 sm[e10] = Fu::template sub_k<2>(y0, y2);
@@ -167,7 +180,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, cons
             uint32_t g = g0 + c;
             // twiddle exponent: (index mod 2^t) * N / 2^(t+1)
             uint32_t imod = (low << a.t0) | (g & lomask);
-            uint32_t tidx = imod << (a.log_n - 1 - t);
+            uint32_t tidx = (imod << (a.log_n - 1 - t)) << a.tw_shift;
             uint32_t e0 = (mid0 << clog) | c, e1 = (mid1 << clog) | c;
             Fu u = sm[e0];
             Fu v = sm[e1];

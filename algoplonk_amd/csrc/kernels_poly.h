@@ -240,6 +240,12 @@ struct QuotientArgs {
     Fe<FR> alpha, beta, gamma, beta_u, beta_u2, alpha2;
     Fe<FR> zh_inv[4];
     uint32_t n4;
+    // Sub-coset mode (one proof on G GPUs, backend_impl.h SubCoset): this launch covers the points i = sub_k + G j of the 4n coset,
+    // j < n4 (then = 4n / G).  The per-proof vectors (l, r, o, z, pi2) hold those evaluations at index j; the per-circuit tables are
+    // read at i.  Z(omega X) is the point i + 4: the same class for G <= 4 (index j + 4 / G), class (sub_k + 4) mod 8 for G = 8
+    // (`zs`, index j or j + 1).  sub_glog = 0: the whole coset, as ever.
+    const Fe<FR>* zs;
+    uint32_t sub_k, sub_glog;
 };
 
 // The kernel works on unsaturated limbs (ffu.h) without conditional subtractions, like the NTT tiles: polynomial VALUES stay in
@@ -254,18 +260,23 @@ __global__ void __launch_bounds__(POLY_THREADS) quotient_kernel(QuotientArgs<FR>
     using Fr = Fe<FR>;
     using U = FeU<FR>;
     static_assert(U::HEADROOM >= 64, "lazy sums of up to 16 r times a canonical factor must stay below 2 r");
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n4) return;
+    const uint32_t jj = blockIdx.x * blockDim.x + threadIdx.x;   // index into the per-proof vectors
+    if (jj >= a.n4) return;
+    const uint32_t i = (jj << a.sub_glog) + a.sub_k;             // index into the per-circuit tables (the point of the 4n coset)
     auto ld = [](const Fr* p, uint32_t k) { Fr v = p[k]; return U::unpack(v.l); };
     auto cst = [](const Fr& v) { return U::unpack(v.l); };
-    const U l = ld(a.l, i), r = ld(a.r, i), o = ld(a.o, i), z = ld(a.z, i);
-    const uint32_t is = i + 4 < a.n4 ? i + 4 : i + 4 - a.n4;
-    const U zs = ld(a.z, is);
+    const U l = ld(a.l, jj), r = ld(a.r, jj), o = ld(a.o, jj), z = ld(a.z, jj);
+    uint32_t is;
+    const Fr* zsp = a.z;
+    if (a.sub_glog <= 2) is = jj + (4u >> a.sub_glog);
+    else { is = jj + (a.sub_k + 4u >= 8u ? 1u : 0u); zsp = a.zs; }
+    if (is >= a.n4) is -= a.n4;
+    const U zs = ld(zsp, is);
     U gate = U::add_n(U::mul_nr(ld(a.ql, i), l), U::mul_nr(ld(a.qr, i), r));
     gate = U::add_n(gate, U::mul_nr(ld(a.qm, i), U::mul_nr(l, r)));
     gate = U::add_n(gate, U::mul_nr(ld(a.qo, i), o));
     gate = U::add_n(gate, ld(a.qk, i));
-    for (int k = 0; k < a.nb_commit; k++) gate = U::add_n(gate, U::mul_nr(ld(a.qcp[k], i), ld(a.pi2[k], i)));
+    for (int k = 0; k < a.nb_commit; k++) gate = U::add_n(gate, U::mul_nr(ld(a.qcp[k], i), ld(a.pi2[k], jj)));
     for (int j = 0; j < a.nb_inject; j++) gate = U::add_n(gate, U::mul_nr(cst(a.inj_delta[j]), ld(a.inj_tab[j], i)));
     const U gm = cst(a.gamma), beta = cst(a.beta);
     const U lg = U::add_n(l, gm), rg = U::add_n(r, gm), og = U::add_n(o, gm);          // < 2
@@ -284,7 +295,40 @@ __global__ void __launch_bounds__(POLY_THREADS) quotient_kernel(QuotientArgs<FR>
     const U res = U::template canon<1>(U::mul_nr(cst(a.zh_inv[i & 3]), num));
     Fr w;
     res.pack(w.l);
-    out[i] = w;
+    out[jj] = w;
+}
+
+// Sub-coset mode, the last log2(G) stages of the inverse 4n transform on every rank: part[k][c'] = omega_4n^(-k c') * (size-m inverse
+// transform of rank k's quotient values, unscaled)[c'] for the G classes k (all-gathered), m = 4n / G.  Coefficient c = c' + m t:
+//     h_c = u^-c / (4n) * sum_k rho^(-k t) part[k][c'],        rho = omega_4n^m (a primitive G-th root of unity)
+// post[c] = u^-c / (4n) in the radix R' (the whole-coset transform's own table), rho_inv[e] = 32 rho^-e (R').
+template <class FR>
+struct SubMergeArgs { Fe<FR> rho_inv[8]; uint32_t m, glog; };
+template <class FR>
+__global__ void __launch_bounds__(POLY_THREADS) subcoset_merge_kernel(SubMergeArgs<FR> a, const Fe<FR>* __restrict__ part, const Fe<FR>* __restrict__ post,
+                                                                      Fe<FR>* __restrict__ out) {
+    wave_priority<APK_PRIO_FR>();
+    using Fr = Fe<FR>;
+    using U = FeU<FR>;
+    static_assert(U::HEADROOM >= 64, "sums of 8 products below 2 r each");
+    const uint32_t cp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cp >= a.m) return;
+    const uint32_t G = 1u << a.glog;
+    U v[8];
+    for (uint32_t k = 0; k < G; k++) { Fr x = part[(size_t)k * a.m + cp]; v[k] = U::unpack(x.l); }
+    for (uint32_t t = 0; t < G; t++) {
+        U acc = v[0];                                           // rho^0
+        for (uint32_t k = 1; k < G; k++) {
+            const uint32_t e = (k * t) & (G - 1u);
+            acc = U::add_n(acc, e ? U::mul_nr(U::unpack(a.rho_inv[e].l), v[k]) : v[k]);
+        }
+        const size_t c = (size_t)t * a.m + cp;
+        Fr pw = post[c];
+        const U res = U::template canon<1>(U::mul_nr(U::unpack(pw.l), acc));
+        Fr w;
+        res.pack(w.l);
+        out[c] = w;
+    }
 }
 
 // p[i] *= c  (setup: selector tables into the quotient kernel's radix)

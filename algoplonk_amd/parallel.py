@@ -182,6 +182,14 @@ class Comm:
         shared out by index range with nothing scattered (apk_comm_spmd_begin)."""
         check(lib.apk_comm_spmd_begin(self._c))
 
+    @property
+    def subcoset_active(self) -> bool:
+        return bool(lib.apk_comm_subcoset_active(self._c))
+
+    def allgather_device(self, d_all: int, bytes_per_rank: int) -> None:
+        """In-place all-gather of device memory (apk_comm_allgather_device): rank r's part at d_all + r * bytes_per_rank."""
+        check(lib.apk_comm_allgather_device(self._c, d_all, bytes_per_rank))
+
     def spmd_end(self) -> None:
         check(lib.apk_comm_spmd_end(self._c))
 

@@ -165,6 +165,16 @@ int apk_ctx_set_commit_hook(apk_ctx* ctx, apk_commit_hook hook, void* user);
 typedef int (*apk_wire_hook)(void* user, uint32_t count, const void* const* d_canonical, const uint32_t* lens, void* const* d_evals);
 int apk_ctx_set_wire_hook(apk_ctx* ctx, apk_wire_hook hook, void* user);
 int apk_coset_ntt_device(apk_ctx* ctx, const void* d_canonical, uint64_t len, void* d_evals);
+/* Sub-coset split of round 3, for the replicated prover: rank k of `world`
+ * (2, 4 or 8) evaluates the wire and permutation polynomials only on the points i = k (mod world) of the 4n coset (a coset of
+ * 4n / world points: one transform of that size per polynomial), runs the quotient kernel there and inverse-transforms locally;
+ * ONE all-gather of 4n / world field elements per rank - the hook: `d_all` holds world x bytes_per_rank bytes of THIS context's
+ * device memory, rank r's part at r * bytes_per_rank, this rank's part filled in; the hook returns with every part filled in -
+ * and the last log2(world) butterfly stages on every rank give the quotient's 4n coefficients, bit for bit those of the whole-
+ * coset path.  world = 1 or hook = NULL switches it off.  Needs a context whose Qk is completed inside the quotient kernel (the
+ * default: at most 6 public inputs + commitments); APK_ERR_STATE otherwise. */
+typedef int (*apk_gather_hook)(void* user, void* d_all, size_t bytes_per_rank);
+int apk_ctx_set_subcoset(apk_ctx* ctx, int k, int world, apk_gather_hook hook, void* user);
 
 /* ---- multi-GPU behind the boundary: one process per GPU, libapk's own communicator ---------------------
  * The reference's host is Go (algoplonk.go:89): a cgo caller cannot use a Python process group, so the exchange steps of the
@@ -244,6 +254,12 @@ int apk_comm_wires(apk_comm* comm, uint32_t count, const void* const* d_canonica
 int apk_comm_spmd_begin(apk_comm* comm);
 int apk_comm_spmd_end(apk_comm* comm);
 int apk_comm_commit_local(apk_comm* comm, int basis, uint32_t count, const void* const* d_scalars, const uint32_t* lens, void* out_points);
+/* In-place all-gather of device memory (the sub-coset split's one exchange): d_all holds world x bytes_per_rank bytes, rank r's
+ * part at r * bytes_per_rank.  ncclAllGather on the RCCL plane, pulls from the peers' exported buffers on the IPC plane, staged
+ * through the host and the TCP star otherwise.  apk_comm_spmd_begin installs it as the bound context's gather hook when the world
+ * is 2, 4 or 8 and APK_SPMD_SUBCOSET is not 0. */
+int apk_comm_allgather_device(apk_comm* comm, void* d_all, size_t bytes_per_rank);
+int apk_comm_subcoset_active(const apk_comm* comm);        /* 1 between spmd_begin and spmd_end when round 3 runs on sub-cosets */
 
 /* ---- the verifier: the host-side mirror of plonk.Verify(proof, vk, publicWitness) (algoplonk.go:93) --------------------
  * (*CompiledCircuit).Verify runs the prover AND gnark's verifier before it hands out a VerifiedProof (algoplonk.go:79-98).

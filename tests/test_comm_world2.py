@@ -142,6 +142,11 @@ def _split_worker(rank, world, port, q):
         for batch in ([0, 1, 2], [3], [4, 3]):
             got = comm.commit_local(cv, 0, [C.addressof(host[i]) for i in batch], [len(vectors[i]) for i in batch])
             assert [cv.g1_from_bytes(b) for b in got] == [ov.mul(ov.g1, oplonk.poly_eval(vectors[i], tau, cv.r)) for i in batch], ("local", batch)
+        # the sub-coset split's one exchange: an in-place all-gather of "device" memory (host-staged through the star on this tier)
+        buf2 = C.create_string_buffer(world * 4096)
+        C.memmove(C.addressof(buf2) + rank * 4096, bytes([(rank * 31 + i) & 0xFF for i in range(4096)]), 4096)
+        comm.allgather_device(C.addressof(buf2), 4096)
+        assert buf2.raw == b"".join(bytes([(r * 31 + i) & 0xFF for i in range(4096)]) for r in range(world)), "allgather_device"
         comm.close()
         # a rank that fails its share fails the step on EVERY rank, with its rank named
         comm = parallel.Comm(rank, world, "127.0.0.1", port + 1)

@@ -62,6 +62,7 @@ def _worker(rank, world, port, q, cname, split_wires, ipc):
         # rank's own polynomials, nothing scattered; every rank must return the single-GPU proof
         plain_here = MarshalProof(ap_plonk.Prove(ccs, pk, w, bl))
         comm.spmd_begin()
+        assert comm.subcoset_active == (world in (2, 4, 8)), "round 3 on sub-cosets whenever the world is 2, 4 or 8"
         for _ in range(2):
             assert MarshalProof(ap_plonk.Prove(ccs, pk, w, bl)) == plain_here, "replicated-prover proof differs from the single-GPU proof"
         comm.spmd_end()
@@ -90,7 +91,7 @@ def _worker(rank, world, port, q, cname, split_wires, ipc):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cname,world,split_wires,ipc", [("bn254", 2, False, True), ("bls12-381", 2, True, True), ("bn254", 3, True, True),
-                                                         ("bn254", 2, True, False)])
+                                                         ("bn254", 2, True, False), ("bls12-381", 4, False, True)])
 def test_split_proof_and_sharded_msm_between_processes_sharing_the_gpu(gpu, cname, world, split_wires, ipc):
     from algoplonk_amd.parallel import free_port
     ctx = mp.get_context("spawn")
@@ -179,3 +180,72 @@ def test_rccl_branch_runs_on_hardware_world_1(gpu):
     from algoplonk_amd import parallel
     assert parallel.rccl_selftest(0) == 1
     assert parallel.rccl_selftest(0) == 1          # init and teardown are repeatable in one process
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cname,G,log_n,bsb", [("bn254", 2, 9, 0), ("bn254", 4, 9, 0), ("bn254", 8, 9, 0), ("bls12-381", 8, 8, 0), ("bls12-381", 4, 10, 0),
+                                               ("bls12-381", 8, 9, 1), ("bn254", 4, 8, 1)])
+def test_subcoset_split_of_round_3_is_byte_identical(gpu, cname, G, log_n, bsb):
+    """SURVEY.md section 8e row 2 / DESIGN.md section 6: rank k of G evaluates the wire polynomials on the points i = k (mod G) of
+    the 4n coset only, runs the quotient kernel there, inverse-transforms locally; ONE all-gather and the last log2(G) stages
+    give the quotient's coefficients.  G contexts in ONE process stand for the G ranks (G threads prove at the same time, the
+    gather hook is a barrier + device-to-device copies between the contexts): every "rank" must return the proof of the
+    whole-coset path, byte for byte - including G = 8, where Z(omega X) lives in another class than Z(X) and n + 3 coefficients
+    fold onto n / 2 points."""
+    import threading
+    from algoplonk_amd import MarshalProof, _lib, plonk as ap_plonk, setup as ap_setup
+    from algoplonk_amd._lib import lib, check
+    from helpers import CURVES, blinding, random_chain_ccs
+    from oracle.prng import tau_from_seed
+    cv, ov = CURVES[cname]
+    kw = {}
+    if bsb:      # a BSB22 commitment: the committed column's evaluations (pi2) live on the sub-coset too
+        from algoplonk_amd import workloads
+        ccs, w, bl, tau = workloads.random_circuit_bsb22(cv, log_n, 0xA193)
+        srs = ap_setup.unsafe_srs(cv, ccs.domain_size(), tau, device=gpu, lagrange=True)
+        kw = {"hiding": [(0xA193, 0x3910A)]}
+    else:
+        ccs, w, sol = random_chain_ccs(cv, log_n, 0xA190 + log_n)
+        srs = ap_setup.unsafe_srs(cv, ccs.domain_size(), tau_from_seed(5, cv.r), device=gpu)
+        bl = blinding(cv, 9)
+    pks = [ap_plonk.Setup(ccs, srs, device=gpu)[0] for _ in range(G)]
+    plain = MarshalProof(ap_plonk.Prove(ccs, pks[0], w, bl, **kw))
+    gate = threading.Barrier(G)
+    bufs = {}
+    HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+
+    def make_hook(k):
+        def hook(_user, d_all, nbytes):
+            try:
+                bufs[k] = d_all
+                gate.wait(timeout=120)
+                for r in range(G):
+                    if r != k:
+                        check(lib.apk_device_copy(pks[k].ctx, d_all + r * nbytes, bufs[r] + r * nbytes, nbytes))
+                gate.wait(timeout=120)
+                return 0
+            except Exception:
+                return _lib.APK_ERR_STATE
+        return HOOK(hook)
+
+    hooks = [make_hook(k) for k in range(G)]
+    for k in range(G):
+        check(lib.apk_ctx_set_subcoset(pks[k].ctx, k, G, hooks[k], None))
+    out = [None] * G
+
+    def run(k):
+        try:
+            out[k] = MarshalProof(ap_plonk.Prove(ccs, pks[k], w, bl, **kw))
+        except Exception as e:
+            out[k] = e
+            gate.abort()
+
+    ts = [threading.Thread(target=run, args=(k,)) for k in range(G)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert all(o == plain for o in out), [o if isinstance(o, Exception) else o == plain for o in out]
+    for k in range(G):
+        check(lib.apk_ctx_set_subcoset(pks[k].ctx, 0, 1, None, None))
+    assert MarshalProof(ap_plonk.Prove(ccs, pks[1], w, bl, **kw)) == plain
+    for pk in pks:
+        pk.close()
