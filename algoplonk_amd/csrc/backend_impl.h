@@ -481,6 +481,7 @@ class CurveBackend : public Backend {
             uint32_t sl2 = slice_eff ? slice_eff : 2048u;
             if ((uint64_t)sl2 * W_ > MSM_PART_STAGE) sl2 = MSM_PART_STAGE / (uint32_t)W_;
             G2 = cdiv(maxlen, sl2);
+            if (G2 > 1024u && (uint64_t)cdiv(maxlen, 1024u) * W_ <= MSM_PART_STAGE) G2 = 1024u;   // 2^21 + 3 scalars: 1 024 slices of 2 049
             if (G2 < 1) G2 = 1;
         }
         static const int small_scan_env = env_int("APK_MSM_PART_SMALL_SCAN", 1, 0, 1);   // 0: always the three-launch scan (tests)
@@ -492,7 +493,9 @@ class CurveBackend : public Backend {
         uint32_t* runstart = pcounts + (size_t)a.batch * G * P;
         uint32_t* ptot = runstart + (size_t)a.batch * G * P;
         uint32_t* csum = ptot + (size_t)a.batch * P;
-        if (sort2) {
+        if (sort2 && !APK_PHASE(1)) {
+            // knock-out build, bit 1: the two-level sort is not launched (the previous batch's sorted entries stay in place)
+        } else if (sort2) {
             // LDS stage of the first level: a slice's entries (<= slice x W words; slices that do not fit scatter in HBM)
             const uint32_t per_slice = cdiv(maxlen, G);
             uint32_t stage_cap = per_slice * (uint32_t)W_;

@@ -17,6 +17,7 @@
 // exponentiation is (p^6 - 1) by conjugate/inverse, then the plain power (p^6+1)/r.  Any non-degenerate bilinear pairing
 // decides e(A, G2_0) e(B, G2_1) = 1; constants from tools/gen_pairing_params.py (checked numerically there).
 #pragma once
+#include <mutex>
 #include <string.h>
 #include <vector>
 
@@ -513,9 +514,36 @@ struct HostVerifier {
             memcpy(&g2[j].x, vk->g2[j], sizeof(g2[j].x));
             memcpy(&g2[j].y, vk->g2[j] + 2 * FPB, sizeof(g2[j].y));
             g2[j].inf = g2[j].x.is_zero() && g2[j].y.is_zero();
-            if (g2[j].inf || !g2[j].on_curve()) { set_error("verifying key: Kzg.G2[%d] is not a point of the twist", j); return APK_ERR_ARG; }
-            // the twists have large cofactors and the ate Miller loop is a pairing only on the order-r subgroup
-            if (!G2::template mul<FRP>(g2[j], Fr::modulus()).inf) { set_error("verifying key: Kzg.G2[%d] is not in the prime-order subgroup", j); return APK_ERR_ARG; }
+        }
+        // The key's own points are constants of the circuit: checked ONCE per key (on the curve / the twist, in the prime-order
+        // subgroups - gnark rejects such points when it decodes a key; the twists have large cofactors and the ate Miller loop is
+        // a pairing only on the order-r subgroup), remembered by value.  Two G2 scalar multiplications by r per call were most of a
+        // small verification's time.
+        {
+            std::vector<uint8_t> blob;
+            auto put = [&](const void* p, size_t nb) { const uint8_t* b = (const uint8_t*)p; blob.insert(blob.end(), b, b + nb); };
+            const int cid = CURVE_ID;
+            put(&cid, sizeof cid);
+            for (const Aff* p : {&Ql, &Qr, &Qm, &Qo, &Qk, &S1, &S2, &S3, &G1}) put(p, sizeof(Aff));
+            for (uint32_t i = 0; i < k; i++) put(&Qcp[i], sizeof(Aff));
+            put(vk->g2[0], 4 * FPB); put(vk->g2[1], 4 * FPB);
+            static std::mutex mu;
+            static std::vector<std::vector<uint8_t>> seen;
+            bool known = false;
+            { std::lock_guard<std::mutex> lk(mu); for (const auto& b : seen) if (b == blob) { known = true; break; } }
+            if (!known) {
+                std::vector<Aff> kp = {Ql, Qr, Qm, Qo, Qk, S1, S2, S3, G1};
+                for (uint32_t i = 0; i < k; i++) kp.push_back(Qcp[i]);
+                for (const Aff& p : kp) if (!g1_on_curve(p)) { set_error("verifying key: a G1 point is not on the curve"); return APK_ERR_ARG; }
+                for (const Aff& p : kp) if (!g1_in_subgroup(p)) { set_error("verifying key: a G1 point is not in the prime-order subgroup"); return APK_ERR_ARG; }
+                for (int j = 0; j < 2; j++) {
+                    if (g2[j].inf || !g2[j].on_curve()) { set_error("verifying key: Kzg.G2[%d] is not a point of the twist", j); return APK_ERR_ARG; }
+                    if (!G2::template mul<FRP>(g2[j], Fr::modulus()).inf) { set_error("verifying key: Kzg.G2[%d] is not in the prime-order subgroup", j); return APK_ERR_ARG; }
+                }
+                std::lock_guard<std::mutex> lk(mu);
+                if (seen.size() >= 16) seen.erase(seen.begin());
+                seen.push_back(std::move(blob));
+            }
         }
         if (!pairing_check2<FPP, PP>(A.to_affine(), g2[0], B.to_affine(), g2[1])) {
             set_error("plonk verification failed: pairing check");

@@ -94,7 +94,11 @@ void apk_ctx_destroy(apk_ctx* ctx);
  * workspace, no circuit.  Used to shard ONE large MSM by index range across GPUs (BASELINE.json configs[3]):
  * each rank builds a context over its slice of the SRS, runs apk_msm_g1 on its slice of the scalars, and the
  * partial sums (one point per rank) are all-gathered and added (algoplonk_amd/parallel.py).  apk_msm_g1* with
- * basis 0 and the device-memory helpers work on it; apk_prove / apk_ntt / apk_ctx_get_vk return APK_ERR_STATE. */
+ * basis 0 and the device-memory helpers work on it; apk_prove / apk_ntt / apk_ctx_get_vk return APK_ERR_STATE.
+ * The bases must lie in the prime-order subgroup (every KZG SRS does): the tables hold R^-1 * P_i so that Montgomery-form scalars
+ * are used as they arrive, and (a R)(R^-1 P) = a P holds only for points of order r.  BN254's G1 has cofactor 1; an on-curve
+ * BLS12-381 point outside the subgroup gives a different sum than gnark's MultiExp (not checked: a subgroup test per base would
+ * double the table build). */
 int apk_msm_ctx_create(int curve, int device, const void* bases, uint64_t count, int msm_window, apk_ctx** out);
 
 /* Verifying-key commitments produced during context creation (the 8+k MSMs of plonk.Setup).

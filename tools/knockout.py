@@ -46,7 +46,7 @@ def rate():
 
 os.environ["APK_DEBUG_SKIP"] = "0"
 rate()                                       # every slot has sorted a batch: the skipped sort phases leave valid data behind
-NAMES = {1: "count pass + column scan", 32: "scan launches", 64: "scatter pass", 97: "whole sort", 2: "accumulate", 4: "merge",
+NAMES = {1: "count pass + column scan (two-level: the whole sort)", 32: "scan launches", 64: "scatter pass", 97: "whole sort", 2: "accumulate", 4: "merge",
          8: "row/column sums", 16: "bit sums + final", 28: "whole tail", 125: "everything but accumulate", 127: "everything"}
 base = None
 for mask in (0, 1, 32, 64, 97, 2, 4, 8, 16, 28, 125, 127, 0):
