@@ -142,6 +142,8 @@ class CurveBackend : public Backend {
         DevBuf scratch_in;  // upload staging for primitives
         DevBuf ntt_wide;    // NTT_MAX_BATCH transforms of 4n unsaturated-limb elements: the NTT's inter-pass form
         // MSM workspace
+        DevBuf ptot2;   // fused two-level sort: two buffers of partition totals (one in use, one zeroed for the next batch)
+        uint32_t ptot_parity = 0;
         DevBuf sort_tmp, counts, hist, offsets, unit_off, full_off, rem_rank, rem_list, merge_rank, merge_list, scan_blk, sorted, partial, bucket_sum, rowcol, bit_partial, result, result_xyzz, done_count;
         void* h_pinned = nullptr;  // small pinned staging for results: [0,1024) affine, [1024,2048) XYZZ, [2048,4096) scalars
         uint32_t pending_pts = 0;  // MSM sums waiting in h_pinned for their affine conversion (sync_results)
@@ -500,6 +502,27 @@ class CurveBackend : public Backend {
             const uint32_t per_slice = cdiv(maxlen, G);
             uint32_t stage_cap = per_slice * (uint32_t)W_;
             if (stage_cap > MSM_PART_STAGE) stage_cap = MSM_PART_STAGE;
+            // tile of the second level: the mean partition + 15 % (uniform scalars stay within 2 %); at 2^17 that is 74 KiB, so two
+            // workgroups share a CU and the 384 partitions of a three-MSM batch run in one round instead of two.  Partitions
+            // above it (skewed scalars) scatter in HBM.
+            uint32_t tile_cap = (uint32_t)(entries / ((uint64_t)a.batch * P)) + (uint32_t)(entries / ((uint64_t)a.batch * P)) / 7u + 256u;
+            if (tile_cap > MSM_PART_TILE) tile_cap = MSM_PART_TILE;
+            // Two launches instead of four (kernels_msm.h "the two levels in TWO launches"): slice-major runs need no scan between
+            // the levels.  A slice's entries always fit its stage here (per_slice x W <= MSM_PART_STAGE by the choice of G).
+            static const int fused_env = env_int("APK_MSM_SORT_FUSED", 1, 0, 1);
+            const bool fused = fused_env && !graphs_on /* a replayed capture would reuse one totals buffer */ && (uint64_t)per_slice * W_ <= MSM_PART_STAGE && s.ptot2.p &&
+                               (uint64_t)a.batch * G * (P + 1) <= (uint64_t)total_buckets * msm_G_max_ &&
+                               (uint64_t)a.batch * G * stage_cap * 4 <= s.sort_tmp.bytes;
+            if (fused) {
+                uint32_t* pt_cur = ptr<uint32_t>(s.ptot2) + (size_t)(s.ptot_parity & 1u) * MSM_MAX_BATCH * MSM_PART_MAX;
+                uint32_t* pt_next = ptr<uint32_t>(s.ptot2) + (size_t)((s.ptot_parity & 1u) ^ 1u) * MSM_MAX_BATCH * MSM_PART_MAX;
+                s.ptot_parity ^= 1u;
+                msm_part1_kernel<FRP><<<gd, dth, (size_t)stage_cap * 4, st>>>(a, win_, pc, T.n_bases, G, ptr<uint32_t>(s.sort_tmp), stage_cap, pcounts, pt_cur);
+                KCHK();
+                msm_part_sort_runs_kernel<0><<<dim3(P, a.batch), 1024, (size_t)tile_cap * 4, st>>>(
+                    ptr<uint32_t>(s.sort_tmp), stage_cap, pcounts, pt_cur, pt_next, pc, G, NB_, ptr<uint32_t>(s.hist), ptr<uint32_t>(s.sorted), tile_cap);
+                KCHK();
+            } else {
             msm_part_kernel<FRP, false><<<gd, dth, 0, st>>>(a, win_, pc, NB_, T.n_bases, G, pcounts, nullptr, nullptr, 0);
             KCHK();
             if (small_scan) {
@@ -523,14 +546,10 @@ class CurveBackend : public Backend {
             msm_part_kernel<FRP, true><<<gd, dth, (size_t)stage_cap * 4, st>>>(a, win_, pc1, NB_, T.n_bases, G, pcounts, runstart, ptr<uint32_t>(s.sort_tmp),
                                                                                stage_cap);
             KCHK();
-            // tile of the second level: the mean partition + 15 % (uniform scalars stay within 2 %); at 2^17 that is 74 KiB, so two
-            // workgroups share a CU and the 384 partitions of a three-MSM batch run in one round instead of two.  Partitions
-            // above it (skewed scalars) scatter in HBM.
-            uint32_t tile_cap = (uint32_t)(entries / ((uint64_t)a.batch * P)) + (uint32_t)(entries / ((uint64_t)a.batch * P)) / 7u + 256u;
-            if (tile_cap > MSM_PART_TILE) tile_cap = MSM_PART_TILE;
             msm_part_sort_kernel<0><<<dim3(P, a.batch), 1024, (size_t)tile_cap * 4, st>>>(ptr<uint32_t>(s.sort_tmp), runstart, ptot, pc, G, NB_,
                                                                                           ptr<uint32_t>(s.hist), ptr<uint32_t>(s.sorted), tile_cap);
             KCHK();
+            }
         } else if (APK_PHASE(1)) {
         msm_digits_kernel<FRP, false><<<gd, dth, lds, st>>>(a, win_, NB_, T.n_bases, G, ptr<uint32_t>(s.counts), nullptr, nullptr);
         KCHK();
@@ -541,13 +560,26 @@ class CurveBackend : public Backend {
             const uint32_t nblk = cdiv(total_buckets, MSM_SCAN_BLOCK);   // <= 1024: total_buckets <= 4 * 2^15... checked at init
             uint32_t* blk_tot = ptr<uint32_t>(s.scan_blk);
             uint32_t* blk_bins = blk_tot + 3 * nblk;
-            msm_scan_local_kernel<0><<<nblk, MSM_SCAN_BLOCK, 0, st>>>(ptr<uint32_t>(s.hist), total_buckets, unit, ptr<uint32_t>(s.offsets),
-                                                                       ptr<uint32_t>(s.unit_off), ptr<uint32_t>(s.full_off), ptr<uint32_t>(s.rem_rank),
-                                                                       ptr<uint32_t>(s.merge_rank), blk_tot, blk_bins, nblk);
-            KCHK();
-            msm_scan_totals_kernel<0><<<1, MSM_SCAN_BLOCK, 0, st>>>(blk_tot, blk_bins, nblk, total_buckets, ptr<uint32_t>(s.offsets),
-                                                                     ptr<uint32_t>(s.unit_off), ptr<uint32_t>(s.full_off));
-            KCHK();
+            // APK_MSM_SCAN_FUSED=1: two launches - the last workgroup of the local scan runs the totals step.  Built and measured
+            // (round 4, same box, interleaved): 506 -> 472 proofs/s at BN254 2^17 and a lone proof 3.36 -> 3.41 ms - every scan
+            // workgroup then carries the totals step's 40 KiB of LDS and an agent-scope fence, and the step itself runs behind the
+            // slowest of them instead of on an idle CU.  Off; three launches stay.
+            static const int scan_fused = env_int("APK_MSM_SCAN_FUSED", 0, 0, 1);
+            uint32_t* scan_done = ptr<uint32_t>(s.done_count) + MSM_MAX_BATCH;
+            if (scan_fused) {
+                msm_scan_local_kernel<1><<<nblk, MSM_SCAN_BLOCK, 0, st>>>(ptr<uint32_t>(s.hist), total_buckets, unit, ptr<uint32_t>(s.offsets),
+                                                                           ptr<uint32_t>(s.unit_off), ptr<uint32_t>(s.full_off), ptr<uint32_t>(s.rem_rank),
+                                                                           ptr<uint32_t>(s.merge_rank), blk_tot, blk_bins, nblk, scan_done);
+                KCHK();
+            } else {
+                msm_scan_local_kernel<0><<<nblk, MSM_SCAN_BLOCK, 0, st>>>(ptr<uint32_t>(s.hist), total_buckets, unit, ptr<uint32_t>(s.offsets),
+                                                                           ptr<uint32_t>(s.unit_off), ptr<uint32_t>(s.full_off), ptr<uint32_t>(s.rem_rank),
+                                                                           ptr<uint32_t>(s.merge_rank), blk_tot, blk_bins, nblk, scan_done);
+                KCHK();
+                msm_scan_totals_kernel<0><<<1, MSM_SCAN_BLOCK, 0, st>>>(blk_tot, blk_bins, nblk, total_buckets, ptr<uint32_t>(s.offsets),
+                                                                         ptr<uint32_t>(s.unit_off), ptr<uint32_t>(s.full_off));
+                KCHK();
+            }
             msm_scan_apply_kernel<0><<<nblk, MSM_SCAN_BLOCK, 0, st>>>(blk_tot, blk_bins, ptr<uint32_t>(s.hist), ptr<uint32_t>(s.rem_rank),
                                                                       ptr<uint32_t>(s.merge_rank), nblk,
                                                                       total_buckets, unit, ptr<uint32_t>(s.offsets), ptr<uint32_t>(s.unit_off),
@@ -780,7 +812,11 @@ class CurveBackend : public Backend {
         CHK(s.counts.alloc((size_t)tb * msm_G_max_ * 4));
         CHK(s.sorted.alloc(entries * 4));
         if (env_int("APK_MSM_SORT2", -1, -1, 1) != 0 && part_cfg_.P >= 4 && (msm_bases_ >= 65536u || env_int("APK_MSM_SORT2", -1, -1, 1) == 1))
-            CHK(s.sort_tmp.alloc(entries * 4));   // two-level sort: packed entries between the levels
+        {
+            CHK(s.sort_tmp.alloc((entries + (uint64_t)batch * 1024u * (uint64_t)W_ + 4096u) * 4));   // two-level sort: packed entries between the levels (slice-major runs: a few entries of slack per slice)
+            CHK(s.ptot2.alloc((size_t)2 * MSM_MAX_BATCH * MSM_PART_MAX * 4));
+            HIPCHK(hipMemset(s.ptot2.p, 0, (size_t)2 * MSM_MAX_BATCH * MSM_PART_MAX * 4));
+        }
         {   // unit partials: entries / 16 + a remainder per bucket - or, for small batches, entries / MSM_UNIT_SMALL (run_msm_body)
             const uint64_t big = entries / MSM_UNIT_MIN + tb;
             const uint64_t small = (entries < MSM_SMALL_ENTRIES ? entries : MSM_SMALL_ENTRIES) / MSM_UNIT_SMALL + tb;
@@ -795,8 +831,8 @@ class CurveBackend : public Backend {
         CHK(s.bit_partial.alloc((size_t)batch * 2 * 32 * sizeof(PtU)));
         CHK(s.result.alloc(MSM_MAX_BATCH * sizeof(Aff)));
         CHK(s.result_xyzz.alloc(MSM_MAX_BATCH * sizeof(Pt)));
-        CHK(s.done_count.alloc(MSM_MAX_BATCH * sizeof(uint32_t)));
-        HIPCHK(hipMemset(s.done_count.p, 0, MSM_MAX_BATCH * sizeof(uint32_t)));
+        CHK(s.done_count.alloc((MSM_MAX_BATCH + 1) * sizeof(uint32_t)));   // per MSM: bit sums done; + 1: scan workgroups done
+        HIPCHK(hipMemset(s.done_count.p, 0, (MSM_MAX_BATCH + 1) * sizeof(uint32_t)));
         return APK_OK;
     }
 
@@ -921,6 +957,8 @@ class CurveBackend : public Backend {
         }
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_STAGE * 4));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_sort_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_TILE * 4));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part1_kernel<FRP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_STAGE * 4));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_sort_runs_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_TILE * 4));
         DevBuf srs;
         CHK(srs.alloc(count * sizeof(Aff)));
         HIPCHK(hipMemcpy(srs.p, bases, count * sizeof(Aff), hipMemcpyHostToDevice));
@@ -1020,6 +1058,8 @@ class CurveBackend : public Backend {
         }
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_STAGE * 4));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_sort_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_TILE * 4));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part1_kernel<FRP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_STAGE * 4));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_sort_runs_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_TILE * 4));
         // proving slots
         int nslots = d->slots > 0 ? d->slots : 1;
         // more than 16 concurrently active streams collapse the throughput (24: -25 %, 32: -40 %, 48: -55 % at 2^17); callers

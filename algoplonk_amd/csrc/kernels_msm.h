@@ -510,6 +510,207 @@ __global__ void __launch_bounds__(1024) msm_part_sort_kernel(const uint32_t* __r
     }
 }
 
+// ---- the two levels in TWO launches (round 4; APK_MSM_SORT_FUSED) ------------------------------------------------------------
+// The four launches above are count - scan - scatter - sort because the first level's runs are laid out in the order (msm,
+// partition, slice), which needs every slice's counts before any slice can place an entry.  Laid out SLICE-MAJOR instead - slice g
+// of msm b owns tmp[(b G + g) cap, +cap), its entries in partition order exactly as they sit in its LDS stage - a slice needs
+// nobody's counts but its own: ONE launch counts (LDS), scans (one wave), recodes the scalars it still holds in registers and
+// scatters into the stage, copies the stage out as one contiguous block, and leaves its run table (P + 1 offsets) and its share
+// of the partition totals (one device atomic per partition and slice: ~8 k per MSM against the 2 M entries it sorts).  The second
+// level gathers a partition's entries from its G runs (a wave per run) instead of one range.  Launches per batch 7 -> 5, the
+// digits are still extracted twice but the scalars are read once, the counter arrays between the launches are gone.
+template <class FR, class F>
+__device__ __forceinline__ void msm_for_each_digit(const Fe<FR>& s, const MsmWindows& win, F&& f) {
+    using Fr = Fe<FR>;
+    uint32_t carry = 0;
+    uint64_t buf = 0;
+    int avail = 0, j = 0;
+#pragma unroll
+    for (int li = 0; li < Fr::N; li++) {
+        buf |= (uint64_t)s.l[li] << avail;
+        avail += 32;
+        while (j < win.W && (avail >= (int)win.width[j] || li == Fr::N - 1)) {
+            const int c = win.width[j];
+            const uint32_t half = 1u << (c - 1);
+            uint32_t d = ((uint32_t)buf & ((1u << c) - 1u)) + carry;
+            buf >>= c;
+            avail -= c;
+            uint32_t neg = 0;
+            if (d > half) { d = (1u << c) - d; neg = 1; carry = 1; }
+            else carry = 0;
+            if (d != 0) f((uint32_t)j, d - 1, neg);
+            j++;
+        }
+    }
+}
+
+constexpr int MSM_PART1_HOLD = 3;   // scalars a lane keeps in registers between the two passes (2 049 per slice / 1 024 lanes)
+template <class FR>
+__global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part1_kernel(MsmBatchArgs a, MsmWindows win, MsmPartCfg pc, uint32_t n_max, uint32_t G,
+                                                                      uint32_t* __restrict__ tmp, uint32_t cap,       // cap entries per slice
+                                                                      uint32_t* __restrict__ runtab,                   // [batch][G][P + 1]
+                                                                      uint32_t* __restrict__ ptot) {                   // [batch][P], zero on entry
+    wave_priority<APK_PRIO_SORT>();
+    using Fr = Fe<FR>;
+    __shared__ uint32_t cur[MSM_PART_MAX], lstart[MSM_PART_MAX + 1];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t* stage = reinterpret_cast<uint32_t*>(smem_raw);
+    const uint32_t g = blockIdx.x, b = blockIdx.y;
+    const uint32_t P = pc.P, pb_log = pc.pb_log, pb_mask = (1u << pc.pb_log) - 1u;
+    for (uint32_t k = threadIdx.x; k < P; k += blockDim.x) cur[k] = 0u;
+    __syncthreads();
+    const uint32_t len = a.len[b];
+    const uint32_t per = (len + G - 1) / G;
+    const uint32_t lo = min(g * per, len), hi = min(lo + per, len);
+    const Fr* __restrict__ sc = reinterpret_cast<const Fr*>(a.scalars[b]);
+    Fr held[MSM_PART1_HOLD];
+    const bool hold = (hi - lo) <= (uint32_t)MSM_PART1_HOLD * blockDim.x;    // uniform
+    {
+        int it = 0;
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x, it++) {
+#ifndef APK_MSM_NO_RINV
+            const Fr s = sc[i];
+#else
+            const Fr s = Fr::from_mont(sc[i]);
+#endif
+            if (hold) {
+#pragma unroll
+                for (int h = 0; h < MSM_PART1_HOLD; h++) if (h == it) held[h] = s;    // static register indices
+            }
+            msm_for_each_digit<FR>(s, win, [&](uint32_t, uint32_t k, uint32_t) { atomicAdd(&cur[k >> pb_log], 1u); });
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {      // exclusive prefix of the partition counts: a contiguous chunk per lane, a shuffle scan over the lanes
+        const uint32_t lane = threadIdx.x, chunk = (P + 63u) / 64u, k0 = lane * chunk;
+        uint32_t sum = 0;
+        for (uint32_t i = 0; i < chunk; i++) if (k0 + i < P) sum += cur[k0 + i];
+        uint32_t inc = sum;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t v = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += v;
+        }
+        uint32_t run = inc - sum;
+        for (uint32_t i = 0; i < chunk; i++) if (k0 + i < P) { lstart[k0 + i] = run; run += cur[k0 + i]; }
+        if (lane == 63) lstart[P] = inc;
+    }
+    __syncthreads();
+    uint32_t* rt = runtab + ((size_t)b * G + g) * (P + 1);
+    for (uint32_t k = threadIdx.x; k < P; k += blockDim.x) {
+        const uint32_t c = cur[k];
+        if (c) atomicAdd(&ptot[b * P + k], c);
+        rt[k] = lstart[k];
+        cur[k] = lstart[k];
+    }
+    if (threadIdx.x == 0) rt[P] = lstart[P];
+    __syncthreads();
+    {
+        int it = 0;
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x, it++) {
+            Fr s;
+            if (hold) {
+#pragma unroll
+                for (int h = 0; h < MSM_PART1_HOLD; h++) if (h == it) s = held[h];
+            } else {
+#ifndef APK_MSM_NO_RINV
+                s = sc[i];
+#else
+                s = Fr::from_mont(sc[i]);
+#endif
+            }
+            const uint32_t base_idx = a.offset[b] + i;
+            msm_for_each_digit<FR>(s, win, [&](uint32_t j, uint32_t k, uint32_t neg) {
+                const uint32_t pos = atomicAdd(&cur[k >> pb_log], 1u);
+                stage[pos] = (j * n_max + base_idx) | ((k & pb_mask) << pc.idx_bits) | (neg << 31);
+            });
+        }
+    }
+    __syncthreads();
+    const uint32_t total = lstart[P];
+    uint32_t* dst = tmp + ((size_t)b * G + g) * cap;
+    for (uint32_t l = threadIdx.x; l < total; l += blockDim.x) dst[l] = stage[l];     // one contiguous block: whole lines
+}
+
+// grid (P, batch): the second level over slice-major runs.  ptot_next: the other totals buffer, zeroed here for the next batch.
+template <int DUMMY>
+__global__ void __launch_bounds__(1024) msm_part_sort_runs_kernel(const uint32_t* __restrict__ tmp, uint32_t cap, const uint32_t* __restrict__ runtab,
+                                                                const uint32_t* __restrict__ ptot, uint32_t* __restrict__ ptot_next, MsmPartCfg pc,
+                                                                uint32_t G, uint32_t nb, uint32_t* __restrict__ hist, uint32_t* __restrict__ sorted,
+                                                                uint32_t tile_cap) {
+    wave_priority<APK_PRIO_SORT>();
+    __shared__ uint32_t cnt[MSM_PART_COUNTERS], cur[MSM_PART_COUNTERS];
+    __shared__ uint32_t s_red[16];
+    __shared__ uint32_t s_first;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t* tile = reinterpret_cast<uint32_t*>(smem_raw);
+    const uint32_t p = blockIdx.x, b = blockIdx.y, t = threadIdx.x, wave = t >> 6, lane = t & 63u;
+    const uint32_t P = pc.P, PB = 1u << pc.pb_log, pb_mask = PB - 1u;
+    const uint32_t sets_log = pc.pb_log > 6 ? 0u : min(4u, 10u - pc.pb_log);
+    const uint32_t SETS = 1u << sets_log, NC = PB << sets_log;
+    const uint32_t set_base = (wave & (SETS - 1u)) << pc.pb_log;
+    const uint32_t KEEP = ((1u << pc.idx_bits) - 1u) | 0x80000000u;
+    // first slot of this partition in `sorted` = the totals of every (msm, partition) before it
+    {
+        const uint32_t before = b * P + p;
+        uint32_t sum = 0;
+        for (uint32_t q = t; q < before; q += blockDim.x) sum += ptot[q];
+        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_down(sum, d, 64);
+        if (lane == 0) s_red[wave] = sum;
+        if (t < NC) cnt[t] = 0u;
+        __syncthreads();
+        if (t == 0) { uint32_t f = 0; for (uint32_t w = 0; w < (blockDim.x >> 6); w++) f += s_red[w]; s_first = f; }
+        if (p == 0 && b == 0) for (uint32_t q = t; q < MSM_MAX_BATCH * P; q += blockDim.x) ptot_next[q] = 0u;
+        __syncthreads();
+    }
+    const uint32_t first = s_first;
+    const uint32_t n = ptot[b * P + p];
+    const uint32_t waves = blockDim.x >> 6;
+    const uint32_t* rt0 = runtab + (size_t)b * G * (P + 1) + p;
+    // count: a wave per run
+    for (uint32_t g = wave; g < G; g += waves) {
+        const uint32_t r0 = rt0[(size_t)g * (P + 1)], r1 = rt0[(size_t)g * (P + 1) + 1];
+        const uint32_t* src = tmp + ((size_t)b * G + g) * cap;
+        for (uint32_t l = r0 + lane; l < r1; l += 64u) atomicAdd(&cnt[set_base + ((src[l] >> pc.idx_bits) & pb_mask)], 1u);
+    }
+    __syncthreads();
+    uint32_t mine = 0;
+    const uint32_t my_at = ((t & (SETS - 1u)) << pc.pb_log) + (t >> sets_log);
+    if (t < NC) { mine = cnt[my_at]; cur[t] = mine; }
+    __syncthreads();
+    for (uint32_t d = 1; d < NC; d <<= 1) {
+        uint32_t v = 0;
+        if (t < NC && t >= d) v = cur[t - d];
+        __syncthreads();
+        if (t < NC) cur[t] += v;
+        __syncthreads();
+    }
+    const bool in_lds = n <= tile_cap;                               // uniform
+    uint32_t incl = 0, before = 0;
+    if (t < NC) {
+        incl = cur[t];
+        if ((t & (SETS - 1u)) == SETS - 1u) before = t >= SETS ? cur[t - SETS] : 0u;
+    }
+    __syncthreads();
+    if (t < NC) {
+        if ((t & (SETS - 1u)) == SETS - 1u) hist[(size_t)b * nb + p * PB + (t >> sets_log)] = incl - before;
+        cnt[my_at] = (in_lds ? 0u : first) + incl - mine;
+    }
+    __syncthreads();
+    for (uint32_t g = wave; g < G; g += waves) {
+        const uint32_t r0 = rt0[(size_t)g * (P + 1)], r1 = rt0[(size_t)g * (P + 1) + 1];
+        const uint32_t* src = tmp + ((size_t)b * G + g) * cap;
+        for (uint32_t l = r0 + lane; l < r1; l += 64u) {
+            const uint32_t e = src[l];
+            const uint32_t pos = atomicAdd(&cnt[set_base + ((e >> pc.idx_bits) & pb_mask)], 1u);
+            if (in_lds) tile[pos] = e & KEEP; else sorted[pos] = e & KEEP;
+        }
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (uint32_t i = t; i < n; i += blockDim.x) sorted[first + i] = tile[i];
+    }
+}
+
 // ---- exclusive scans of the bucket counts: entry offsets and work-unit offsets ------------------------------------------
 // A bucket of h entries is cut into floor(h/unit) FULL work units and, if h % unit != 0, one REMAINDER unit.
 //   offsets[k]  = sum_{i<k} hist[i]                 (entries)
@@ -529,13 +730,59 @@ constexpr int MSM_SCAN_MAX_BLOCKS = 256;   // MSM_MAX_BATCH * 2^16 buckets / MSM
 constexpr int MSM_MERGE_BINS = 16;
 constexpr int MSM_BINS = MSM_UNIT_MAX + MSM_MERGE_BINS;   // [0, MSM_UNIT_MAX): remainder lengths, then the unit counts
 
-template <int DUMMY>
+// one block: exclusive scan of the (<= 1024) block totals in place; grand totals to offsets[total] / unit_off[total] /
+// full_off[total]; block_bins[blk][r] becomes the first rem_list (merge_list) position of block blk's buckets with remainder r (unit count r - MSM_UNIT_MAX)
+// A device function: its own launch (msm_scan_totals_kernel), or the last workgroup of msm_scan_local_kernel to finish (round 4:
+// two scan launches instead of three).
+struct MsmScanTotalsLds {
+    uint32_t s_bintot[MSM_BINS];
+    uint16_t s_bins[MSM_SCAN_MAX_BLOCKS * MSM_BINS];   // per-block remainder / unit-count histograms (<= 1024 each): 40 KB
+};
+__device__ __forceinline__ void msm_scan_totals_body(uint32_t* __restrict__ block_tot, uint32_t* __restrict__ block_bins, uint32_t nblocks, uint32_t total,
+                                                     uint32_t* __restrict__ offsets, uint32_t* __restrict__ unit_off, uint32_t* __restrict__ full_off,
+                                                     uint32_t* s_cnt, uint32_t* s_unit, uint32_t* s_full, MsmScanTotalsLds& L) {
+    const uint32_t t = threadIdx.x;
+    const uint32_t h = t < nblocks ? block_tot[t] : 0u, hu = t < nblocks ? block_tot[nblocks + t] : 0u,
+                   hf = t < nblocks ? block_tot[2 * nblocks + t] : 0u;
+    s_cnt[t] = h; s_unit[t] = hu; s_full[t] = hf;
+    for (uint32_t i = t; i < nblocks * MSM_BINS; i += MSM_SCAN_BLOCK) L.s_bins[i] = (uint16_t)block_bins[i];
+    __syncthreads();
+    if (t < MSM_BINS) {   // per remainder length / unit count: the total over the blocks
+        uint32_t run = 0;
+        for (uint32_t blk = 0; blk < nblocks; blk++) run += L.s_bins[blk * MSM_BINS + t];
+        L.s_bintot[t] = run;
+    }
+    __syncthreads();
+    for (uint32_t d = 1; d < MSM_SCAN_BLOCK; d <<= 1) {
+        uint32_t vc = 0, vu = 0, vf = 0;
+        if (t >= d) { vc = s_cnt[t - d]; vu = s_unit[t - d]; vf = s_full[t - d]; }
+        __syncthreads();
+        s_cnt[t] += vc; s_unit[t] += vu; s_full[t] += vf;
+        __syncthreads();
+    }
+    if (t < nblocks) { block_tot[t] = s_cnt[t] - h; block_tot[nblocks + t] = s_unit[t] - hu; block_tot[2 * nblocks + t] = s_full[t] - hf; }
+    if (t == MSM_SCAN_BLOCK - 1) { offsets[total] = s_cnt[t]; unit_off[total] = s_unit[t]; full_off[total] = s_full[t]; }
+    if (t < MSM_BINS) {   // longest remainders (most partials) first: base of bin t in its list, then the exclusive prefix over the blocks
+        uint32_t run = 0;
+        const uint32_t top = t < (uint32_t)MSM_UNIT_MAX ? MSM_UNIT_MAX : MSM_BINS;
+        for (uint32_t r = top - 1; r > t; r--) run += L.s_bintot[r];
+        for (uint32_t blk = 0; blk < nblocks; blk++) {
+            const uint32_t v = L.s_bins[blk * MSM_BINS + t];
+            block_bins[blk * MSM_BINS + t] = run;
+            run += v;
+        }
+    }
+}
+// FUSED = 1: the workgroup that finishes last (an agent-scope counter, reset by that workgroup; no spinning) goes on to run the
+// totals step, so the scan is two launches; FUSED = 0: msm_scan_totals_kernel follows as a launch of its own.
+template <int FUSED>
 __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_local_kernel(const uint32_t* __restrict__ hist, uint32_t total, uint32_t unit,
                                                                          uint32_t* __restrict__ offsets, uint32_t* __restrict__ unit_off,
                                                                          uint32_t* __restrict__ full_off, uint32_t* __restrict__ rem_rank,
                                                                          uint32_t* __restrict__ merge_rank,
                                                                          uint32_t* __restrict__ block_tot /* [3][nblocks] */,
-                                                                         uint32_t* __restrict__ block_bins /* [nblocks][MSM_BINS] */, uint32_t nblocks) {
+                                                                         uint32_t* __restrict__ block_bins /* [nblocks][MSM_BINS] */, uint32_t nblocks,
+                                                                         uint32_t* __restrict__ done) {
     wave_priority<APK_PRIO_SORT>();
     __shared__ uint32_t s_cnt[MSM_SCAN_BLOCK];
     __shared__ uint32_t s_unit[MSM_SCAN_BLOCK];
@@ -561,10 +808,23 @@ __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_local_kernel(const ui
         block_tot[blockIdx.x] = s_cnt[t]; block_tot[nblocks + blockIdx.x] = s_unit[t]; block_tot[2 * nblocks + blockIdx.x] = s_full[t];
     }
     if (t < MSM_BINS) block_bins[blockIdx.x * MSM_BINS + t] = s_bins[t];
+    if constexpr (FUSED != 0) {
+        __shared__ MsmScanTotalsLds L;
+        __shared__ uint32_t s_last;
+        __threadfence();                 // this workgroup's totals and bins, written by several lanes, before the count
+        __syncthreads();
+        if (t == 0) {
+            const uint32_t old = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (old == gridDim.x - 1) ? 1u : 0u;
+            if (s_last) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!s_last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        msm_scan_totals_body(block_tot, block_bins, nblocks, total, offsets, unit_off, full_off, s_cnt, s_unit, s_full, L);
+    }
 }
 
-// one block: exclusive scan of the (<= 1024) block totals in place; grand totals to offsets[total] / unit_off[total] /
-// full_off[total]; block_bins[blk][r] becomes the first rem_list (merge_list) position of block blk's buckets with remainder r (unit count r - MSM_UNIT_MAX)
 template <int DUMMY>
 __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_totals_kernel(uint32_t* __restrict__ block_tot, uint32_t* __restrict__ block_bins,
                                                                           uint32_t nblocks, uint32_t total, uint32_t* __restrict__ offsets,
@@ -573,39 +833,8 @@ __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_totals_kernel(uint32_
     __shared__ uint32_t s_cnt[MSM_SCAN_BLOCK];
     __shared__ uint32_t s_unit[MSM_SCAN_BLOCK];
     __shared__ uint32_t s_full[MSM_SCAN_BLOCK];
-    __shared__ uint32_t s_bintot[MSM_BINS];
-    __shared__ uint16_t s_bins[MSM_SCAN_MAX_BLOCKS * MSM_BINS];   // per-block remainder / unit-count histograms (<= 1024 each): 40 KB
-    const uint32_t t = threadIdx.x;
-    const uint32_t h = t < nblocks ? block_tot[t] : 0u, hu = t < nblocks ? block_tot[nblocks + t] : 0u,
-                   hf = t < nblocks ? block_tot[2 * nblocks + t] : 0u;
-    s_cnt[t] = h; s_unit[t] = hu; s_full[t] = hf;
-    for (uint32_t i = t; i < nblocks * MSM_BINS; i += MSM_SCAN_BLOCK) s_bins[i] = (uint16_t)block_bins[i];
-    __syncthreads();
-    if (t < MSM_BINS) {   // per remainder length / unit count: the total over the blocks
-        uint32_t run = 0;
-        for (uint32_t blk = 0; blk < nblocks; blk++) run += s_bins[blk * MSM_BINS + t];
-        s_bintot[t] = run;
-    }
-    __syncthreads();
-    for (uint32_t d = 1; d < MSM_SCAN_BLOCK; d <<= 1) {
-        uint32_t vc = 0, vu = 0, vf = 0;
-        if (t >= d) { vc = s_cnt[t - d]; vu = s_unit[t - d]; vf = s_full[t - d]; }
-        __syncthreads();
-        s_cnt[t] += vc; s_unit[t] += vu; s_full[t] += vf;
-        __syncthreads();
-    }
-    if (t < nblocks) { block_tot[t] = s_cnt[t] - h; block_tot[nblocks + t] = s_unit[t] - hu; block_tot[2 * nblocks + t] = s_full[t] - hf; }
-    if (t == MSM_SCAN_BLOCK - 1) { offsets[total] = s_cnt[t]; unit_off[total] = s_unit[t]; full_off[total] = s_full[t]; }
-    if (t < MSM_BINS) {   // longest remainders (most partials) first: base of bin t in its list, then the exclusive prefix over the blocks
-        uint32_t run = 0;
-        const uint32_t top = t < (uint32_t)MSM_UNIT_MAX ? MSM_UNIT_MAX : MSM_BINS;
-        for (uint32_t r = top - 1; r > t; r--) run += s_bintot[r];
-        for (uint32_t blk = 0; blk < nblocks; blk++) {
-            const uint32_t v = s_bins[blk * MSM_BINS + t];
-            block_bins[blk * MSM_BINS + t] = run;
-            run += v;
-        }
-    }
+    __shared__ MsmScanTotalsLds L;
+    msm_scan_totals_body(block_tot, block_bins, nblocks, total, offsets, unit_off, full_off, s_cnt, s_unit, s_full, L);
 }
 
 template <int DUMMY>

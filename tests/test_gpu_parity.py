@@ -674,7 +674,10 @@ print("SHA", hashlib.sha256(MarshalProof(plonk.Prove(ccs, pk, w, blinding(cv, 3)
                        # round 4: the layouts the large sorts take - 2 048 partitions of 16 buckets with wave-private counters,
                        # sixteen lanes per run in the copy-out, the three-launch partition scan - forced at a size the test can afford
                        {"APK_MSM_SORT2": "1", "APK_MSM_PART_PBLOG": "4"}, {"APK_MSM_SORT2": "1", "APK_MSM_PART_PBLOG": "6", "APK_MSM_PART_SMALL_SCAN": "0"},
-                       {"APK_MSM_SORTED_MERGE": "0"}, {"APK_MSM_LEAN_TAIL": "1", "APK_MSM_ROWCOL_LANES": "8"}]),
+                       {"APK_MSM_SORTED_MERGE": "0"}, {"APK_MSM_LEAN_TAIL": "1", "APK_MSM_ROWCOL_LANES": "8"},
+                       # the four-launch form of the two-level sort (count - scan - scatter - sort) behind the two-launch default
+                       {"APK_MSM_SORT2": "1", "APK_MSM_SORT_FUSED": "0"}, {"APK_MSM_SORT2": "1", "APK_MSM_SORT_FUSED": "0", "APK_MSM_PART_PBLOG": "4"},
+                       {"APK_MSM_SCAN_FUSED": "1"}, {"APK_MSM_GRAPH": "1", "APK_MSM_SORT2": "1"}]),
     ("bls12-381", 10, 12, [{"APK_MSM_LEAN_TAIL": "1", "APK_NTT_RADIX4": "1"}, {"APK_MSM_SORT2": "1"},
                            {"APK_MSM_SORT2": "1", "APK_MSM_PART_PBLOG": "3", "APK_MSM_PART_SMALL_SCAN": "0"}]),
 ])
@@ -733,7 +736,9 @@ print("SKEWED_OK")
 """
 
 
-@pytest.mark.parametrize("extra", [{}, {"APK_MSM_PART_PBLOG": "4", "APK_MSM_PART_SMALL_SCAN": "0"}], ids=["default-layout", "16-bucket-partitions"])
+@pytest.mark.parametrize("extra", [{}, {"APK_MSM_PART_PBLOG": "4", "APK_MSM_PART_SMALL_SCAN": "0"}, {"APK_MSM_SORT_FUSED": "0"},
+                                   {"APK_MSM_SORT_FUSED": "0", "APK_MSM_PART_PBLOG": "4", "APK_MSM_PART_SMALL_SCAN": "0"}],
+                         ids=["default-layout", "16-bucket-partitions", "four-launch", "four-launch-16-bucket-partitions"])
 def test_two_level_sort_with_skewed_scalars(gpu, extra):
     """The two-level sort's overflow paths: all-equal scalars put a whole MSM's entries into W buckets, so the partitions that
     hold them are far larger than the LDS tile of the second level (it then scatters in HBM) and every other partition is
