@@ -258,10 +258,11 @@ static int ensure(apk_comm* c, void** p, size_t* cap, size_t need) {
 }
 
 // ---- HIP IPC transfers: {generation, handle, offset, bytes} over the control plane, one device-to-device pull, one ack ----
-struct IpcMsg { uint32_t gen, pad; uint64_t offset, bytes; hipIpcMemHandle_t h; };
+struct IpcMsg { uint32_t gen, pad; uint64_t offset, bytes, cap; hipIpcMemHandle_t h; };   // cap: size of the exported allocation
 static int ipc_offer(apk_comm* c, int fd, size_t offset, size_t bytes) {      // the exporter's side
     IpcMsg m{};
     m.gen = c->export_gen; m.offset = offset; m.bytes = bytes; m.h = c->export_handle;
+    m.cap = c->rank == 0 ? c->stage_cap : c->wire_out_cap;
     return send_all(fd, &m, sizeof m);
 }
 static int ipc_wait_ack(int fd) {
@@ -283,6 +284,7 @@ static int ipc_pull(apk_comm* c, int from_rank, int fd, void* d_dst, size_t expe
         mp.gen = m.gen;
     }
     if (e == hipSuccess && m.bytes != expect) { set_error("comm: peer offered %llu bytes, %llu expected", (unsigned long long)m.bytes, (unsigned long long)expect); st = APK_ERR_STATE; }
+    if (e == hipSuccess && (m.offset > m.cap || m.bytes > m.cap - m.offset)) { set_error("comm: peer's offer leaves its exported buffer (%llu + %llu of %llu bytes)", (unsigned long long)m.offset, (unsigned long long)m.bytes, (unsigned long long)m.cap); st = APK_ERR_STATE; }
     // hipMemcpy device-to-device returns before the copy is done and the contexts' streams are non-blocking (they do not order
     // themselves behind the null stream): copy on the communicator's own stream and wait for it
     if (e == hipSuccess && st == APK_OK) e = hipMemcpyAsync(d_dst, (const uint8_t*)mp.p + m.offset, m.bytes, hipMemcpyDeviceToDevice, c->stream);
@@ -794,12 +796,12 @@ int apk_comm_allgather_device(apk_comm* c, void* d_all, size_t bytes) {
         int32_t ok = ensure(c, slot, cap, bytes) == APK_OK && c->cp.copy(CP_USER(c, copy), *slot, mine, bytes, 0) == APK_OK ? 1 : 0;
         std::vector<IpcMsg> msgs(c->world);
         IpcMsg m{};
-        m.gen = c->export_gen; m.offset = 0; m.bytes = ok ? bytes : 0; m.h = c->export_handle;
+        m.gen = c->export_gen; m.offset = 0; m.bytes = ok ? bytes : 0; m.h = c->export_handle; m.cap = *cap;
         CHK(ctl_allgather(c, &m, msgs.data(), sizeof m));
         hipError_t e = hipSetDevice(c->device);
         for (int r = 0; r < c->world && ok; r++) {
             if (r == c->rank) continue;
-            if (msgs[r].bytes != bytes) { ok = 0; break; }
+            if (msgs[r].bytes != bytes || msgs[r].offset > msgs[r].cap || bytes > msgs[r].cap - msgs[r].offset) { ok = 0; break; }
             apk_comm::Mapping& mp = c->maps[r];
             if (e == hipSuccess && (mp.gen != msgs[r].gen || !mp.p)) {
                 if (mp.p) (void)hipIpcCloseMemHandle(mp.p);

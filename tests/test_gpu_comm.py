@@ -164,6 +164,9 @@ def test_bench_line_carries_the_contract_fields(gpu):
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma", "valu") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["kernel"] == "msm_accumulate_kernel"
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-5 and (rf["traffic"] is None or rf["traffic"] > 0)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import check_bench_line
+    check_bench_line(d)          # every derived figure of the line recomputed from the line's own inputs (the CPU tier does the same on the committed lines)
     assert abs(rf["achieved"] - rf["pairs_per_launch"] * rf["algorithmic_bytes_per_pair"] / (rf["avg_launch_ms"] * 1e-3) / 1e9) / rf["achieved"] < 0.01
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["unit"] == "proofs/sec" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
