@@ -602,21 +602,41 @@ class CurveBackend : public Backend {
         // lanes per bucket: ~5 unit partials per lane, so the sequential part and the shuffle tree are balanced; one lane walks up
         // to 32 partials when the GPU has other work (a shuffle level costs every lane of the group an addition, useful or not)
         int lanes_log = 0;
+        const uint32_t per_lane = lean && total_buckets >= 32768u ? 32u : 5u;
         {
             const uint64_t upb = (entries / unit) / total_buckets + 1;  // unit partials per bucket (estimate)
             // (only with enough buckets to fill the SIMDs at one lane each: at BLS12-381 2^14 - 6 144 buckets, 11 partials
             // each - one lane per bucket was measured SLOWER under load, 1 137 -> 1 114 proofs/s)
-            const uint64_t per_lane = lean && total_buckets >= 32768u ? 32 : 5;
             while ((1u << lanes_log) < MSM_COMBINE_LANES && (upb >> lanes_log) > per_lane) lanes_log++;
         }
+        // A batch that has the GPU to itself lets the DEVICE pick the lanes per bucket, from the bucket scan's count of partials per
+        // NON-EMPTY bucket: the host's estimate averages over all buckets, and a skewed input (256 distinct scalars: 4 096 buckets of
+        // 32 partials, the rest empty) then left one lane walking 32 partials (0.56 of that MSM's 1.07 ms).  The grid covers up to
+        // four times the host's lanes; for uniform scalars the two rules agree and the surplus workgroups return at once.
+        static const int dyn_env = env_int("APK_MSM_COMBINE_DYN", 1, 0, 1);
+        const bool dyn_lanes = dyn_env && !lean && APK_PHASE(32);
+        if (dyn_lanes) { lanes_log += 2; if ((1u << lanes_log) > MSM_COMBINE_LANES) lanes_log = 4; }
+        const uint32_t* avg_partials = dyn_lanes ? ptr<uint32_t>(s.scan_blk) + (size_t)(3 + MSM_BINS) * cdiv(total_buckets, MSM_SCAN_BLOCK) : nullptr;
         {   // light and heavy merge in one launch (the heavy blocks return at once when no bucket is skewed)
             const uint32_t normal_blocks = cdiv((uint64_t)total_buckets << lanes_log, 256);
             // the buckets in the order of their partial counts (merge_list): a wave's lanes run the same number of additions
             static const int sorted_merge = env_int("APK_MSM_SORTED_MERGE", 1, 0, 1);
-            if (APK_PHASE(4))
+            // a SMALL batch that has the GPU to itself: four lanes per addition (the merge is a chain of dependent additions on a
+            // few hundred lone waves then).  Measured, lone proofs, same box: BLS12-381 2^14 (2 048 buckets) 3.30 -> 3.05 ms and a
+            // lone MSM 0.59 -> 0.47 ms; BN254 2^17 (16 384 buckets) 3.39 -> 3.48 ms although its lone MSM gains 4 % - the quads'
+            // 1.6 x instructions then compete with the coset transforms that fill the tail - so: up to 4 096 buckets per MSM.
+            static const int cq_env = env_int("APK_MSM_COMBINE_QUAD", -1, -1, 1);
+            const bool cquad = cq_env >= 0 ? cq_env != 0 : (!lean && !graphs_on && NB_ <= 4096u);
+            if (!APK_PHASE(4)) {
+            } else if (cquad) {
+                const uint32_t qblocks = cdiv(((uint64_t)total_buckets << lanes_log) * 4, 256);
+                msm_combine_quad_kernel<FPP><<<qblocks + MSM_HEAVY_BLOCKS, 256, 0, st>>>(
+                    ptr<PtU>(s.partial), ptr<uint32_t>(s.unit_off), sorted_merge ? ptr<uint32_t>(s.merge_list) : nullptr, total_buckets, lanes_log,
+                    qblocks, ptr<PtU>(s.bucket_sum), avg_partials, per_lane);
+            } else
             msm_combine_kernel<FPP><<<normal_blocks + MSM_HEAVY_BLOCKS, 256, 0, st>>>(
                 ptr<PtU>(s.partial), ptr<uint32_t>(s.unit_off), sorted_merge ? ptr<uint32_t>(s.merge_list) : nullptr, total_buckets, lanes_log,
-                normal_blocks, ptr<PtU>(s.bucket_sum));
+                normal_blocks, ptr<PtU>(s.bucket_sum), avg_partials, per_lane);
             KCHK();
         }
         // sum_k k*B_k: row/column sums of the bucket array, bit-wise weighted sums of those, final scaling + affine

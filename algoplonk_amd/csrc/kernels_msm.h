@@ -666,11 +666,41 @@ __global__ void __launch_bounds__(1024) msm_part_sort_runs_kernel(const uint32_t
     const uint32_t n = ptot[b * P + p];
     const uint32_t waves = blockDim.x >> 6;
     const uint32_t* rt0 = runtab + (size_t)b * G * (P + 1) + p;
+    // A partition far above the mean is a SKEWED input (all-equal scalars put a whole MSM's entries of a window into one bucket):
+    // its lanes would then queue up on one LDS counter, 131 k atomics in a row (226 us for such a partition, measured).  There
+    // the lanes of a wave that hold the same bucket add ONCE (a ballot per distinct bucket: one or two rounds when the input is
+    // skewed; never taken for uniform scalars, whose partitions stay within 2 % of the mean).
+    const bool skew = n > tile_cap;                                  // uniform across the workgroup
     // count: a wave per run
     for (uint32_t g = wave; g < G; g += waves) {
         const uint32_t r0 = rt0[(size_t)g * (P + 1)], r1 = rt0[(size_t)g * (P + 1) + 1];
         const uint32_t* src = tmp + ((size_t)b * G + g) * cap;
-        for (uint32_t l = r0 + lane; l < r1; l += 64u) atomicAdd(&cnt[set_base + ((src[l] >> pc.idx_bits) & pb_mask)], 1u);
+        if (!skew) {
+            for (uint32_t l = r0 + lane; l < r1; l += 64u) atomicAdd(&cnt[set_base + ((src[l] >> pc.idx_bits) & pb_mask)], 1u);
+        } else {
+            for (uint32_t l0 = r0; l0 < r1; l0 += 64u) {             // wave-uniform trip count
+                const uint32_t l = l0 + lane;
+                const bool act = l < r1;
+                const uint32_t key = act ? ((src[l] >> pc.idx_bits) & pb_mask) : 0u;
+                uint64_t todo = __ballot(act);
+                // only when the wave really is concentrated (half of its lanes on the first lane's bucket); a partition that is
+                // large but spread over its buckets (256 distinct scalars) keeps the plain atomics
+                {
+                    const uint32_t kf = __shfl(key, todo ? __ffsll((unsigned long long)todo) - 1 : 0, 64);
+                    if (2 * __popcll(__ballot(act && key == kf)) < __popcll(todo)) {
+                        if (act) atomicAdd(&cnt[set_base + key], 1u);
+                        todo = 0;
+                    }
+                }
+                while (todo) {
+                    const int leader = __ffsll((unsigned long long)todo) - 1;
+                    const uint32_t k0 = __shfl(key, leader, 64);
+                    const uint64_t same = __ballot(act && key == k0);
+                    if ((int)lane == leader) atomicAdd(&cnt[set_base + k0], (uint32_t)__popcll(same));
+                    todo &= ~same;
+                }
+            }
+        }
     }
     __syncthreads();
     uint32_t mine = 0;
@@ -699,10 +729,39 @@ __global__ void __launch_bounds__(1024) msm_part_sort_runs_kernel(const uint32_t
     for (uint32_t g = wave; g < G; g += waves) {
         const uint32_t r0 = rt0[(size_t)g * (P + 1)], r1 = rt0[(size_t)g * (P + 1) + 1];
         const uint32_t* src = tmp + ((size_t)b * G + g) * cap;
-        for (uint32_t l = r0 + lane; l < r1; l += 64u) {
-            const uint32_t e = src[l];
-            const uint32_t pos = atomicAdd(&cnt[set_base + ((e >> pc.idx_bits) & pb_mask)], 1u);
-            if (in_lds) tile[pos] = e & KEEP; else sorted[pos] = e & KEEP;
+        if (!skew) {
+            for (uint32_t l = r0 + lane; l < r1; l += 64u) {
+                const uint32_t e = src[l];
+                const uint32_t pos = atomicAdd(&cnt[set_base + ((e >> pc.idx_bits) & pb_mask)], 1u);
+                if (in_lds) tile[pos] = e & KEEP; else sorted[pos] = e & KEEP;
+            }
+        } else {                                                     // skew implies !in_lds: straight to HBM, neighbours together
+            for (uint32_t l0 = r0; l0 < r1; l0 += 64u) {
+                const uint32_t l = l0 + lane;
+                const bool act = l < r1;
+                const uint32_t e = act ? src[l] : 0u;
+                const uint32_t key = (e >> pc.idx_bits) & pb_mask;
+                uint64_t todo = __ballot(act);
+                uint32_t pos = 0;
+                {
+                    const uint32_t kf = __shfl(key, todo ? __ffsll((unsigned long long)todo) - 1 : 0, 64);
+                    if (2 * __popcll(__ballot(act && key == kf)) < __popcll(todo)) {
+                        if (act) pos = atomicAdd(&cnt[set_base + key], 1u);
+                        todo = 0;
+                    }
+                }
+                while (todo) {
+                    const int leader = __ffsll((unsigned long long)todo) - 1;
+                    const uint32_t k0 = __shfl(key, leader, 64);
+                    const uint64_t same = __ballot(act && key == k0);
+                    uint32_t base = 0;
+                    if ((int)lane == leader) base = atomicAdd(&cnt[set_base + k0], (uint32_t)__popcll(same));
+                    base = __shfl(base, leader, 64);
+                    if (act && key == k0) pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+                    todo &= ~same;
+                }
+                if (act) sorted[pos] = e & KEEP;
+            }
         }
     }
     if (in_lds) {
@@ -761,7 +820,13 @@ __device__ __forceinline__ void msm_scan_totals_body(uint32_t* __restrict__ bloc
         __syncthreads();
     }
     if (t < nblocks) { block_tot[t] = s_cnt[t] - h; block_tot[nblocks + t] = s_unit[t] - hu; block_tot[2 * nblocks + t] = s_full[t] - hf; }
-    if (t == MSM_SCAN_BLOCK - 1) { offsets[total] = s_cnt[t]; unit_off[total] = s_unit[t]; full_off[total] = s_full[t]; }
+    if (t == MSM_SCAN_BLOCK - 1) {
+        offsets[total] = s_cnt[t]; unit_off[total] = s_unit[t]; full_off[total] = s_full[t];
+        // unit partials per NON-EMPTY bucket, behind the bins: the merge picks its lanes per bucket from it (a skewed input has few
+        // buckets with many partials; the host only knows the average over all buckets)
+        const uint32_t nonempty = total - L.s_bintot[MSM_UNIT_MAX];
+        block_bins[nblocks * MSM_BINS] = nonempty ? s_unit[t] / nonempty : 0u;
+    }
     if (t < MSM_BINS) {   // longest remainders (most partials) first: base of bin t in its list, then the exclusive prefix over the blocks
         uint32_t run = 0;
         const uint32_t top = t < (uint32_t)MSM_UNIT_MAX ? MSM_UNIT_MAX : MSM_BINS;
@@ -950,20 +1015,32 @@ template <class FP>
 __device__ __forceinline__ void msm_combine_heavy_body(const XYZZ<FP, FeU<FP>>* __restrict__ partial, const uint32_t* __restrict__ unit_off,
                                                        uint32_t total_buckets, XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum, uint32_t blk, uint32_t nblk);
 
+// lanes per bucket of the merge: as many as bring the partials per lane down to `per_lane`, from the bucket scan's own count of
+// partials per non-empty bucket (avg_partials; null: the host's choice stands), at most 2^max_log
+__device__ __forceinline__ int msm_combine_lanes(int max_log, const uint32_t* __restrict__ avg_partials, uint32_t per_lane) {
+    if (!avg_partials) return max_log;
+    const uint32_t avg = *avg_partials + 1u;
+    int l = 0;
+    while (l < max_log && (avg >> l) > per_lane) l++;
+    return l;
+}
 template <class FP>
 __global__ void __launch_bounds__(256) msm_combine_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ partial,
                                                           const uint32_t* __restrict__ unit_off,
                                                           const uint32_t* __restrict__ merge_list,   // buckets by number of partials, or null: bucket order
                                                           uint32_t total_buckets,
-                                                          int lanes_log,  // lanes per bucket = 2^lanes_log <= MSM_COMBINE_LANES
+                                                          int lanes_log,  // lanes per bucket = 2^lanes_log <= MSM_COMBINE_LANES: the most the grid covers
                                                           uint32_t normal_blocks,
-                                                          XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum) {
+                                                          XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum,
+                                                          const uint32_t* __restrict__ avg_partials, uint32_t per_lane) {
     wave_priority<APK_PRIO_TAIL>();
     using PT = XYZZ<FP, FeU<FP>>;
     if (blockIdx.x >= normal_blocks) {   // block-uniform
         msm_combine_heavy_body<FP>(partial, unit_off, total_buckets, bucket_sum, blockIdx.x - normal_blocks, gridDim.x - normal_blocks);
         return;
     }
+    lanes_log = msm_combine_lanes(lanes_log, avg_partials, per_lane);
+    if ((uint64_t)blockIdx.x * blockDim.x >= ((uint64_t)total_buckets << lanes_log)) return;   // the grid was sized for the most lanes
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t LANES = 1u << lanes_log;
     const uint32_t slot = gid >> lanes_log;
@@ -1121,6 +1198,49 @@ __device__ __forceinline__ void quad_tree_add(PT& acc, const PT& o, int q) {
         acc.add_quad_general(o, q, degenerate);
         if (degenerate) acc.add_lazy(o);
     }
+}
+
+// The same merge with FOUR LANES PER POINT OPERATION (ec.h add_quad_general), for a batch that has the GPU to itself: the merge is
+// then a chain of 5 - 8 dependent additions on a few hundred lone waves (BLS12-381 2^14: 105 - 150 us of a 0.5 ms MSM), and a quad
+// finishes an addition in 4 product stages instead of 14 products.  1.6 x the VALU instructions: never under load (run_msm_body).
+// 64 quads per workgroup; the heavy-bucket blocks behind the light ones are the one-lane form above.
+template <class FP>
+__global__ void __launch_bounds__(256) msm_combine_quad_kernel(const XYZZ<FP, FeU<FP>>* __restrict__ partial,
+                                                               const uint32_t* __restrict__ unit_off,
+                                                               const uint32_t* __restrict__ merge_list, uint32_t total_buckets,
+                                                               int lanes_log,  // QUADS per bucket = 2^lanes_log <= MSM_COMBINE_LANES: the most the grid covers
+                                                               uint32_t normal_blocks,
+                                                               XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum,
+                                                               const uint32_t* __restrict__ avg_partials, uint32_t per_lane) {
+    wave_priority<APK_PRIO_TAIL>();
+    using PT = XYZZ<FP, FeU<FP>>;
+    if (blockIdx.x >= normal_blocks) {   // block-uniform
+        msm_combine_heavy_body<FP>(partial, unit_off, total_buckets, bucket_sum, blockIdx.x - normal_blocks, gridDim.x - normal_blocks);
+        return;
+    }
+    lanes_log = msm_combine_lanes(lanes_log, avg_partials, per_lane);
+    if ((uint64_t)blockIdx.x * blockDim.x >= (((uint64_t)total_buckets << lanes_log) << 2)) return;
+    const uint32_t gq = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;      // the quad's number
+    const int q = threadIdx.x & 3;
+    const uint32_t LANES = 1u << lanes_log;
+    const uint32_t slot = gq >> lanes_log;
+    const uint32_t lane = gq & (LANES - 1);
+    uint32_t k = slot;
+    if (merge_list && slot < total_buckets) k = merge_list[slot];
+    PT acc = PT::inf();
+    uint32_t beg = 0, end = 0;
+    if (slot < total_buckets) { beg = unit_off[k]; end = unit_off[k + 1]; }
+    if (end - beg > MSM_HEAVY_UNITS) end = beg;
+    for (uint32_t u = beg + lane; u < end; u += LANES) quad_tree_add(acc, partial[u], q);
+    const uint32_t n_units = end - beg;
+    uint64_t need = __ballot(n_units > 1);
+    if (need) {
+        for (int d = (int)LANES / 2; d >= 1; d >>= 1) {
+            PT o = shfl_down_point<PT>(acc, d * 4, (int)LANES * 4);
+            if (lane < (uint32_t)d && n_units > (uint32_t)d) quad_tree_add(acc, o, q);
+        }
+    }
+    if (slot < total_buckets && lane == 0 && q == 0 && unit_off[k + 1] - unit_off[k] <= MSM_HEAVY_UNITS) bucket_sum[k] = acc;
 }
 
 // Row / column sums for throughput contexts: one lane per operation while a level still has more than 16 additions to do

@@ -677,9 +677,11 @@ print("SHA", hashlib.sha256(MarshalProof(plonk.Prove(ccs, pk, w, blinding(cv, 3)
                        {"APK_MSM_SORTED_MERGE": "0"}, {"APK_MSM_LEAN_TAIL": "1", "APK_MSM_ROWCOL_LANES": "8"},
                        # the four-launch form of the two-level sort (count - scan - scatter - sort) behind the two-launch default
                        {"APK_MSM_SORT2": "1", "APK_MSM_SORT_FUSED": "0"}, {"APK_MSM_SORT2": "1", "APK_MSM_SORT_FUSED": "0", "APK_MSM_PART_PBLOG": "4"},
-                       {"APK_MSM_SCAN_FUSED": "1"}, {"APK_MSM_GRAPH": "1", "APK_MSM_SORT2": "1"}]),
+                       {"APK_MSM_SCAN_FUSED": "1"}, {"APK_MSM_GRAPH": "1", "APK_MSM_SORT2": "1"},
+                       {"APK_MSM_COMBINE_QUAD": "1", "APK_MSM_LEAN_TAIL": "0"}, {"APK_MSM_COMBINE_QUAD": "0", "APK_MSM_LEAN_TAIL": "0"}]),
     ("bls12-381", 10, 12, [{"APK_MSM_LEAN_TAIL": "1", "APK_NTT_RADIX4": "1"}, {"APK_MSM_SORT2": "1"},
-                           {"APK_MSM_SORT2": "1", "APK_MSM_PART_PBLOG": "3", "APK_MSM_PART_SMALL_SCAN": "0"}]),
+                           {"APK_MSM_SORT2": "1", "APK_MSM_PART_PBLOG": "3", "APK_MSM_PART_SMALL_SCAN": "0"},
+                           {"APK_MSM_COMBINE_QUAD": "1", "APK_MSM_LEAN_TAIL": "0"}, {"APK_MSM_COMBINE_QUAD": "0", "APK_MSM_LEAN_TAIL": "0"}]),
 ])
 def test_run_time_variants_give_the_same_bytes(gpu, cname, log_n, window, variants):
     """The forms the library picks at run time - lean tail kernels when other proofs are in flight (sixteen-lane row/column
