@@ -424,13 +424,26 @@ class CurveBackend : public Backend {
         }
         if (unit < (uint32_t)MSM_UNIT_MIN) unit = MSM_UNIT_MIN;
         if (unit > (uint32_t)MSM_UNIT_MAX) unit = MSM_UNIT_MAX;
+        // Are other proofs keeping the GPU busy?  Then nobody waits for this batch's reduction chain and the instruction-lean
+        // forms of the tail kernels win (fewer, longer chains: every lane of a wave does useful additions); a lone proof keeps
+        // the short-chain forms.
+        bool others_busy = false;
+        if (slots_.size() > 2) {
+            std::lock_guard<std::mutex> lk(mu_);
+            int busy = 0;
+            for (Slot* t : slots_) busy += t->busy ? 1 : 0;
+            others_busy = busy > 1;
+        }
         // Small batches (a lone 2^14 MSM: 360 k entries) do not even give every SIMD one wave at 16 entries per lane, and a lone
         // wave issues a dependent instruction every ~6.5 cycles: the accumulate launch is then 16 additions long whatever the
         // size (BLS12-381 2^14: 229 of the MSM's 580 us).  Below one wave per SIMD the unit shrinks - down to
         // APK_MSM_UNIT_SMALL entries - so that the lanes fill the SIMDs once; the merge takes more lanes per bucket instead.
         static const uint32_t unit_small = (uint32_t)env_int("APK_MSM_UNIT_SMALL", MSM_UNIT_SMALL, MSM_UNIT_SMALL, MSM_UNIT_MIN);
-        if (!unit_env && entries <= MSM_SMALL_ENTRIES && entries / unit < (uint64_t)simds_ * 64) {
-            uint32_t u = (uint32_t)(entries / ((uint64_t)simds_ * 64));
+        // (two waves per SIMD: BLS12-381 2^14 lone proof 3.01 -> 2.90 ms, BN254 2^14 1.84 -> 1.78; four: back to 3.01 - the merge
+        // grows as the units shrink.  Only for a batch that has the GPU to itself.)
+        static const uint32_t small_waves = (uint32_t)env_int("APK_MSM_SMALL_WAVES", 2, 1, 4);   // waves per SIMD the shrunken units aim at
+        if (!unit_env && !others_busy && entries <= MSM_SMALL_ENTRIES * small_waves && entries / unit < (uint64_t)simds_ * 64 * small_waves) {
+            uint32_t u = (uint32_t)(entries / ((uint64_t)simds_ * 64 * small_waves));
             if (u < unit_small) u = unit_small;
             if (u < unit) unit = u;
         }
@@ -447,16 +460,6 @@ class CurveBackend : public Backend {
         dim3 gd(G, a.batch);   // (the two-level sort re-cuts its slices below)
         const size_t lds = digits_lds_bytes();
         static const int dth = env_int("APK_MSM_DIGITS_THREADS", MSM_DIGITS_THREADS, 64, MSM_DIGITS_THREADS) & ~63;   // whole waves, <= the launch bound
-        // Are other proofs keeping the GPU busy?  Then nobody waits for this batch's reduction chain and the instruction-lean
-        // forms of the tail kernels win (fewer, longer chains: every lane of a wave does useful additions); a lone proof keeps
-        // the short-chain forms.
-        bool others_busy = false;
-        if (slots_.size() > 2) {
-            std::lock_guard<std::mutex> lk(mu_);
-            int busy = 0;
-            for (Slot* t : slots_) busy += t->busy ? 1 : 0;
-            others_busy = busy > 1;
-        }
         static const int graphs_on = env_int("APK_MSM_GRAPH", 0, 0, 1);   // a captured batch must not depend on the moment of capture
         if (graphs_on) others_busy = false;
         static const int lean_env = env_int("APK_MSM_LEAN_TAIL", -1, -1, 1);
@@ -839,7 +842,7 @@ class CurveBackend : public Backend {
         }
         {   // unit partials: entries / 16 + a remainder per bucket - or, for small batches, entries / MSM_UNIT_SMALL (run_msm_body)
             const uint64_t big = entries / MSM_UNIT_MIN + tb;
-            const uint64_t small = (entries < MSM_SMALL_ENTRIES ? entries : MSM_SMALL_ENTRIES) / MSM_UNIT_SMALL + tb;
+            const uint64_t small = (entries < 4 * MSM_SMALL_ENTRIES ? entries : 4 * MSM_SMALL_ENTRIES) / MSM_UNIT_SMALL + tb;
             CHK(s.partial.alloc((big > small ? big : small) * sizeof(PtU)));
         }
         CHK(s.bucket_sum.alloc((size_t)tb * sizeof(PtU)));
