@@ -513,7 +513,11 @@ class CurveBackend : public Backend {
             // Two launches instead of four (kernels_msm.h "the two levels in TWO launches"): slice-major runs need no scan between
             // the levels.  A slice's entries always fit its stage here (per_slice x W <= MSM_PART_STAGE by the choice of G).
             static const int fused_env = env_int("APK_MSM_SORT_FUSED", 1, 0, 1);
-            const bool fused = fused_env && !graphs_on /* a replayed capture would reuse one totals buffer */ && (uint64_t)per_slice * W_ <= MSM_PART_STAGE && s.ptot2.p &&
+            // Only while a (slice, partition) run is at least a wave long: the second level walks a partition run by run, and at
+            // BLS12-381 2^21 (1 024 slices x 1 024 partitions, 32 entries per run, two strided table loads per run) it took
+            // 64 ms per 99 launches against the four-launch form's 21 (profiles/r04_kernel_trace_bls12381_2p21.txt, first cut).
+            const bool fused = fused_env && !graphs_on /* a replayed capture would reuse one totals buffer */ && stage_cap / P >= 64u &&
+                               (uint64_t)per_slice * W_ <= MSM_PART_STAGE && s.ptot2.p &&
                                (uint64_t)a.batch * G * (P + 1) <= (uint64_t)total_buckets * msm_G_max_ &&
                                (uint64_t)a.batch * G * stage_cap * 4 <= s.sort_tmp.bytes;
             if (fused) {
