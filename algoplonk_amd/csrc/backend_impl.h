@@ -257,6 +257,13 @@ class CurveBackend : public Backend {
         if (tile_log > log_n) tile_log = log_n;
         if (max_s > tile_log) max_s = tile_log;
         const int passes = (log_n + max_s - 1) / max_s;
+        bool busy_now = false;     // other proofs in flight on this context (the choice of run_msm_body's lean forms)
+        if (slots_.size() > 2 && log_n >= 17 && log_n <= 19) {
+            std::lock_guard<std::mutex> lk(mu_);
+            int busy = 0;
+            for (Slot* t : slots_) busy += t->busy ? 1 : 0;
+            busy_now = busy > 1;
+        }
         NttBatch nb{};
         for (int i = 0; i < count; i++) { nb.in[i] = ins[i]; nb.out[i] = outs[i]; nb.in_len[i] = in_lens[i]; }
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -279,8 +286,11 @@ class CurveBackend : public Backend {
             const dim3 grid(1u << (log_n - tile_log), count);
             const size_t lds = ((size_t)1 << tile_log) * sizeof(FeU<FRP>);
             // radix 4 (two stages per LDS round trip, one four-element group per lane and step) pays above 2^19 only: kernels_ntt.h
+            // ... and, with other proofs in flight, from 2^17 up: the instruction saving shows there (BN254 2^17, same box,
+            // under the round-4 wave priorities: 508.6 -> 513.7 proofs/s) while a lone proof's latency-bound launches would lose
+            // ~0.6 % to the halved lane count.
             static const int r4_env = env_int("APK_NTT_RADIX4", -1, -1, 1);
-            a.radix4 = r4_env >= 0 ? r4_env : (log_n > 19 ? 1 : 0);
+            a.radix4 = r4_env >= 0 ? r4_env : (log_n > 19 || (log_n >= 17 && busy_now) ? 1 : 0);
             static const int thr_env = env_int("APK_NTT_THREADS", 0, 0, NTT_THREADS) & ~63;
             uint32_t threads = NTT_THREADS;
             if (a.radix4) {
