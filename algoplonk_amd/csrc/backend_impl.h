@@ -610,7 +610,7 @@ class CurveBackend : public Backend {
         }
         if (stats_on_) HIPCHK(hipEventRecord(s.ev2, st));
         if (APK_PHASE(2))
-        msm_accumulate_kernel<FPP><<<cdiv(max_units, 128), 128, 0, st>>>(ptr<Aff>(T.table), ptr<uint32_t>(s.sorted), ptr<uint32_t>(s.offsets),
+        msm_accumulate_kernel<FPP><<<cdiv(max_units, MsmAcc<FPP>::THREADS), MsmAcc<FPP>::THREADS, 0, st>>>(ptr<Aff>(T.table), ptr<uint32_t>(s.sorted), ptr<uint32_t>(s.offsets),
                                                                         ptr<uint32_t>(s.unit_off), ptr<uint32_t>(s.full_off), ptr<uint32_t>(s.rem_list),
                                                                         total_buckets, max_units, unit, ptr<PtU>(s.partial));
         KCHK();

@@ -927,9 +927,12 @@ __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_apply_kernel(const ui
 #ifndef APK_ACC_WAVES_BLS
 #define APK_ACC_WAVES_BLS 2
 #endif
-template <class FP> struct MsmAcc { static constexpr int MIN_WAVES = FP::N > 8 ? APK_ACC_WAVES_BLS : 1; };
+#ifndef APK_ACC_THREADS
+#define APK_ACC_THREADS 128   // lanes per accumulate workgroup (round 4 variant builds, same box: 64 -> -0.6 %, 256 -> +0.6 % proofs/s: inside the noise)
+#endif
+template <class FP> struct MsmAcc { static constexpr int MIN_WAVES = FP::N > 8 ? APK_ACC_WAVES_BLS : 1; static constexpr int THREADS = APK_ACC_THREADS; };
 template <class FP>
-__global__ void __launch_bounds__(128, MsmAcc<FP>::MIN_WAVES) msm_accumulate_kernel(const Affine<FP>* __restrict__ table,
+__global__ void __launch_bounds__(APK_ACC_THREADS, MsmAcc<FP>::MIN_WAVES) msm_accumulate_kernel(const Affine<FP>* __restrict__ table,
                                                              const uint32_t* __restrict__ sorted,
                                                              const uint32_t* __restrict__ offsets,
                                                              const uint32_t* __restrict__ unit_off,
