@@ -1733,7 +1733,20 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     {
         Fr* outs[4] = {ptr<Fr>(s.pw_z), ptr<Fr>(s.pw_zw), ptr<Fr>(s.pw_zi), ptr<Fr>(s.pw_zwi)};
         const Fr ws[4] = {zeta, zw, zeta_inv, zw_inv};
-        CHK(powers_batch(st, z0 ? 2 : 4, outs, ws, n + 3));
+        static const int derive = env_int("APK_POWERS_DERIVE", 1, 0, 1);
+        if (z0 || !derive) {
+            CHK(powers_batch(st, z0 ? 2 : 4, outs, ws, n + 3));
+        } else {
+            // zeta^i and zeta^-i by square-and-multiply walks (~6 products per element); (omega zeta)^(+-i) from them and the
+            // transform's own table of omega^j: one product per element
+            Fr* two[2] = {outs[0], outs[2]};
+            const Fr w2[2] = {zeta, zeta_inv};
+            CHK(powers_batch(st, 2, two, w2, n + 3));
+            DerivePowers<FRP> dp{};
+            dp.in[0] = outs[0]; dp.out[0] = outs[1]; dp.inverse[0] = 0;
+            dp.in[1] = outs[2]; dp.out[1] = outs[3]; dp.inverse[1] = 1;
+            derive_powers_kernel<FRP><<<dim3(cdiv(n + 3, POLY_THREADS), 2), POLY_THREADS, 0, st>>>(dp, ptr<Fr>(twu_n_), n, n + 3); KCHK();
+        }
     }
     Fr ev[EVAL_MAX];
     {
@@ -1750,7 +1763,8 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         // the opening quotient of Z at omega*zeta does not wait for anything the host derives from the evaluations
         CHK(kzg_quotient(s, ptr<Fr>(s.cz), n + 3, ptr<Fr>(s.pw_zw), ptr<Fr>(s.pw_zwi), z0, ptr<Fr>(s.q2)));
         CHK(sync_results(s));
-        for (int i = 0; i < ea.count; i++) ev[i] = hfr[i];
+        const Fr c32 = fr_u64(32);        // eval_partial_kernel multiplies value x value on the product's radix: f(z) / 32 comes back
+        for (int i = 0; i < ea.count; i++) ev[i] = hfr[i] * c32;
     }
     const Fr lz = ev[0], rz = ev[1], oz = ev[2], s1z = ev[3], s2z = ev[4];
     const Fr zshift = ev[5 + nb_commit_];
@@ -1844,6 +1858,10 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         push(ptr<Fr>(s_c_[0]), n); push(ptr<Fr>(s_c_[1]), n);
         for (uint32_t k = 0; k < nb_commit_; k++) push(ptr<Fr>(qcp_c_[k]), n);
         lc.count = c; lc.out_len = n + 3;
+        {   // the kernel multiplies on unsaturated limbs: coefficients in the product's radix R' = 32 R
+            const Fr c32 = fr_u64(32);
+            for (int k = 0; k < c; k++) lc.coef[k] = lc.coef[k] * c32;
+        }
         lincomb_kernel<FRP><<<cdiv(n + 3, POLY_THREADS), POLY_THREADS, 0, st>>>(lc, ptr<Fr>(s.folded)); KCHK();
         CHK(kzg_quotient(s, ptr<Fr>(s.folded), n + 3, ptr<Fr>(s.pw_z), ptr<Fr>(s.pw_zi), z0, ptr<Fr>(s.q1)));
         // both opening proofs in one batch: W_zeta (batched opening) and W_omega*zeta (kzg.Open of Z [UPSTREAM])

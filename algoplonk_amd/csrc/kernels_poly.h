@@ -361,11 +361,17 @@ __global__ void __launch_bounds__(POLY_THREADS) eval_partial_kernel(EvalArgs<FR>
     const Fr* f = a.f[p];
     const Fr* __restrict__ pwp = a.pw[p] ? a.pw[p] : pw;
     const uint32_t len = a.len[p];
-    Fr acc = Fr::zero();
+    // the EVAL_PER_THREAD products of a lane on unsaturated limbs: value x value products come out as f pw / 32 (both operands
+    // are in gnark's radix R, the product's own radix is R' = 32 R) - the HOST multiplies the few results by 32 (eval_many's caller)
+    using U = FeU<FR>;
+    static_assert(U::HEADROOM >= 64 && EVAL_PER_THREAD * 2 <= 16, "8 products below 2 r each");
+    U accu = U::zero();
     for (int k = 0; k < EVAL_PER_THREAD; k++) {
         uint32_t i = blockIdx.x * EVAL_BLOCK + k * POLY_THREADS + t;
-        if (i < len) acc = acc + f[i] * pwp[i];
+        if (i < len) { Fr a0 = f[i], b0 = pwp[i]; accu = U::add_n(accu, U::mul_nr(U::unpack(a0.l), U::unpack(b0.l))); }
     }
+    Fr acc;
+    U::template canon<8>(accu).pack(acc.l);
     sm[t] = acc;
     __syncthreads();
     for (uint32_t d = POLY_THREADS / 2; d >= 1; d >>= 1) {
@@ -394,6 +400,29 @@ __global__ void __launch_bounds__(POLY_THREADS) eval_final_kernel(const Fe<FR>* 
     if (t == 0) result[p] = acc;
 }
 
+// ---- (omega z)^i from z^i: out[i] = in[i] * omega^(+-i), one product per element where the square-and-multiply walk of
+// powers_kernel costs ~6.  twu[j] = omega^j in the radix R' for j < n / 2; omega^(n/2) = -1.  inverse: omega^-i = omega^(n - i mod n).
+template <class FR>
+struct DerivePowers { const Fe<FR>* in[2]; Fe<FR>* out[2]; int inverse[2]; };
+template <class FR>
+__global__ void __launch_bounds__(POLY_THREADS) derive_powers_kernel(DerivePowers<FR> a, const Fe<FR>* __restrict__ twu, uint32_t n, uint32_t count) {
+    wave_priority<APK_PRIO_FR>();
+    using Fr = Fe<FR>;
+    using U = FeU<FR>;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int p = blockIdx.y;
+    uint32_t e = i & (n - 1u);                       // omega^n = 1
+    if (a.inverse[p]) e = (n - e) & (n - 1u);
+    const bool neg = e >= n / 2;
+    Fr w = twu[e & (n / 2 - 1u)], v = a.in[p][i];
+    U r = U::template canon<1>(U::mul_nr(U::unpack(w.l), U::unpack(v.l)));
+    Fr o;
+    r.pack(o.l);
+    if (neg) o = Fr::neg(o);
+    a.out[p][i] = o;
+}
+
 // ---- out[i] = sum_k coef[k] * f_k[i]  (linearised polynomial, folded opening polynomial) -------------------
 constexpr int LC_MAX = 20;   // folded opening polynomial: 11 + k terms of the linearised polynomial, 5 + k folded ones (k <= 2)
 template <class FR>
@@ -409,12 +438,20 @@ template <class FR>
 __global__ void __launch_bounds__(POLY_THREADS) lincomb_kernel(LinCombArgs<FR> a, Fe<FR>* __restrict__ out) {
     wave_priority<APK_PRIO_FR>();
     using Fr = Fe<FR>;
+    // unsaturated limbs, lazily (like the quotient kernel): the coefficients arrive as 32 c (the product's radix R' = 32 R), every
+    // product is below 2 r, up to LC_MAX of them add up below 64 r, ONE canonicalisation at the end - 206 instead of ~300
+    // instructions per term
+    using U = FeU<FR>;
+    static_assert(U::HEADROOM >= 64 && LC_MAX * 2 <= 64, "the sum of LC_MAX products below 2 r each must stay below 64 r");
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.out_len) return;
-    Fr acc = Fr::zero();
+    U acc = U::zero();
     for (int k = 0; k < a.count; k++)
-        if (i < a.len[k]) acc = acc + a.coef[k] * a.f[k][i];
-    out[i] = acc;
+        if (i < a.len[k]) { Fr v = a.f[k][i]; acc = U::add_n(acc, U::mul_nr(U::unpack(a.coef[k].l), U::unpack(v.l))); }
+    const U res = U::template canon<32>(acc);
+    Fr w;
+    res.pack(w.l);
+    out[i] = w;
 }
 
 // q[j] = zinv_pw[j+1] * suffix[j+1], j < len-1   where suffix[i] = sum_{k>=i} f[k] z^k
