@@ -1606,7 +1606,8 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         g.data[0] = ptr<Fr>(s.ratio); g.data[1] = ptr<Fr>(s.tmp);
         g.tot[0] = ptr<Fr>(s.scan_tot); g.tot[1] = ptr<Fr>(s.scan_tot) + nb + 1;
         gp_terms_kernel<FRP><<<cdiv(n, POLY_THREADS), POLY_THREADS, 0, st>>>(
-            dL, dR, dO, ptr<Fr>(s_lag_[0]), ptr<Fr>(s_lag_[1]), ptr<Fr>(s_lag_[2]), ptr<Fr>(tw_n_), n, beta, gamma, beta_u, beta_u2,
+            dL, dR, dO, ptr<Fr>(s_lag_[0]), ptr<Fr>(s_lag_[1]), ptr<Fr>(s_lag_[2]), ptr<Fr>(tw_n_), n, beta * fr_u64(32), gamma, beta_u * fr_u64(32),
+            beta_u2 * fr_u64(32),   // the kernel multiplies on unsaturated limbs: the challenges in the product's radix R' = 32 R
             g.data[0], g.data[1]);
         KCHK();
         gp_scan_block_kernel<FRP><<<dim3(nb, 2), POLY_THREADS, 0, st>>>(g, n); KCHK();

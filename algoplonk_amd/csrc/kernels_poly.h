@@ -77,10 +77,24 @@ __global__ void __launch_bounds__(POLY_THREADS) gp_terms_kernel(const Fe<FR>* __
     using Fr = Fe<FR>;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fr w = i < n / 2 ? tw[i] : Fr::neg(tw[i - n / 2]);
-    Fr l = L[i] + gamma, r = R[i] + gamma, o = O[i] + gamma;
-    num[i] = (l + beta * w) * (r + beta_u * w) * (o + beta_u2 * w);
-    den[i] = (l + beta * S1[i]) * (r + beta * S2[i]) * (o + beta * S3[i]);
+    // On unsaturated limbs, lazily.  beta, beta_u, beta_u2 arrive as 32 x (the product's radix R' = 32 R), so beta * w is exact;
+    // the two value x value products of each triple leave num and den BOTH divided by 1024 - which cancels in
+    // Z[k] = prod_{i<k} num * prod_{i>=k} den / prod den (k factors, n - k factors, n factors).  Sums below 4 r, products below 2 r.
+    using U = FeU<FR>;
+    static_assert(U::HEADROOM >= 64, "factors below 4 r");
+    auto ld = [](const Fr* p, uint32_t k) { Fr v = p[k]; return U::unpack(v.l); };
+    Fr wf = i < n / 2 ? tw[i] : Fr::neg(tw[i - n / 2]);
+    const U w = U::unpack(wf.l), gm = U::unpack(gamma.l), b = U::unpack(beta.l), bu = U::unpack(beta_u.l), bu2 = U::unpack(beta_u2.l);
+    const U l = U::add_n(ld(L, i), gm), r = U::add_n(ld(R, i), gm), o = U::add_n(ld(O, i), gm);      // < 2
+    U nu = U::mul_nr(U::add_n(l, U::mul_nr(b, w)), U::add_n(r, U::mul_nr(bu, w)));                      // factors < 4
+    nu = U::mul_nr(nu, U::add_n(o, U::mul_nr(bu2, w)));
+    U de = U::mul_nr(U::add_n(l, U::mul_nr(b, ld(S1, i))), U::add_n(r, U::mul_nr(b, ld(S2, i))));
+    de = U::mul_nr(de, U::add_n(o, U::mul_nr(b, ld(S3, i))));
+    Fr on, od;
+    U::template canon<1>(nu).pack(on.l);
+    U::template canon<1>(de).pack(od.l);
+    num[i] = on;
+    den[i] = od;
 }
 
 // ---- generic scans over Fr: op = multiply (grand product) or add (suffix sums for the KZG quotient) ------
