@@ -171,6 +171,7 @@ class CurveBackend : public Backend {
     MsmPartCfg part_cfg_{};   // two-level sort: bit layout of the packed entries, partition count (choose_window)
     uint32_t msm_G_max_ = 256;
     bool msm_only_ = false;
+    bool many_slots_ = false;   // a throughput context (more than two proving slots): small MSMs may take the two-level sort under load
     uint32_t msm_bases_ = 0;  // bases the MSM workspaces are sized for
     uint32_t NB_ = 0;
     Fr omega_, omega_inv_, omega4_, omega4_inv_, shift_, shift_inv_, n_inv_, n4_inv_;
@@ -484,7 +485,10 @@ class CurveBackend : public Backend {
         static const int sort2_env = env_int("APK_MSM_SORT2", -1, -1, 1);
         // (a lone single MSM was 0.49 against 0.47 ms with the first version - and 0.468 against 0.473 once the partition scan
         // ran eight lanes per pair and the second-level tile let two partitions share a CU: no exception for it any more)
-        const bool sort2_want = sort2_env >= 0 ? sort2_env != 0 : T.n_bases >= 65536u;
+        // Round 4, with the two-launch form and the wave priorities: under LOAD it also pays from 2^13 bases (same box, proofs/s:
+        // BN254 2^13 +1 %, 2^14 +3.5 %, 2^15 +4.6 %, BLS12-381 2^14 +3 %) while a LONE proof there is 2.5 - 4 % slower with it - so
+        // below 2^16 bases it follows the load.
+        const bool sort2_want = sort2_env >= 0 ? sort2_env != 0 : (T.n_bases >= 65536u || (others_busy && T.n_bases >= 8192u));
         // Round 4: the packed entry's layout follows the context (MsmPartCfg, part_cfg_): the table index takes the bits it needs
         // and the partitions shrink until one fits the second level's LDS tile - BLS12-381 2^21 x 16 windows (26 index bits,
         // 2 048 partitions of 16 buckets) sorts in two levels as well.  The first level's slices are cut so that a slice's entries
@@ -848,7 +852,7 @@ class CurveBackend : public Backend {
         CHK(s.full_off.alloc((size_t)(tb + 1) * 4)); CHK(s.rem_rank.alloc((size_t)(tb + 1) * 4)); CHK(s.rem_list.alloc((size_t)(tb + 1) * 4));
         CHK(s.counts.alloc((size_t)tb * msm_G_max_ * 4));
         CHK(s.sorted.alloc(entries * 4));
-        if (env_int("APK_MSM_SORT2", -1, -1, 1) != 0 && part_cfg_.P >= 4 && (msm_bases_ >= 65536u || env_int("APK_MSM_SORT2", -1, -1, 1) == 1))
+        if (env_int("APK_MSM_SORT2", -1, -1, 1) != 0 && part_cfg_.P >= 4 && (msm_bases_ >= 65536u || (many_slots_ && msm_bases_ >= 8192u) || env_int("APK_MSM_SORT2", -1, -1, 1) == 1))
         {
             CHK(s.sort_tmp.alloc((entries + (uint64_t)batch * 1024u * (uint64_t)W_ + 4096u) * 4));   // two-level sort: packed entries between the levels (slice-major runs: a few entries of slack per slice)
             CHK(s.ptot2.alloc((size_t)2 * MSM_MAX_BATCH * MSM_PART_MAX * 4));
@@ -1103,6 +1107,7 @@ class CurveBackend : public Backend {
         // beyond the cap wait for a slot, which also hides their host-side gaps
         static const int max_slots = env_int("APK_MAX_SLOTS", 16, 1, 64);
         if (nslots > max_slots) nslots = max_slots;
+        many_slots_ = nslots > 2;
         for (int i = 0; i < nslots; i++) {
             Slot* s = new Slot();
             slots_.push_back(s);
