@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string.h>
 #include <vector>
@@ -171,6 +172,7 @@ class CurveBackend : public Backend {
     MsmPartCfg part_cfg_{};   // two-level sort: bit layout of the packed entries, partition count (choose_window)
     uint32_t msm_G_max_ = 256;
     bool msm_only_ = false;
+    std::unique_ptr<HostPool> lc_pool_;   // parked host threads for the [lin] combination of a lone proof (created on first use)
     bool many_slots_ = false;   // a throughput context (more than two proving slots): small MSMs may take the two-level sort under load
     uint32_t msm_bases_ = 0;  // bases the MSM workspaces are sized for
     uint32_t NB_ = 0;
@@ -1829,19 +1831,20 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         Fr lk[HOST_MSM_MAX];
         for (size_t i = 0; i < lin_terms.size(); i++) { lp[i] = lin_terms[i].com; lk[i] = lin_terms[i].coef; }
         const auto t_lc = std::chrono::steady_clock::now();
-        // several host threads while this proof has the context (nearly) to itself - then the GPU idles through the combination;
-        // with many proofs in flight the callers' own threads already keep the host busy
-        // (measured, lone proofs: BLS12-381 2^14 2.91 -> 2.83 ms with 4 threads; BN254 2^17 3.37 -> 3.40 - its 0.16 ms combination
-        // is not worth three thread starts - so by default only the 14-limb field does it)
-        static const int lc_threads = env_int("APK_HOST_LINCOMB_THREADS", FPP::N > 8 ? 4 : 1, 1, 8);
-        int lct = 1;
+        // the context's parked host threads while this proof has it (nearly) to itself - then the GPU idles through the
+        // combination; with many proofs in flight the callers' own threads already keep the host busy
+        static const int lc_threads = env_int("APK_HOST_LINCOMB_THREADS", 4, 1, 8);
+        HostPool* pool = nullptr;
         if (lc_threads > 1) {
             std::lock_guard<std::mutex> lk2(mu_);
             int busy = 0;
             for (Slot* t : slots_) busy += t->busy ? 1 : 0;
-            if (busy <= 2) lct = lc_threads;
+            if (busy <= 2) {
+                if (!lc_pool_) lc_pool_.reset(new HostPool(lc_threads - 1));
+                pool = lc_pool_.get();
+            }
         }
-        lin_com = host_lincomb<FRP, FPP>(lp, lk, (int)lin_terms.size(), lct);
+        lin_com = host_lincomb<FRP, FPP>(lp, lk, (int)lin_terms.size(), pool);
         if (stats_on_) lincomb_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lc).count();
     }
     memcpy(out->zshift_value, &zshift, sizeof(Fr));

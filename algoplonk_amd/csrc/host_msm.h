@@ -8,12 +8,68 @@
 // inversion), 5 doublings + `count` mixed additions per window.  ~11 k field products for 11 points: ~0.35 ms (BN254) /
 // ~0.85 ms (BLS12-381) on one host core with host_fp.h's 64-bit limbs.
 #pragma once
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "ec.h"
 #include "host_fp.h"
 
 namespace apk {
+
+// A few parked host threads for the pieces of host work that sit between two Fiat-Shamir challenges with the GPU idle (the [lin]
+// combination): starting threads per call cost more than the 0.16 ms BN254 combination saves; waking parked ones costs ~10 us.
+// One job at a time: a caller that finds the pool taken does the work itself.
+class HostPool {
+public:
+    explicit HostPool(int workers) {
+        for (int i = 0; i < workers; i++) th_.emplace_back([this, i] { loop(i); });
+    }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    int workers() const { return (int)th_.size(); }
+    // fn(0) on the caller, fn(1) .. fn(parts - 1) on the workers; returns once all are done - or false, nothing run, when the pool is in use
+    bool run(int parts, const std::function<void(int)>& fn) {
+        std::unique_lock<std::mutex> use(use_mu_, std::try_to_lock);
+        if (!use.owns_lock() || parts < 2 || parts - 1 > (int)th_.size()) return false;
+        { std::lock_guard<std::mutex> g(mu_); job_ = &fn; parts_ = parts; pending_ = parts - 1; gen_++; }
+        cv_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> g(mu_);
+        done_.wait(g, [&] { return pending_ == 0; });
+        job_ = nullptr;
+        return true;
+    }
+private:
+    void loop(int i) {
+        uint64_t last = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> g(mu_);
+            cv_.wait(g, [&] { return stop_ || gen_ != last; });
+            if (stop_) return;
+            last = gen_;
+            const bool mine = i + 1 < parts_;
+            const std::function<void(int)>* job = job_;
+            g.unlock();
+            if (mine) {
+                (*job)(i + 1);
+                std::lock_guard<std::mutex> g2(mu_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_, use_mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)>* job_ = nullptr;
+    int parts_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
 
 constexpr int HOST_MSM_MAX = 16;
 constexpr int HOST_MSM_W = 5;
@@ -79,33 +135,33 @@ XYZZ<FPP, Fe64<FPP>> host_lincomb_xyzz(const Affine<FPP>* pts, const Fe<FRP>* sc
     return acc;
 }
 
-// `threads` > 1: the points are dealt to that many host threads (each runs its own Straus pass - the doublings are repeated,
-// the additions and the tables are shared out), the parts are added, one inversion.  The combination sits between two
+// `pool`: the points are dealt to the caller and the pool's parked threads (each runs its own Straus pass - the doublings are
+// repeated, the additions and the tables are shared out), the parts are added, one inversion.  The combination sits between two
 // Fiat-Shamir challenges with the GPU idle: on a lone BLS12-381 2^14 proof it was 0.36 of 2.91 ms on one thread.
 template <class FRP, class FPP>
-Affine<FPP> host_lincomb(const Affine<FPP>* pts, const Fe<FRP>* scalars_mont, int count, int threads = 1) {
+Affine<FPP> host_lincomb(const Affine<FPP>* pts, const Fe<FRP>* scalars_mont, int count, HostPool* pool = nullptr) {
     using F = Fe64<FPP>;
     using X = XYZZ<FPP, F>;
     if (count <= 0 || count > HOST_MSM_MAX) return Affine<FPP>::inf();
-    if (threads > count / 2) threads = count / 2;
     X acc;
-    if (threads <= 1) {
-        acc = host_lincomb_xyzz<FRP, FPP>(pts, scalars_mont, count);
-    } else {
-        X part[8];
-        if (threads > 8) threads = 8;
-        std::thread th[8];
-        auto share = [&](int t, int& lo, int& hi) { lo = (int)((long)count * t / threads); hi = (int)((long)count * (t + 1) / threads); };
-        for (int t = 1; t < threads; t++) {
-            int lo, hi;
-            share(t, lo, hi);
-            th[t] = std::thread([&, t, lo, hi] { part[t] = host_lincomb_xyzz<FRP, FPP>(pts + lo, scalars_mont + lo, hi - lo); });
+    bool done = false;
+    if (pool) {
+        int parts = pool->workers() + 1;
+        if (parts > count / 2) parts = count / 2;
+        if (parts >= 2) {
+            X part[HOST_MSM_MAX];
+            const std::function<void(int)> fn = [&](int t) {
+                const int lo = (int)((long)count * t / parts), hi = (int)((long)count * (t + 1) / parts);
+                part[t] = host_lincomb_xyzz<FRP, FPP>(pts + lo, scalars_mont + lo, hi - lo);
+            };
+            if (pool->run(parts, fn)) {
+                acc = part[0];
+                for (int t = 1; t < parts; t++) acc.add(part[t]);
+                done = true;
+            }
         }
-        int lo, hi;
-        share(0, lo, hi);
-        acc = host_lincomb_xyzz<FRP, FPP>(pts + lo, scalars_mont + lo, hi - lo);
-        for (int t = 1; t < threads; t++) { th[t].join(); acc.add(part[t]); }
     }
+    if (!done) acc = host_lincomb_xyzz<FRP, FPP>(pts, scalars_mont, count);
     if (acc.is_inf()) return Affine<FPP>::inf();
     const F zzz_inv = F::inv(acc.ZZZ);
     const F zz_inv = F::sqr(zzz_inv * acc.ZZ);
