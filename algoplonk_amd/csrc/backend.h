@@ -38,6 +38,7 @@ struct Backend {
     virtual int dev_download(void* d, const void* s, size_t bytes) = 0;
     virtual int stats_enable(int enable) = 0;
     virtual int stats_read(apk_stats* out, int reset) = 0;
+    virtual int paths_read(apk_path_counts* out, int reset) = 0;
 };
 
 int g1_mul_batch_bn254(int device, const void* base, const void* scalars, uint64_t count, void* out);

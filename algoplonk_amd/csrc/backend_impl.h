@@ -11,6 +11,7 @@
 // (5 coset NTTs per proof, the 7 trace polynomials' coset evaluations are precomputed per circuit).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <memory>
@@ -215,6 +216,18 @@ class CurveBackend : public Backend {
         Fr rho_inv[8];
         bool on() const { return G > 1 && hook; }
     } sc_;
+    // which forms the load-dependent choices took (apk_paths_read): always counted, relaxed atomics
+    enum PathIdx { P_PROOFS, P_MSM_BATCHES, P_SORT2, P_SORT2_LOAD, P_SORT_FUSED, P_LEAN_TAIL, P_ROWCOL_SERIAL, P_COMBINE_QUAD, P_SMALL_UNITS,
+                   P_ONE_LAUNCH, P_LAGRANGE_WIRES, P_NTT_SEQ, P_NTT_R4, P_NTT_R4_LOAD, P_TAIL_FILL, P_LINCOMB_POOL, P_COUNT };
+    std::atomic<uint64_t> paths_[P_COUNT] = {};
+    void path(PathIdx i) { paths_[i].fetch_add(1, std::memory_order_relaxed); }
+    int paths_read(apk_path_counts* out, int reset) override {
+        static_assert(sizeof(apk_path_counts) >= P_COUNT * sizeof(uint64_t), "apk_path_counts holds every counter");
+        memset(out, 0, sizeof *out);
+        uint64_t* o = reinterpret_cast<uint64_t*>(out);    // the struct's fields are in PathIdx order
+        for (int i = 0; i < P_COUNT; i++) o[i] = reset ? paths_[i].exchange(0, std::memory_order_relaxed) : paths_[i].load(std::memory_order_relaxed);
+        return APK_OK;
+    }
     // stats
     bool stats_on_ = false;
     uint32_t simds_ = 1024;  // SIMDs of the device (4 per CU); set at init
@@ -294,6 +307,7 @@ class CurveBackend : public Backend {
             // ~0.6 % to the halved lane count.
             static const int r4_env = env_int("APK_NTT_RADIX4", -1, -1, 1);
             a.radix4 = r4_env >= 0 ? r4_env : (log_n > 19 || (log_n >= 17 && busy_now) ? 1 : 0);
+            if (p == 0) { path(P_NTT_SEQ); if (a.radix4) { path(P_NTT_R4); if (r4_env < 0 && log_n <= 19) path(P_NTT_R4_LOAD); } }
             static const int thr_env = env_int("APK_NTT_THREADS", 0, 0, NTT_THREADS) & ~63;
             uint32_t threads = NTT_THREADS;
             if (a.radix4) {
@@ -447,6 +461,8 @@ class CurveBackend : public Backend {
             for (Slot* t : slots_) busy += t->busy ? 1 : 0;
             others_busy = busy > 1;
         }
+        static const int graphs_on = env_int("APK_MSM_GRAPH", 0, 0, 1);   // a captured batch must not depend on the moment of capture:
+        if (graphs_on) others_busy = false;                               // neither its unit nor its kernel forms
         // Small batches (a lone 2^14 MSM: 360 k entries) do not even give every SIMD one wave at 16 entries per lane, and a lone
         // wave issues a dependent instruction every ~6.5 cycles: the accumulate launch is then 16 additions long whatever the
         // size (BLS12-381 2^14: 229 of the MSM's 580 us).  Below one wave per SIMD the unit shrinks - down to
@@ -458,7 +474,7 @@ class CurveBackend : public Backend {
         if (!unit_env && !others_busy && entries <= MSM_SMALL_ENTRIES * small_waves && entries / unit < (uint64_t)simds_ * 64 * small_waves) {
             uint32_t u = (uint32_t)(entries / ((uint64_t)simds_ * 64 * small_waves));
             if (u < unit_small) u = unit_small;
-            if (u < unit) unit = u;
+            if (u < unit) { unit = u; path(P_SMALL_UNITS); }
         }
         const uint32_t max_units = (uint32_t)(entries / unit) + total_buckets;
         if (stats_on_) HIPCHK(hipEventRecord(s.ev0, st));
@@ -473,8 +489,6 @@ class CurveBackend : public Backend {
         dim3 gd(G, a.batch);   // (the two-level sort re-cuts its slices below)
         const size_t lds = digits_lds_bytes();
         static const int dth = env_int("APK_MSM_DIGITS_THREADS", MSM_DIGITS_THREADS, 64, MSM_DIGITS_THREADS) & ~63;   // whole waves, <= the launch bound
-        static const int graphs_on = env_int("APK_MSM_GRAPH", 0, 0, 1);   // a captured batch must not depend on the moment of capture
-        if (graphs_on) others_busy = false;
         static const int lean_env = env_int("APK_MSM_LEAN_TAIL", -1, -1, 1);
         const bool lean = lean_env >= 0 ? lean_env != 0 : others_busy;
         // two-level sort (kernels_msm.h): partitions of 256 buckets, then a counting sort per partition - the stores of both
@@ -510,6 +524,9 @@ class CurveBackend : public Backend {
         const bool sort2 = sort2_want && P >= 4 && s.sort_tmp.p && G2 <= 1024u &&
                            (uint64_t)a.batch * G2 * P * 2 + (uint64_t)a.batch * P * (1 + MSM_PART_CHUNKS) <= (uint64_t)total_buckets * msm_G_max_;
         if (sort2) { G = G2; gd = dim3(G, a.batch); }
+        path(P_MSM_BATCHES);
+        if (sort2) { path(P_SORT2); if (sort2_env < 0 && T.n_bases < 65536u) path(P_SORT2_LOAD); }
+        if (lean) path(P_LEAN_TAIL);
         uint32_t* pcounts = ptr<uint32_t>(s.counts);
         uint32_t* runstart = pcounts + (size_t)a.batch * G * P;
         uint32_t* ptot = runstart + (size_t)a.batch * G * P;
@@ -537,6 +554,7 @@ class CurveBackend : public Backend {
                                (uint64_t)a.batch * G * (P + 1) <= (uint64_t)total_buckets * msm_G_max_ &&
                                (uint64_t)a.batch * G * stage_cap * 4 <= s.sort_tmp.bytes;
             if (fused) {
+                path(P_SORT_FUSED);
                 uint32_t* pt_cur = ptr<uint32_t>(s.ptot2) + (size_t)(s.ptot_parity & 1u) * MSM_MAX_BATCH * MSM_PART_MAX;
                 uint32_t* pt_next = ptr<uint32_t>(s.ptot2) + (size_t)((s.ptot_parity & 1u) ^ 1u) * MSM_MAX_BATCH * MSM_PART_MAX;
                 s.ptot_parity ^= 1u;
@@ -652,6 +670,7 @@ class CurveBackend : public Backend {
             const bool cquad = cq_env >= 0 ? cq_env != 0 : (!lean && !graphs_on && NB_ <= 4096u);
             if (!APK_PHASE(4)) {
             } else if (cquad) {
+                path(P_COMBINE_QUAD);
                 const uint32_t qblocks = cdiv(((uint64_t)total_buckets << lanes_log) * 4, 256);
                 msm_combine_quad_kernel<FPP><<<qblocks + MSM_HEAVY_BLOCKS, 256, 0, st>>>(
                     ptr<PtU>(s.partial), ptr<uint32_t>(s.unit_off), sorted_merge ? ptr<uint32_t>(s.merge_list) : nullptr, total_buckets, lanes_log,
@@ -683,6 +702,7 @@ class CurveBackend : public Backend {
         if (quad_env < 0 && !graphs_on && rows % 4 == 0 && cols % 4 == 0) serial = serial_env >= 0 ? serial_env != 0 : lean;
         if (!APK_PHASE(8)) {
         } else if (serial) {
+            path(P_ROWCOL_SERIAL);
             // lanes per line: 16 (19 / 11 addition-times per wave of four rows / columns at c = 16) or 8 (34 / 18 per eight)
             static const int lpl = env_int("APK_MSM_ROWCOL_LANES", 16, 8, 16);
             if (lpl == 8 && rows % 8 == 0 && cols % 8 == 0)
@@ -1532,6 +1552,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         blind3_kernel<FRP><<<3, 64, 0, st>>>(b3, n, 2); KCHK();
     }
     const int fill = tail_fill(s);
+    if (fill) path(P_TAIL_FILL);
     {
         MsmBatchArgs a{};
         a.batch = 3;
@@ -1842,6 +1863,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
             if (busy <= 2) {
                 if (!lc_pool_) lc_pool_.reset(new HostPool(lc_threads - 1));
                 pool = lc_pool_.get();
+                path(P_LINCOMB_POOL);
             }
         }
         lin_com = host_lincomb<FRP, FPP>(lp, lk, (int)lin_terms.size(), pool);
@@ -1898,6 +1920,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     memcpy(out->gamma, &gamma, sizeof(Fr)); memcpy(out->beta, &beta, sizeof(Fr)); memcpy(out->alpha, &alpha, sizeof(Fr));
     memcpy(out->zeta, &zeta, sizeof(Fr)); memcpy(out->gamma_kzg, &gk, sizeof(Fr));
     mark(3);
+    path(P_PROOFS);
     if (stats_on_) {
         double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
         std::lock_guard<std::mutex> g(stats_mu_);

@@ -22,6 +22,7 @@
 #include <sys/time.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -183,6 +184,7 @@ struct apk_comm {
     bool step_synced = false;       // the current step's status reached every rank of it (serve() keeps serving) - or the transport
                                     // broke mid-step and the stream to the leader is no longer aligned (serve() leaves)
     bool split_on = false;
+    bool spmd_on = false;           // replicated prover: this communicator's hooks sit on the bound context (apk_comm_spmd_begin)
     bool subcoset_on = false;       // replicated prover: round 3 on sub-cosets (apk_comm_spmd_begin)
     uint64_t steps = 0;
     std::mutex step_mu;             // leader: one step at a time (a context with several slots proves concurrently, and every
@@ -312,6 +314,39 @@ static int ctl_allgather(apk_comm* c, const void* mine, void* all, size_t n) {
     return recv_all(c->peer[0], all, n * c->world);
 }
 
+// Whatever this communicator installed on its bound context comes off again - on EVERY rank, for either schedule - before the
+// binding changes or the communicator dies: a hook left behind points at freed memory and the next apk_prove on that context
+// would call it (an exception between spmd_begin and spmd_end is enough to get there).
+static void clear_ctx_hooks(apk_comm* c) {
+    if (c->ctx && (c->split_on || c->spmd_on)) {
+        (void)apk_ctx_set_commit_hook(c->ctx, nullptr, nullptr);
+        (void)apk_ctx_set_wire_hook(c->ctx, nullptr, nullptr);
+        (void)apk_ctx_set_subcoset(c->ctx, 0, 1, nullptr, nullptr);
+    }
+    c->spmd_on = false;
+    c->subcoset_on = false;
+}
+
+// Wait for the communicator's stream with the control plane's deadline (APK_COMM_TIMEOUT_S).  A collective that a peer never
+// joins - it failed locally on the way in - would otherwise hold hipStreamSynchronize forever; here the call fails after the
+// timeout like a silent peer on the TCP plane does, and the RCCL plane is given up for the rest of the binding (its stream
+// still holds the unfinished collective).
+static int stream_wait(apk_comm* c, const char* what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; spins++) {
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e == hipSuccess) return APK_OK;
+        if (e != hipErrorNotReady) { (void)hipGetLastError(); set_error("comm: %s: %s", what, hipGetErrorString(e)); return APK_ERR_HIP; }
+        if (spins < 2000) continue;                      // the exchanges this guards take tens of microseconds
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > (double)c->timeout_s) {
+            c->rccl = false;
+            set_error("comm: %s did not complete within %d s (a peer never joined the collective); RCCL plane abandoned", what, c->timeout_s);
+            return APK_ERR_STATE;
+        }
+        usleep(spins < 20000 ? 20 : 500);
+    }
+}
+
 // The ONE exchange of a sharded MSM / a dealt commitment batch: `n` bytes (status word + 64/96-byte partial sums) from every
 // rank to every rank.  north_star: "RCCL-over-xGMI ... for the final bucket-sum of a single MSM" - ncclAllGather on the
 // communicator's stream when RCCL is the data plane (a numeric all-reduce cannot add curve points: the ranks add the gathered
@@ -321,9 +356,21 @@ static int sums_allgather(apk_comm* c, const void* mine, void* all, size_t n) {
     HCHK(hipSetDevice(c->device));
     const size_t need = n * ((size_t)c->world + 1);
     if (c->ag_cap < need) {
+        // the staging buffer grows on every rank at the same call (need depends on n and the world only): the one local step that
+        // can fail before the collective, so the ranks agree on it over the control plane first - nobody enters an all-gather
+        // that a peer cannot join
         if (c->d_ag) (void)hipFree(c->d_ag);
         c->d_ag = nullptr; c->ag_cap = 0;
-        HCHK(hipMalloc(&c->d_ag, need * 2 + 4096));
+        int32_t ok = hipMalloc(&c->d_ag, need * 2 + 4096) == hipSuccess ? 1 : 0;
+        if (!ok) { (void)hipGetLastError(); c->d_ag = nullptr; }
+        std::vector<int32_t> oks(c->world);
+        CHK(ctl_allgather(c, &ok, oks.data(), 4));
+        for (int r = 0; r < c->world; r++)
+            if (!oks[r]) {
+                if (c->d_ag) { (void)hipFree(c->d_ag); c->d_ag = nullptr; }
+                set_error("comm: rank %d could not allocate the all-gather staging buffer (%zu bytes)", r, need * 2 + 4096);
+                return APK_ERR_HIP;
+            }
         c->ag_cap = need * 2 + 4096;
     }
     uint8_t* d_all = (uint8_t*)c->d_ag;
@@ -331,8 +378,7 @@ static int sums_allgather(apk_comm* c, const void* mine, void* all, size_t n) {
     HCHK(hipMemcpyAsync(d_mine, mine, n, hipMemcpyHostToDevice, c->stream));
     NCHK(g_rccl.AllGather(d_mine, d_all, n, ncclUint8, c->nccl, c->stream));
     HCHK(hipMemcpyAsync(all, d_all, n * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
-    HCHK(hipStreamSynchronize(c->stream));
-    return APK_OK;
+    return stream_wait(c, "the partial sums' ncclAllGather");
 }
 
 // ---- data-plane: scatter of per-rank chunks held by rank 0; peer copies between rank 0 and one worker -------------------------
@@ -349,8 +395,7 @@ static int data_scatter(apk_comm* c, const void* d_all, void* d_mine, size_t chu
             NCHK(g_rccl.Recv(d_mine, chunk, ncclUint8, 0, c->nccl, c->stream));
         }
         NCHK(g_rccl.GroupEnd());
-        HCHK(hipStreamSynchronize(c->stream));
-        return APK_OK;
+        return stream_wait(c, "the scatter's ncclSend / ncclRecv group");
     }
     if (c->ipc) {
         // d_all is the leader's exported staging buffer: every worker pulls its chunk at once, the leader collects the acks
@@ -383,8 +428,7 @@ static int data_p2p(apk_comm* c, int w, bool to_worker, void* d_buf, size_t byte
         if (sending) NCHK(g_rccl.Send(d_buf, bytes, ncclUint8, other, c->nccl, c->stream));
         else NCHK(g_rccl.Recv(d_buf, bytes, ncclUint8, other, c->nccl, c->stream));
         NCHK(g_rccl.GroupEnd());
-        HCHK(hipStreamSynchronize(c->stream));
-        return APK_OK;
+        return stream_wait(c, "a peer copy's ncclSend / ncclRecv");
     }
     if (c->ipc) {
         const int fd = c->fd_of(w);
@@ -586,6 +630,7 @@ int apk_comm_create(int rank, int world, const char* addr, int port, apk_comm** 
 void apk_comm_destroy(apk_comm* c) {
     if (!c) return;
     if (c->split_on && c->rank == 0) (void)apk_comm_split_end(c);
+    clear_ctx_hooks(c);
     release_buffers(c);
     if (c->d_ag) { (void)hipSetDevice(c->device); (void)hipFree(c->d_ag); }
     if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
@@ -624,6 +669,8 @@ int apk_comm_set_compute(apk_comm* c, const apk_compute* t) {
 
 int apk_comm_bind(apk_comm* c, apk_ctx* ctx) {
     if (!c) { set_error("null communicator"); return APK_ERR_ARG; }
+    if (c->split_on && c->rank == 0) (void)apk_comm_split_end(c);   // rebinding ends a split proof: the workers leave apk_comm_serve
+    clear_ctx_hooks(c);                       // this communicator's hooks must not outlive its binding to the old context
     release_buffers(c);                       // they belong to the previous binding
     c->ipc = false;
     c->ctx = ctx;
@@ -786,8 +833,7 @@ int apk_comm_allgather_device(apk_comm* c, void* d_all, size_t bytes) {
     if (c->rccl) {
         HCHK(hipSetDevice(c->device));
         NCHK(g_rccl.AllGather(mine, all, bytes, ncclUint8, c->nccl, c->stream));     // in place: sendbuff = recvbuff + rank * count
-        HCHK(hipStreamSynchronize(c->stream));
-        return APK_OK;
+        return stream_wait(c, "the sub-coset ncclAllGather");
     }
     if (c->ipc) {
         // every rank exports its staging buffer (the one allocation a peer can map), parks its part there, and pulls the others'
@@ -838,8 +884,10 @@ int apk_comm_allgather_device(apk_comm* c, void* d_all, size_t bytes) {
 // ranks' batches meet in the order they are issued.
 int apk_comm_spmd_begin(apk_comm* c) {
     if (!c || !c->ctx) { set_error("comm: spmd_begin needs a bound circuit context on every rank"); return APK_ERR_ARG; }
+    if (c->split_on) { set_error("comm: spmd_begin inside a split proof (call apk_comm_split_end first)"); return APK_ERR_STATE; }
     CHK(apk_ctx_set_commit_hook(c->ctx, hook_commit_local, c));
-    c->split_on = false;
+    (void)apk_ctx_set_wire_hook(c->ctx, nullptr, nullptr);   // a wire hook left by an earlier split has no place in the replicated prover
+    c->spmd_on = true;
     // round 3 of the prover on sub-cosets (apk_ctx_set_subcoset): world 2, 4 or 8, unless APK_SPMD_SUBCOSET=0 - and only when
     // EVERY rank's context can take it (the ranks agree first: a rank on its own would wait in an all-gather nobody joins)
     int32_t can = 0;
@@ -857,6 +905,7 @@ int apk_comm_spmd_end(apk_comm* c) {
     if (!c) { set_error("null communicator"); return APK_ERR_ARG; }
     if (c->ctx) { (void)apk_ctx_set_commit_hook(c->ctx, nullptr, nullptr); (void)apk_ctx_set_subcoset(c->ctx, 0, 1, nullptr, nullptr); }
     c->subcoset_on = false;
+    c->spmd_on = false;
     return APK_OK;
 }
 int apk_comm_subcoset_active(const apk_comm* c) { return c && c->subcoset_on ? 1 : 0; }

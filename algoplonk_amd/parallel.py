@@ -115,13 +115,14 @@ class Comm:
             # rank 0 binds the port itself: picked free, then bound by apk_comm_create a moment later - a race with another
             # process taking it in between fails the create loudly (no silent cross-talk: the token guards the hello)
             port = free_port()
-            try:
-                os.unlink(path)                      # a stale file of a crashed launch with the same parent pid
-            except OSError:
-                pass
+            for stale in (path, path + ".tmp"):      # left by a launch with the same parent pid that crashed during its rendezvous
+                try:
+                    os.unlink(stale)
+                except OSError:
+                    pass
             fd = os.open(path + ".tmp", os.O_WRONLY | os.O_CREAT | os.O_EXCL | os.O_NOFOLLOW, 0o600)
             with os.fdopen(fd, "w") as f:
-                f.write("%d %s" % (port, token))
+                f.write("%d %s %d" % (port, token, os.getpid()))     # the pid lets a worker tell a live rank 0 from a stale file
             os.replace(path + ".tmp", path)
             try:
                 return cls(0, world, addr, port)
@@ -131,13 +132,22 @@ class Comm:
                 except OSError:
                     pass
         deadline = time.time() + 300
-        while not os.path.exists(path):
+        while True:
+            # a worker may get here before rank 0 has removed the file of an earlier, crashed launch: a file whose writer is no
+            # longer alive is ignored and read again (rank 0 replaces it atomically)
+            try:
+                fd = os.open(path, os.O_RDONLY | os.O_NOFOLLOW)
+                with os.fdopen(fd) as f:
+                    port_s, token, pid_s = f.read().split()
+                os.kill(int(pid_s), 0)
+                break
+            except (FileNotFoundError, ProcessLookupError, ValueError):
+                pass
+            except PermissionError:       # alive, another user's process: cannot be this launch's rank 0
+                pass
             if time.time() > deadline:
-                raise RuntimeError("rank %d: no rendezvous file %s from rank 0" % (rank, path))
+                raise RuntimeError("rank %d: no rendezvous file %s from a live rank 0" % (rank, path))
             time.sleep(0.02)
-        fd = os.open(path, os.O_RDONLY | os.O_NOFOLLOW)
-        with os.fdopen(fd) as f:
-            port_s, token = f.read().split()
         os.environ["APK_COMM_TOKEN"] = token
         return cls(rank, world, addr, int(port_s))
 

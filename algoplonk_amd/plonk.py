@@ -109,6 +109,12 @@ class ProvingKey:
     def enable_stats(self, on: bool = True) -> None:
         check(lib.apk_stats_enable(self.ctx, int(on)))
 
+    def paths(self, reset: bool = False) -> dict:
+        """Which forms of the load-dependent kernels the context has taken so far (apk_paths_read)."""
+        pc = _lib.PathCounts()
+        check(lib.apk_paths_read(self.ctx, C.byref(pc), int(reset)))
+        return pc.as_dict()
+
 
 @dataclass
 class Proof:

@@ -258,7 +258,10 @@ def write_plonk_vk(vk: plonk.VerifyingKey) -> bytes:
 KZG_LINES_BYTES = {"bn254": 2 * 2 * 65 * 4 * 32, "bls12_381": 2 * 2 * 63 * 4 * 48}
 
 
-def read_plonk_vk(cv: ecc.ID, r: io.BytesIO) -> plonk.VerifyingKey:
+def read_plonk_vk(cv: ecc.ID, r: io.BytesIO, embedded: bool = False) -> plonk.VerifyingKey:
+    """embedded = False: the key is everything that is left in `r` (a vk file) and the layout follows from the REMAINING LENGTH;
+    embedded = True: the key is followed by more data (inside a proving key: kzg.ProvingKey next, whose point count must be
+    Size + 3) and the layout is the one whose continuation is well formed."""
     fr = lambda: int.from_bytes(r.read(32), "big")
     g1 = lambda: setup.decompress_g1(cv, r.read(cv.fp_bytes))
     (size,) = struct.unpack(">Q", r.read(8))
@@ -272,20 +275,40 @@ def read_plonk_vk(cv: ecc.ID, r: io.BytesIO) -> plonk.VerifyingKey:
     kg1 = g1()
     w = 2 * cv.fp_bytes
     g2 = _g2_decompress(cv, r.read(w)) + _g2_decompress(cv, r.read(w))
-    # with or without Kzg.Lines: the layout whose CommitmentConstraintIndexes list (u32 count + count x u64; one index per Qcp)
-    # is well formed at its place.  Without the block the count word sits right here.
+    # with or without Kzg.Lines in front of CommitmentConstraintIndexes (u32 count + count x u64; one index per Qcp)
     here = r.tell()
-    lines_bytes = 0
-    head = r.read(4)
-    plain_ok = len(head) == 4 and struct.unpack(">I", head)[0] == nq
-    if not plain_ok:
-        r.seek(here + KZG_LINES_BYTES[cv.name])
-        head2 = r.read(4)
-        if len(head2) == 4 and struct.unpack(">I", head2)[0] == nq:
-            lines_bytes = KZG_LINES_BYTES[cv.name]
+    tail = 4 + 8 * nq
+    LB = KZG_LINES_BYTES[cv.name]
+
+    def well_formed(skip: int) -> bool:
+        r.seek(here + skip)
+        head = r.read(4)
+        if len(head) != 4 or struct.unpack(">I", head)[0] != nq:
+            return False
+        if not embedded:
+            return True
+        r.seek(here + skip + tail)
+        nxt = r.read(4)                                   # kzg.ProvingKey: its G1 count is Size + 3 (setup/setup.go:113-114)
+        return len(nxt) == 4 and struct.unpack(">I", nxt)[0] == size + 3
+
+    if not embedded:
+        remaining = len(r.getbuffer()) - here
+        if remaining == tail and well_formed(0):
+            lines_bytes = 0
+        elif remaining == LB + tail and well_formed(LB):
+            lines_bytes = LB
         else:
-            raise ValueError("plonk verifying key: no CommitmentConstraintIndexes list of %d entries after Kzg.G2 (with or without a "
-                             "%d-byte Kzg.Lines block): the plonk key layout here is unpinned" % (nq, KZG_LINES_BYTES[cv.name]))
+            raise ValueError("plonk verifying key: %d bytes left after Kzg.G2, expected %d (CommitmentConstraintIndexes of %d entries) "
+                             "or %d (a Kzg.Lines block first): the plonk key layout here is unpinned" % (remaining, tail, nq, LB + tail))
+    elif well_formed(0):
+        lines_bytes = 0
+    elif well_formed(LB):
+        lines_bytes = LB
+    else:
+        raise ValueError("plonk verifying key: no CommitmentConstraintIndexes list of %d entries followed by a kzg proving key of %d "
+                         "points after Kzg.G2 (with or without a %d-byte Kzg.Lines block): the plonk key layout here is unpinned"
+                         % (nq, size + 3, LB))
+    r.seek(here + lines_bytes + 4)
     nc = nq
     cci = [struct.unpack(">Q", r.read(8))[0] for _ in range(nc)]
     if size == 0 or size & (size - 1) or size_inv * size % cv.r != 1 or pow(gen, size, cv.r) != 1:
@@ -302,7 +325,7 @@ def write_plonk_pk(vk: plonk.VerifyingKey, srs: setup.SRS) -> bytes:
 
 
 def read_plonk_pk(cv: ecc.ID, r: io.BytesIO, device: int = 0) -> Tuple[plonk.VerifyingKey, setup.SRS]:
-    vk = read_plonk_vk(cv, r)
+    vk = read_plonk_vk(cv, r, embedded=True)
     g1 = read_kzg_pk(cv, r, device)
     lag = read_kzg_pk(cv, r, device)
     return vk, setup.SRS(cv, vk.Size, g1, lag or None, None, vk.KzgG2)

@@ -255,12 +255,26 @@ def gnark_cpu_baseline(probe: dict, curve: str, log_n: int, budget_s: float):
         return None
 
 
+def valu_issue_rate():
+    """Wall time per wave instruction and SIMD of a dependent v_mad_u64_u32 chain, measured NOW on this box by
+    tools/ubench/valu_rates --json (built by __graft_entry__.build()): the issue cost the accumulate kernel's instruction count is
+    priced at.  None when the binary is missing or fails - the line then carries no issue bound rather than a stale one."""
+    exe = os.path.join(ROOT, "tools", "ubench", "valu_rates")
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, "--json"], capture_output=True, text=True, timeout=60)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception:
+        return None
+
+
 def pmc_traffic(curve: str, log_n: int, window: int, timeout_s: float = 420.0):
-    """HBM bytes per (scalar, point) pair of msm_accumulate_kernel, measured NOW on this box: two separate rocprofv3 --pmc
-    passes (FETCH_SIZE, WRITE_SIZE - one counter per pass and no trace domains, as MI355X_MICROARCH.md's HBM section
-    prescribes) over tools/prof_msm.py (4 single MSMs + the 8 trace commitments of Setup).  gfx950 correction from the same
-    guide: FETCH_SIZE counts 64-byte units reported in KB at half weight -> doubled; WRITE_SIZE as is.  None when rocprofv3 is
-    missing or a pass fails."""
+    """HBM bytes per (scalar, point) pair and VALU instructions per bucket addition of msm_accumulate_kernel, measured NOW on
+    this box: three separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU - one counter per pass and no trace
+    domains, as MI355X_MICROARCH.md's HBM section prescribes) over tools/prof_msm.py (4 single MSMs + the 8 trace commitments of
+    Setup).  gfx950 correction from the same guide: FETCH_SIZE counts 64-byte units reported in KB at half weight -> doubled;
+    WRITE_SIZE as is.  None when rocprofv3 is missing or a traffic pass fails; the instruction pass is optional."""
     if not shutil.which("rocprofv3"):
         return None
     import sqlite3
@@ -269,7 +283,7 @@ def pmc_traffic(curve: str, log_n: int, window: int, timeout_s: float = 420.0):
     env = dict(os.environ, TMPDIR="/tmp")
     if window:
         env["APK_MSM_WINDOW"] = str(window)
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
         d = tempfile.mkdtemp(prefix="apk_pmc_", dir="/tmp")
         try:
             subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable,
@@ -284,6 +298,8 @@ def pmc_traffic(curve: str, log_n: int, window: int, timeout_s: float = 420.0):
                     launches.add(did)
             out[counter] = (tot, len(launches))
         except Exception:
+            if counter == "SQ_INSTS_VALU":
+                continue
             return None
         finally:
             shutil.rmtree(d, ignore_errors=True)
@@ -292,7 +308,15 @@ def pmc_traffic(curve: str, log_n: int, window: int, timeout_s: float = 420.0):
     fetch_kb, nl = out["FETCH_SIZE"]
     write_kb, _ = out["WRITE_SIZE"]
     bytes_total = 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0
-    return {"hbm_bytes_per_pair": bytes_total / pairs, "launches": nl, "fetch_kb": fetch_kb, "write_kb": write_kb}
+    res = {"hbm_bytes_per_pair": bytes_total / pairs, "launches": nl, "fetch_kb": fetch_kb, "write_kb": write_kb, "window_bits": window}
+    if "SQ_INSTS_VALU" in out and window:
+        # SQ_INSTS_VALU counts wave instructions; a bucket addition is one lane's work: x 64 lanes / (pairs x windows) additions
+        from algoplonk_amd import ecc
+        rbits = (ecc.BN254 if curve == "bn254" else ecc.BLS12_381).r.bit_length()
+        windows = (rbits + 1 + window - 1) // window
+        res["valu_wave_instructions"] = out["SQ_INSTS_VALU"][0]
+        res["valu_instructions_per_addition"] = out["SQ_INSTS_VALU"][0] * 64.0 / (pairs * windows)
+    return res
 
 
 # ---------------------------------------------------------------------------------------------------- modes
@@ -454,7 +478,7 @@ def window_bits(args) -> int:
     return 16 if args.log_n >= 21 or (args.log_n >= 17 and throughput) else min(15, max(8, args.log_n - 2))
 
 
-def roofline_from_stats(args, cv, st, pmc):
+def roofline_from_stats(args, cv, st, pmc, issue=None):
     pair_bytes = 32 + 2 * cv.fp_bytes  # 96 B/pair BN254, 128 B/pair BLS12-381
     acc_avg_ms = st.msm_accumulate_ms / max(st.msm_accumulate_launches, 1)
     pairs_per_launch = st.msm_pairs / max(st.msm_accumulate_launches, 1)
@@ -475,13 +499,17 @@ def roofline_from_stats(args, cv, st, pmc):
         windows = (cv.r.bit_length() + 1 + c - 1) // c
         adds_per_s = pairs_per_launch * windows / (acc_avg_ms * 1e-3)
         roofline["valu"] = {"bucket_additions_per_s": round(adds_per_s / 1e9, 3), "unit": "G additions/s", "windows": windows}
-        if cv.name == "bn254":
-            # the kernel's real ceiling: VALU issue.  2 012 VALU instructions per bucket addition and lane (SQ_INSTS_VALU over the
-            # additions of profiles/r02_pmc_msm_accumulate.json) at 2.03 ns per wave instruction and SIMD (tools/ubench/valu_rates.hip,
-            # v_mad_u64_u32 with 4 waves per SIMD) on 1024 SIMDs x 64 lanes
-            bound = 1024 * 64 / (2012 * 2.03e-9)
-            roofline["valu"].update({"issue_bound": round(bound / 1e9, 3), "frac": round(adds_per_s / bound, 4),
-                                     "basis": "2012 VALU instructions per addition (PMC) x 2.03 ns per wave instruction per SIMD (ubench)"})
+        if pmc and pmc.get("valu_instructions_per_addition") and issue:
+            # the kernel's real ceiling: VALU issue.  Both factors are of THIS run: VALU instructions per bucket addition and lane
+            # from the SQ_INSTS_VALU pass above, wall time per wave instruction and SIMD from tools/ubench/valu_rates --json
+            # (dependent v_mad_u64_u32 chain, 4 waves per SIMD), on (4 x CUs) SIMDs x 64 lanes
+            ipa = pmc["valu_instructions_per_addition"]
+            ns = issue["mad_u64_dependent_ns_per_wave_inst_per_simd_4waves"]
+            simds = 4 * (issue.get("compute_units") or 256)
+            bound = simds * 64 / (ipa * ns * 1e-9)
+            roofline["valu"].update({"instructions_per_addition": round(ipa, 1), "ns_per_wave_instruction_per_simd": round(ns, 4), "simds": simds,
+                                     "issue_bound": round(bound / 1e9, 3), "frac": round(adds_per_s / bound, 4),
+                                     "basis": "this run: SQ_INSTS_VALU pass x 64 lanes / (pairs x windows) additions; tools/ubench/valu_rates --json"})
         if pmc:
             roofline["hbm_traffic_frac"] = round(pmc["hbm_bytes_per_pair"] * pairs_per_launch / (acc_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     return roofline
@@ -538,11 +566,20 @@ def bench_prove(args, cv, rk) -> None:
         if rc != 0:
             errors.append((rc, lib.apk_last_error()))
 
+    pk.paths(reset=True)
     elapsed = rk.timed_callers(one, args.inflight, args.steps, args.warmup, args.step_barrier)
     if errors:
         raise SystemExit("apk_prove failed: %r" % (errors[0],))
     total_proofs = args.steps * args.inflight * rk.world
     value = total_proofs / elapsed
+    # ---- what the timed region PRODUCED: every caller's last proof (made with the other callers in flight, i.e. by the loaded
+    # forms of the kernels - `paths` says which ran) is marshalled and hashed before anything else touches the buffers; all of them
+    # must be the same bytes (same inputs, same blinding) and, below, the same bytes as the lone proof and as the CPU oracle's
+    import hashlib
+    from algoplonk_amd import MarshalProof
+    paths_loaded = pk.paths(reset=True)
+    load_hashes = [hashlib.sha256(MarshalProof(plonk.Proof(cv, p))).hexdigest()[:16] for p in proofs]
+    under_load_identical = len(set(load_hashes)) == 1
 
     # ---- single-proof latency + live HIP-event timing of the dominant kernel (own pass, after the timed region)
     # latency as a caller sees it: one proof at a time, instrumentation off (the library's statistics synchronise the host
@@ -550,6 +587,8 @@ def bench_prove(args, cv, rk) -> None:
     # and per-kernel figures below
     nlat = 5
     one(0)
+    lone_sha = hashlib.sha256(MarshalProof(plonk.Proof(cv, proofs[0]))).hexdigest()[:16]
+    paths_lone = pk.paths(reset=True)
     lat0 = time.perf_counter()
     for _ in range(nlat):
         one(0)
@@ -596,8 +635,10 @@ def bench_prove(args, cv, rk) -> None:
     pmc = None
     cpu_baseline = None
     if rk.rank == 0 and rk.world == 1:
-        if not args.no_pmc and not args.bsb22:
-            pmc = pmc_traffic(args.curve, args.log_n, window_bits(args))
+        if not args.no_pmc:
+            # (the PMC passes profile the MSMs of a circuit of the same size and curve WITHOUT the commitment: the accumulate
+            # kernel's traffic and instruction count per pair do not depend on the circuit)
+            pmc = pmc_traffic(args.curve, args.log_n, window_bits(args), timeout_s=420.0 if args.log_n < 20 else 1500.0)
         if not args.no_cpu_baseline and not args.bsb22:
             probe = go_probe()
             cpu_baseline = gnark_cpu_baseline(probe, args.curve, args.log_n, args.cpu_baseline_seconds)
@@ -608,15 +649,17 @@ def bench_prove(args, cv, rk) -> None:
                 except Exception as e:  # the baseline is reported, never required for the GPU number
                     cpu_baseline = {"value": None, "unit": "proofs/sec", "cores": 0, "kind": "port", "sample": "unavailable: %s" % e}
             cpu_baseline["go_probe"] = probe
-    roofline = roofline_from_stats(args, cv, st, pmc)
+    roofline = roofline_from_stats(args, cv, st, pmc, valu_issue_rate() if (rk.rank == 0 and pmc) else None)
     plane = rk.data_plane_probe(pk.ctx)
 
+    # every rank checks its own timed region; the line (rank 0) carries the verdict of all of them
+    loaded_ok = under_load_identical and load_hashes[0] == lone_sha
+    all_ok = rk.comm.max(0.0 if loaded_ok else 1.0) == 0.0
     if rk.rank == 0:
-        import hashlib
-        from algoplonk_amd import MarshalProof
-        gpu_proof_sha = hashlib.sha256(MarshalProof(plonk.Proof(cv, proofs[0]))).hexdigest()[:16]
+        gpu_proof_sha = load_hashes[0]
         if cpu_baseline and cpu_baseline.get("proof_sha256_prefix"):
             cpu_baseline["matches_gpu_proof"] = cpu_baseline["proof_sha256_prefix"] == gpu_proof_sha
+            cpu_baseline["matches_proofs_under_load"] = under_load_identical and cpu_baseline["proof_sha256_prefix"] == load_hashes[0]
         line = {
             "metric": "proofs/sec", "value": round(value, 4), "unit": "proofs/sec", "n_gpus": rk.world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
@@ -635,10 +678,22 @@ def bench_prove(args, cv, rk) -> None:
             "round_ms": [round(x / max(st.proofs, 1), 3) for x in st.round_ms],
             "host_lincomb_ms": round(st.host_lincomb_ms / max(st.proofs, 1), 3),
             "witness_bits": witness_bits,
+            # the timed region's own output: the last proof of each of the `inflight` callers, made under load
+            "proofs_under_load_identical": under_load_identical, "proofs_under_load_checked": len(load_hashes),
+            "proofs_under_load_match_lone_proof": loaded_ok, "proofs_under_load_ok_on_all_ranks": all_ok,
+            "lone_proof_sha256_prefix": lone_sha,
+            "paths_under_load": paths_loaded, "paths_lone_proof": paths_lone,
             "proof_sha256_prefix": gpu_proof_sha, "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line), flush=True)
     rk.close()
+    bad = []
+    if not all_ok:
+        bad.append("proofs of the timed region differ (hashes on rank %d: %s; lone proof %s)" % (rk.rank, sorted(set(load_hashes)), lone_sha))
+    if rk.rank == 0 and cpu_baseline and cpu_baseline.get("matches_proofs_under_load") is False:
+        bad.append("proofs of the timed region differ from the CPU oracle's proof (%s vs %s)" % (load_hashes[0], cpu_baseline.get("proof_sha256_prefix")))
+    if bad:
+        raise SystemExit("bench.py: PARITY FAILURE - " + "; ".join(bad))
 
 
 def skewed_leg(args, cv, rk, seed):
@@ -741,7 +796,7 @@ def bench_sharded_msm(args, cv, rk) -> None:
                                             "world_size": rk.world, "backend": ("libapk comm: tcp control plane, %s data plane" % rk.comm.transport) if rk.world > 1 else "single process",
                                             "rccl_ranks": rk.comm.rccl_ranks},
             "result_sha256_prefix": hashlib.sha256(res[0]).hexdigest()[:16],
-            "roofline": roofline_from_stats(args, cv, st, pmc), "cpu_baseline": cpu_baseline}), flush=True)
+            "roofline": roofline_from_stats(args, cv, st, pmc, valu_issue_rate() if pmc else None), "cpu_baseline": cpu_baseline}), flush=True)
     rk.close()
 
 

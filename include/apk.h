@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define APK_ABI_VERSION 3
+#define APK_ABI_VERSION 4
 
 /* curve ids: the two curves the AVM supports (algoplonk.go:39-41) */
 #define APK_BN254 0
@@ -371,6 +371,33 @@ typedef struct {
 } apk_stats;
 int apk_stats_enable(apk_ctx* ctx, int enable); /* enabling inserts hipEvents around the kernels above */
 int apk_stats_read(apk_ctx* ctx, apk_stats* out, int reset);
+
+/* ---- which forms the library took ------------------------------------------------------------------------------------------
+ * Several kernels exist in two forms and the library picks one per launch from the LOAD it sees (how many proving slots are busy):
+ * a lone proof gets the short-chain / latency forms, proofs under load the instruction-lean ones.  All forms give the same bytes;
+ * the parity tests prove it by asserting, through these counters, that the loaded forms really ran while the blobs they compare
+ * were produced (tests/test_gpu_parity.py::test_proofs_under_load_*).  Counted always, independent of apk_stats_enable - the
+ * statistics synchronise the host with every batch and would change the very load the choices depend on. */
+typedef struct {
+    uint64_t proofs;                    /* apk_prove* calls that returned a proof */
+    uint64_t msm_batches;               /* MSM launch sequences (1..4 MSMs each) */
+    uint64_t msm_sort_two_level;        /* ... sorted in two levels (partitions, then LDS tiles) */
+    uint64_t msm_sort_two_level_by_load;/* ... of those, two-level only BECAUSE other proofs were in flight (below 2^16 bases) */
+    uint64_t msm_sort_fused;            /* ... two-level in the two-launch form */
+    uint64_t msm_lean_tail;             /* lean tail: one lane per bucket in the merge from 32 768 buckets, lean row/column sums */
+    uint64_t msm_rowcol_serial;         /* sixteen-lane serial row/column sums */
+    uint64_t msm_combine_quad;          /* four lanes per addition in the merge (small lone batch) */
+    uint64_t msm_small_units;           /* shrunken accumulate units (small lone batch) */
+    uint64_t msm_one_launch;            /* whole MSM in one cooperative launch (small lone batch) */
+    uint64_t msm_lagrange_wires;        /* [L][R][O] committed over the Lagrange SRS (small-scalar fast path) */
+    uint64_t ntt_sequences;             /* NTT launch sequences */
+    uint64_t ntt_radix4;                /* ... with radix-4 steps */
+    uint64_t ntt_radix4_by_load;        /* ... radix-4 only BECAUSE other proofs were in flight (2^17..2^19) */
+    uint64_t tail_fill_proofs;          /* lone proofs whose coset transforms ran beside the MSM tails (side stream) */
+    uint64_t host_lincomb_pooled;       /* [lin] combinations dealt to the context's parked host threads */
+    uint64_t reserved[8];
+} apk_path_counts;
+int apk_paths_read(apk_ctx* ctx, apk_path_counts* out, int reset);
 
 #ifdef __cplusplus
 }

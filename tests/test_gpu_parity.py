@@ -755,3 +755,84 @@ def test_two_level_sort_with_skewed_scalars(gpu, extra):
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
     out = subprocess.run([sys.executable, "-c", _SKEWED_SORT2_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "SKEWED_OK" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
+@pytest.mark.parametrize("cname,log_n", [("bn254", 17), ("bls12-381", 14)])
+def test_proofs_under_load_match_the_c_oracle(gpu, cname, log_n):
+    """the loaded path at the headline size.  32 callers x 5 rounds on a 32-slot context (the library caps
+    it at 16 proving slots; the other callers wait their turn, which is bench.py's configuration) prove the same instance with
+    the same blinding; EVERY one of the 160 blobs must be the bytes of the C oracle's proof ("safe to call
+    concurrently from several goroutines", algoplonk.go:89).  Under load the library takes other kernels than for a lone proof
+    (backend_impl.h: two-level sort below 2^16 bases, lean merge and sixteen-lane row/column sums, radix-4 NTT steps from 2^17):
+    the context's path counters must show that those forms produced the blobs compared here - and that a lone proof on the same
+    context, which takes the latency forms (tail filling, tree tails), gives the same bytes again."""
+    import hashlib
+    import threading
+    from algoplonk_amd import workloads
+    from oracle import c_oracle
+    cv, ov = CURVES[cname]
+    wl = workloads.random_circuit(cv, log_n, 0xA190 if cname == "bn254" else 0xA191)
+    n = wl.ccs.domain_size()
+    srs = ap_setup.unsafe_srs(cv, n, wl.tau, device=gpu)
+    T, rounds = 32, 5
+    pk, vk = ap_plonk.Setup(wl.ccs, srs, device=gpu, slots=T)
+    tr = frontend.build_trace(wl.ccs)
+    L, R, O = frontend.wire_columns(wl.ccs, wl.solution)
+    rc, want, _ = c_oracle.prove(c_oracle.load(), cv.abi, n, wl.ccs.GetNbPublicVariables(), srs.g1,
+                                 [cv.fr_vector(x) for x in (tr.ql, tr.qr, tr.qm, tr.qo, tr.qk)], tr.perm, cv.fr_vector(L),
+                                 cv.fr_vector(R), cv.fr_vector(O), cv.fr_vector(wl.witness.public), cv.fr_vector(wl.blinding),
+                                 threads=os.cpu_count() or 1)
+    assert rc == 0
+    dptr = []
+    for b in (cv.fr_vector(v) for v in (L, R, O)):
+        p = C.c_void_p()
+        check(lib.apk_device_alloc(pk.ctx, len(b), C.byref(p)))
+        check(lib.apk_device_upload(pk.ctx, p, b, len(b)))
+        dptr.append(p)
+    pub, bl = cv.fr_vector(wl.witness.public), cv.fr_vector(wl.blinding)
+    blobs, errors, lock = {}, [], threading.Lock()
+
+    def worker():
+        pr = _lib.Proof()
+        out = C.create_string_buffer(2048)
+        ln = C.c_size_t(0)
+        for _ in range(rounds):
+            rc_ = lib.apk_prove_device(pk.ctx, dptr[0], dptr[1], dptr[2], pub, bl, None, C.byref(pr))
+            if rc_ != 0:
+                errors.append((rc_, lib.apk_last_error()))
+                return
+            check(lib.apk_marshal_proof(C.byref(pr), out, 2048, C.byref(ln)))
+            with lock:
+                blobs[out.raw[: ln.value]] = blobs.get(out.raw[: ln.value], 0) + 1
+
+    pk.paths(reset=True)
+    th = [threading.Thread(target=worker) for _ in range(T)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors[0]
+    assert sum(blobs.values()) == T * rounds
+    assert list(blobs) == [want], "proofs made under load differ from the C oracle's: %s" % sorted(hashlib.sha256(b).hexdigest()[:12] for b in blobs)
+    loaded = pk.paths(reset=True)
+    assert loaded["proofs"] == T * rounds
+    # the loaded forms ran (nearly every batch has other proofs beside it; the first and last few may not)
+    assert loaded["msm_lean_tail"] >= loaded["msm_batches"] // 2, loaded
+    assert loaded["msm_rowcol_serial"] >= loaded["msm_batches"] // 2, loaded
+    assert loaded["msm_sort_two_level"] >= loaded["msm_batches"] // 2, loaded
+    if log_n >= 17:
+        assert loaded["ntt_radix4_by_load"] >= 1, loaded
+    else:
+        assert loaded["msm_sort_two_level_by_load"] >= loaded["msm_batches"] // 2, loaded      # 2^14 bases: two-level only under load
+    # ... and a lone proof on the same context: the latency forms, the same bytes
+    lone = MarshalProof(ap_plonk.Proof(cv, _prove_resident(pk, dptr, pub, bl)))
+    alone = pk.paths(reset=True)
+    assert lone == want
+    assert alone["proofs"] == 1 and alone["msm_lean_tail"] == 0 and alone["msm_rowcol_serial"] == 0 and alone["tail_fill_proofs"] == 1, alone
+    for p in dptr:
+        check(lib.apk_device_free(pk.ctx, p))
+    pk.close()
+
+
+def _prove_resident(pk, dptr, pub, bl):
+    pr = _lib.Proof()
+    check(lib.apk_prove_device(pk.ctx, dptr[0], dptr[1], dptr[2], pub, bl, None, C.byref(pr)))
+    return pr

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
+#include <string.h>
 
 #define REP 64
 #define OUTER 256
@@ -67,7 +68,42 @@ void run(const char* name, int waves_per_simd) {
     hipFree(d);
 }
 
-int main() {
+// --json: the one figure bench.py's roofline needs from THIS box - wall time per wave instruction and SIMD of a dependent
+// v_mad_u64_u32 chain with 4 and with 8 waves per SIMD (the accumulate kernel runs 8 on the 9-limb field) - as one JSON line
+template <int KIND>
+double ns_per_inst_per_simd(int waves_per_simd) {
+    uint32_t* d;
+    hipMalloc(&d, 1 << 24);
+    const int blocks = 256 * waves_per_simd;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    k<KIND><<<blocks, 256>>>(d, 1);
+    hipDeviceSynchronize();
+    double best = 1e30;
+    for (int rep = 0; rep < 5; rep++) {
+        hipEventRecord(e0);
+        k<KIND><<<blocks, 256>>>(d, 2 + rep);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double v = ms * 1e6 / ((double)OUTER * REP * 4) / waves_per_simd;
+        if (v < best) best = v;
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(d);
+    return best;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "--json")) {
+        int cus = 0;
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+        printf("{\"mad_u64_dependent_ns_per_wave_inst_per_simd_4waves\": %.4f, \"mad_u64_dependent_ns_per_wave_inst_per_simd_8waves\": %.4f, "
+               "\"mad_u64_independent_ns_per_wave_inst_per_simd_4waves\": %.4f, \"compute_units\": %d}\n",
+               ns_per_inst_per_simd<1>(4), ns_per_inst_per_simd<1>(8), ns_per_inst_per_simd<0>(4), cus);
+        return 0;
+    }
     for (int w : {1, 2, 3, 4}) {
         run<0>("v_mad_u64_u32 x4 independent", w);
         run<1>("v_mad_u64_u32 dependent chain", w);
