@@ -65,6 +65,10 @@ template <class T> static inline T* ptr(const DevBuf& b) { return reinterpret_ca
 
 static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
+// kzg.ToLagrangeG1 on device buffers (defined at the end of this file): out[i] = [L_i(tau)]G1 from in[j] = [tau^j]G1
+template <class FRP, class FPP>
+int g1_to_lagrange_dev(const Affine<FPP>* d_in, uint64_t n, Affine<FPP>* d_out);
+
 template <class FRP, class FPP, int CURVE_ID>
 class CurveBackend : public Backend {
   public:
@@ -119,6 +123,7 @@ class CurveBackend : public Backend {
         DevBuf table;
         uint32_t n_bases = 0;
         bool built = false;
+        bool plain = false;   // multiples of the bases themselves (scalars leave the Montgomery form in the sort) instead of R^-1 * P
     };
     // APK_MSM_GRAPH=1: the launch sequence of an MSM batch (10 kernels + the result copy) is captured once per (slot, table,
     // scalar vectors, lengths) into a hipGraph and replayed with one hipGraphLaunch.
@@ -193,7 +198,14 @@ class CurveBackend : public Backend {
     std::vector<uint32_t> inj_row_;
     std::vector<Fr> inj_trace_val_;
     DevBuf eql_, eqr_, eqm_, eqo_, es_[3], eqcp_[APK_MAX_COMMITMENTS];
+    // tab_lag_ (round 5): PLAIN multiples of the n Lagrange-SRS points followed by the three blinding points
+    // D_k = [tau^(n+k)]G1 - [tau^k]G1, so that  [f + b(X)(X^n - 1)] = sum f(omega^i) [L_i(tau)] + sum b_k D_k  is ONE MSM over the
+    // witness values themselves (gnark commits L, R, O this way: setup/setup.go:124,138 builds the Lagrange SRS for it).  Plain:
+    // a witness value 0 / 1 / small then has 0 / 1 / few non-zero digits, where R^-1 tables see a uniform a * R mod r.
     MsmTables tab_can_, tab_lag_;
+    int wires_lag_mode_ = -1;                            // APK_WIRES_LAGRANGE at context creation: -1 auto, 0 never, 1 always
+    std::atomic<uint32_t> wire_density_pm_{0xffffffffu}; // non-zero digits of the last measured proof's wires, per mille of uniform
+    std::atomic<uint32_t> proof_seq_{0};
     Aff vk_pts_[8 + APK_MAX_COMMITMENTS];
     std::vector<Slot*> slots_;
     std::mutex mu_;
@@ -348,12 +360,13 @@ class CurveBackend : public Backend {
     }
 
     // ---------------------------------------------------------------------------------------------- MSM runner
-    int build_tables(hipStream_t st, const Aff* d_bases, uint32_t count, MsmTables& T) {
+    int build_tables(hipStream_t st, const Aff* d_bases, uint32_t count, MsmTables& T, bool plain = false) {
         CHK(T.table.alloc((size_t)count * W_ * sizeof(Aff)));
         T.n_bases = count;
+        T.plain = plain;
         MsmPreScale pre{};
 #ifndef APK_MSM_NO_RINV
-        {   // R^-1 mod r as a plain integer = from_mont of the integer 1
+        if (!plain) {   // R^-1 mod r as a plain integer = from_mont of the integer 1
             Fr one_int{};
             one_int.l[0] = 1u;
             const Fr rinv = Fr::from_mont(one_int);
@@ -843,7 +856,7 @@ class CurveBackend : public Backend {
             CHK(s.scratch_in.alloc((size_t)msm_bases_ * sizeof(Fr)));
             return alloc_msm_workspace(s, 1);
         }
-        CHK(s.wl.alloc(fn)); CHK(s.wr.alloc(fn)); CHK(s.wo.alloc(fn));
+        CHK(s.wl.alloc(fn3)); CHK(s.wr.alloc(fn3)); CHK(s.wo.alloc(fn3));   // n values + the blinding scalars of a Lagrange-basis commitment
         CHK(s.cl.alloc(fn3)); CHK(s.cr.alloc(fn3)); CHK(s.co.alloc(fn3)); CHK(s.cz.alloc(fn3));
         for (DevBuf* b : {&s.cl, &s.cr, &s.co, &s.cz}) HIPCHK(hipMemset(b->p, 0, fn3));
         CHK(s.qk_lag.alloc(fn)); CHK(s.qk_can.alloc(fn));
@@ -1106,11 +1119,23 @@ class CurveBackend : public Backend {
         CHK(srs.alloc((size_t)(n_ + 3) * sizeof(Aff)));
         HIPCHK(hipMemcpy(srs.p, d->srs_g1, (size_t)(n_ + 3) * sizeof(Aff), hipMemcpyHostToDevice));
         CHK(build_tables(st, ptr<Aff>(srs), n_ + 3, tab_can_));
-        if (d->srs_g1_lagrange) {
+        wires_lag_mode_ = env_int("APK_WIRES_LAGRANGE", -1, -1, 1);
+        if (d->srs_g1_lagrange || wires_lag_mode_ != 0) {
+            // the extended Lagrange table: the caller's Lagrange SRS (gnark's ProvingKey.KzgLagrange), or - not given - derived
+            // here from the canonical one (kzg.ToLagrangeG1 as an inverse FFT in the exponent, kernels_setup.h), then D_0..D_2
             DevBuf lag;
-            CHK(lag.alloc((size_t)n_ * sizeof(Aff)));
-            HIPCHK(hipMemcpy(lag.p, d->srs_g1_lagrange, (size_t)n_ * sizeof(Aff), hipMemcpyHostToDevice));
-            CHK(build_tables(st, ptr<Aff>(lag), n_, tab_lag_));
+            CHK(lag.alloc((size_t)(n_ + 3) * sizeof(Aff)));
+            if (d->srs_g1_lagrange) HIPCHK(hipMemcpy(lag.p, d->srs_g1_lagrange, (size_t)n_ * sizeof(Aff), hipMemcpyHostToDevice));
+            else CHK((g1_to_lagrange_dev<FRP, FPP>(ptr<Aff>(srs), n_, ptr<Aff>(lag))));
+            const Aff* g = reinterpret_cast<const Aff*>(d->srs_g1);
+            Aff dk[3];
+            for (int k = 0; k < 3; k++) {
+                Pt p = Pt::from_affine(g[n_ + k]);
+                p.madd(g[k], /*negate=*/true);
+                dk[k] = p.to_affine();
+            }
+            HIPCHK(hipMemcpy(ptr<Aff>(lag) + n_, dk, sizeof dk, hipMemcpyHostToDevice));
+            CHK(build_tables(st, ptr<Aff>(lag), n_ + 3, tab_lag_, /*plain=*/true));
             HIPCHK(hipDeviceSynchronize());
         }
         HIPCHK(hipDeviceSynchronize());
@@ -1174,7 +1199,7 @@ class CurveBackend : public Backend {
             dsc = s.scratch_in.p;
         }
         MsmBatchArgs a{};
-        a.batch = 1; a.scalars[0] = dsc; a.len[0] = (uint32_t)len; a.offset[0] = 0;
+        a.batch = 1; a.scalars[0] = dsc; a.len[0] = (uint32_t)len; a.offset[0] = 0; a.plain = T.plain ? 1u : 0u;
         CHK(run_msm(s, T, a, reinterpret_cast<Aff*>(s.h_pinned)));
         CHK(sync_results(s));
         memcpy(out, s.h_pinned, sizeof(Aff));
@@ -1196,6 +1221,7 @@ class CurveBackend : public Backend {
         Slot& s = *g.s;
         MsmBatchArgs a{};
         a.batch = count;
+        a.plain = T.plain ? 1u : 0u;
         for (uint32_t b = 0; b < count; b++) {
             hipPointerAttribute_t at{};
             if (d_scalars[b] && (hipPointerGetAttributes(&at, d_scalars[b]) != hipSuccess || at.type != hipMemoryTypeDevice)) {
@@ -1526,7 +1552,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         // kzg.Commit(pi2, Lagrange SRS) then hash_to_field (templateLogicSigBN254.go:386-397)
         HIPCHK(hipMemcpyAsync(s.pi2_lag[k].p, pi2[k], fn, kin, st));
         MsmBatchArgs a{};
-        a.batch = 1; a.scalars[0] = s.pi2_lag[k].p; a.len[0] = n; a.offset[0] = 0;
+        a.batch = 1; a.scalars[0] = s.pi2_lag[k].p; a.len[0] = n; a.offset[0] = 0; a.plain = tab_lag_.plain ? 1u : 0u;
         CHK(commit(s, tab_lag_, 1, a, hp));
         CHK(inv_ntt_n(st, ptr<Fr>(s.pi2_lag[k]), ptr<Fr>(s.pi2_can[k])));
         {
@@ -1541,6 +1567,43 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     }
     Fr* canon[3] = {ptr<Fr>(s.cl), ptr<Fr>(s.cr), ptr<Fr>(s.co)};
     const Fr* wires[3] = {dL, dR, dO};
+    // [L][R][O] over the Lagrange SRS (gnark's way) or over the canonical one: the same group elements, so the choice is about
+    // work only.  Over the Lagrange SRS the scalars are the witness values - in real circuits mostly 0, 1 or small, i.e. few
+    // non-zero digits on the plain table - over the canonical SRS they are the uniform coefficients of the blinded polynomial.
+    // auto: the Lagrange route when the wires' non-zero digits (msm_density_kernel, every 16th proof of the context; the first
+    // proof waits for its own count) are below 90 % of what uniform scalars have.  Never with a commit hook installed (the
+    // multi-GPU schedules deal canonical batches).
+    constexpr uint32_t DENSITY_UNKNOWN = 0xffffffffu;
+    volatile uint32_t* h_density = reinterpret_cast<volatile uint32_t*>(reinterpret_cast<uint8_t*>(s.h_pinned) + 3200);
+    bool use_lag = false, measuring = false;
+    if (tab_lag_.built && tab_lag_.plain && !hook_ && wires_lag_mode_ != 0) {
+        const uint32_t seq = proof_seq_.fetch_add(1, std::memory_order_relaxed);
+        uint32_t pm = wire_density_pm_.load(std::memory_order_relaxed);
+        if (wires_lag_mode_ == 1) use_lag = true;
+        else {
+            measuring = pm == DENSITY_UNKNOWN || (seq & 15u) == 0;
+            if (measuring) {
+                uint32_t* d_cnt = ptr<uint32_t>(s.tail_flag) + 2;
+                HIPCHK(hipMemsetAsync(d_cnt, 0, 4, st));
+                MsmBatchArgs da{};
+                da.batch = 3;
+                for (int j = 0; j < 3; j++) { da.scalars[j] = wires[j]; da.len[j] = n; }
+                msm_density_kernel<FRP><<<dim3(cdiv(n, 256) < 512 ? cdiv(n, 256) : 512, 3), 256, 0, st>>>(da, win_, d_cnt); KCHK();
+                HIPCHK(hipMemcpyAsync(const_cast<uint32_t*>(h_density), d_cnt, 4, hipMemcpyDeviceToHost, st));
+            }
+            auto per_mille = [&]() { return (uint32_t)((uint64_t)*h_density * 1000u / ((uint64_t)3 * n * W_)); };
+            if (pm == DENSITY_UNKNOWN) {        // the context's first proof: wait for the count
+                HIPCHK(hipStreamSynchronize(st));
+                pm = per_mille();
+                wire_density_pm_.store(pm, std::memory_order_relaxed);
+                measuring = false;
+            }
+            use_lag = pm < 900u;
+        }
+    }
+    Fr* lagv[3] = {ptr<Fr>(s.wl), ptr<Fr>(s.wr), ptr<Fr>(s.wo)};
+    if (use_lag && on_device)
+        for (int j = 0; j < 3; j++) HIPCHK(hipMemcpyAsync(lagv[j], wires[j], fn, hipMemcpyDeviceToDevice, st));
     // (no zero-fill of the tails: blind_kernel assigns the coefficients n .. n+d-1 and nothing reads beyond them)
     {
         const uint32_t lens[3] = {n, n, n};
@@ -1548,7 +1611,10 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     }
     {
         Blind3<FRP> b3{};
-        for (int j = 0; j < 3; j++) { b3.p[j] = canon[j]; b3.b[j].v[0] = bl[2 * j]; b3.b[j].v[1] = bl[2 * j + 1]; }
+        for (int j = 0; j < 3; j++) {
+            b3.p[j] = canon[j]; b3.b[j].v[0] = bl[2 * j]; b3.b[j].v[1] = bl[2 * j + 1];
+            b3.lag[j] = use_lag ? lagv[j] : nullptr;     // the blinding scalars behind the n witness values: the scalars of D_0, D_1
+        }
         blind3_kernel<FRP><<<3, 64, 0, st>>>(b3, n, 2); KCHK();
     }
     const int fill = tail_fill(s);
@@ -1556,9 +1622,11 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     {
         MsmBatchArgs a{};
         a.batch = 3;
-        for (int j = 0; j < 3; j++) { a.scalars[j] = canon[j]; a.len[j] = n + 2; a.offset[j] = 0; }
+        for (int j = 0; j < 3; j++) { a.scalars[j] = use_lag ? lagv[j] : canon[j]; a.len[j] = n + 2; a.offset[j] = 0; }
+        a.plain = use_lag ? 1u : 0u;
+        if (use_lag) path(P_LAGRANGE_WIRES);
         s.mark_acc = fill;
-        const int rc = commit(s, tab_can_, 0, a, hp);
+        const int rc = use_lag ? commit(s, tab_lag_, 1, a, hp) : commit(s, tab_can_, 0, a, hp);
         s.mark_acc = 0;
         CHK(rc);
     }
@@ -1593,6 +1661,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         }
     }
     CHK(sync_results(s));
+    if (measuring) wire_density_pm_.store((uint32_t)((uint64_t)*h_density * 1000u / ((uint64_t)3 * n * W_)), std::memory_order_relaxed);
     Aff lro[3] = {hp[0], hp[1], hp[2]};
     for (int j = 0; j < 3; j++) store_pt(out->lro[j], lro[j]);
 
@@ -1984,13 +2053,13 @@ int g1_decompress_impl(int device, const uint8_t* in, uint64_t count, void* out)
     return APK_OK;
 }
 
+// kzg.ToLagrangeG1 on device buffers: an inverse FFT in the exponent (kernels_setup.h); complete when it returns
 template <class FRP, class FPP>
-int g1_to_lagrange_impl(int device, const void* points, uint64_t n, void* out) {
+int g1_to_lagrange_dev(const Affine<FPP>* d_in, uint64_t n, Affine<FPP>* d_out) {
     using Fr = Fe<FRP>;
     using Aff = Affine<FPP>;
     using Pt = XYZZ<FPP>;
     if (n < 2 || (n & (n - 1)) || n > (1ull << 24)) { set_error("ToLagrangeG1: size must be a power of two in [2, 2^24]"); return APK_ERR_ARG; }
-    CHK(pick_device(device));
     int log_n = 0;
     while ((1ull << log_n) < n) log_n++;
     // omega^-1 of the size-n domain, 1/n
@@ -2002,24 +2071,35 @@ int g1_to_lagrange_impl(int device, const void* points, uint64_t n, void* out) {
     Fr nn = Fr::zero();
     nn.l[0] = (uint32_t)n;
     Fr ninv = Fr::inv(Fr::to_mont(nn));
-    DevBuf din, dout, work, twi;
-    CHK(din.alloc(n * sizeof(Aff)));
-    CHK(dout.alloc(n * sizeof(Aff)));
+    DevBuf work, twi;
     CHK(work.alloc(n * sizeof(Pt)));
     CHK(twi.alloc((n / 2 + 1) * sizeof(Fr)));
-    HIPCHK(hipMemcpy(din.p, points, n * sizeof(Aff), hipMemcpyHostToDevice));
     PowersBatch<FRP> pb{};
     pb.out[0] = ptr<Fr>(twi); pb.w[0] = winv; pb.scale[0] = Fr::one();
     powers_kernel<FRP><<<dim3(cdiv(cdiv(n / 2, 8), 256), 1), 256>>>(pb, (uint32_t)(n / 2));
     KCHK();
-    lagrange_load_kernel<FPP><<<cdiv(n, 256), 256>>>(ptr<Aff>(din), (uint32_t)n, log_n, ptr<Pt>(work));
+    lagrange_load_kernel<FPP><<<cdiv(n, 256), 256>>>(d_in, (uint32_t)n, log_n, ptr<Pt>(work));
     KCHK();
     for (int t = 0; t < log_n; t++) {
         lagrange_stage_kernel<FRP, FPP><<<cdiv(n / 2, 128), 128>>>(ptr<Pt>(work), ptr<Fr>(twi), (uint32_t)n, log_n, t);
         KCHK();
     }
-    lagrange_finish_kernel<FRP, FPP><<<cdiv(n, 128), 128>>>(ptr<Pt>(work), (uint32_t)n, ninv, ptr<Aff>(dout));
+    lagrange_finish_kernel<FRP, FPP><<<cdiv(n, 128), 128>>>(ptr<Pt>(work), (uint32_t)n, ninv, d_out);
     KCHK();
+    HIPCHK(hipDeviceSynchronize());
+    return APK_OK;
+}
+
+template <class FRP, class FPP>
+int g1_to_lagrange_impl(int device, const void* points, uint64_t n, void* out) {
+    using Aff = Affine<FPP>;
+    if (n < 2 || (n & (n - 1)) || n > (1ull << 24)) { set_error("ToLagrangeG1: size must be a power of two in [2, 2^24]"); return APK_ERR_ARG; }
+    CHK(pick_device(device));
+    DevBuf din, dout;
+    CHK(din.alloc(n * sizeof(Aff)));
+    CHK(dout.alloc(n * sizeof(Aff)));
+    HIPCHK(hipMemcpy(din.p, points, n * sizeof(Aff), hipMemcpyHostToDevice));
+    CHK((g1_to_lagrange_dev<FRP, FPP>(ptr<Aff>(din), n, ptr<Aff>(dout))));
     HIPCHK(hipMemcpy(out, dout.p, n * sizeof(Aff), hipMemcpyDeviceToHost));
     return APK_OK;
 }

@@ -47,6 +47,8 @@ struct MsmBatchArgs {
     uint32_t len[MSM_MAX_BATCH];
     uint32_t offset[MSM_MAX_BATCH];      // first base index used by msm b (bases [offset, offset+len))
     uint32_t batch;
+    uint32_t plain;                      // the table holds the bases themselves, not R^-1 * P: the sort leaves the Montgomery form first, so
+                                         // that SMALL values have few non-zero digits (Lagrange-basis wire commitments: backend_impl.h)
 };
 
 // ---- signed-digit recoding ---------------------------------------------------------------------------
@@ -90,6 +92,7 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_digits_kernel(MsmBatch
         // Montgomery product per scalar to leave the form (it was ~45 % of the two passes' instructions).
 #ifndef APK_MSM_NO_RINV
         Fr s = reinterpret_cast<const Fr*>(a.scalars[b])[i];
+        if (a.plain) s = Fr::from_mont(s);        // uniform
 #else
         Fr s = Fr::from_mont(reinterpret_cast<const Fr*>(a.scalars[b])[i]);
 #endif
@@ -251,6 +254,7 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part_kernel(MsmBatchAr
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
 #ifndef APK_MSM_NO_RINV
         Fr s = reinterpret_cast<const Fr*>(a.scalars[b])[i];      // Montgomery form as it is: the tables hold R^-1 * P
+        if (a.plain) s = Fr::from_mont(s);                        // ... unless they hold P itself (uniform)
 #else
         Fr s = Fr::from_mont(reinterpret_cast<const Fr*>(a.scalars[b])[i]);
 #endif
@@ -544,6 +548,23 @@ __device__ __forceinline__ void msm_for_each_digit(const Fe<FR>& s, const MsmWin
     }
 }
 
+// Non-zero signed digits of the CANONICAL values of a batch's scalars (grid (blocks, batch), 256 lanes): what a commitment over
+// plain tables would sort and add.  The prover compares it with the uniform expectation (len x W) to decide whether the wire
+// polynomials are committed over the Lagrange SRS - where the scalars are the witness values themselves, mostly 0 / 1 / small in
+// real circuits - or, as always before round 5, over the canonical SRS after the inverse transform (backend_impl.h, round 1).
+template <class FR>
+__global__ void __launch_bounds__(256) msm_density_kernel(MsmBatchArgs a, MsmWindows win, uint32_t* __restrict__ out) {
+    wave_priority<APK_PRIO_SORT>();
+    using Fr = Fe<FR>;
+    const uint32_t b = blockIdx.y;
+    const Fr* __restrict__ sc = reinterpret_cast<const Fr*>(a.scalars[b]);
+    uint32_t cnt = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.len[b]; i += gridDim.x * blockDim.x)
+        msm_for_each_digit<FR>(Fr::from_mont(sc[i]), win, [&](uint32_t, uint32_t, uint32_t) { cnt++; });
+    for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_down(cnt, d, 64);
+    if ((threadIdx.x & 63u) == 0 && cnt) atomicAdd(out, cnt);
+}
+
 constexpr int MSM_PART1_HOLD = 3;   // scalars a lane keeps in registers between the two passes (2 049 per slice / 1 024 lanes)
 template <class FR>
 __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part1_kernel(MsmBatchArgs a, MsmWindows win, MsmPartCfg pc, uint32_t n_max, uint32_t G,
@@ -569,7 +590,7 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part1_kernel(MsmBatchA
         int it = 0;
         for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x, it++) {
 #ifndef APK_MSM_NO_RINV
-            const Fr s = sc[i];
+            const Fr s = a.plain ? Fr::from_mont(sc[i]) : sc[i];
 #else
             const Fr s = Fr::from_mont(sc[i]);
 #endif
@@ -613,7 +634,7 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part1_kernel(MsmBatchA
                 for (int h = 0; h < MSM_PART1_HOLD; h++) if (h == it) s = held[h];
             } else {
 #ifndef APK_MSM_NO_RINV
-                s = sc[i];
+                s = a.plain ? Fr::from_mont(sc[i]) : sc[i];
 #else
                 s = Fr::from_mont(sc[i]);
 #endif

@@ -40,6 +40,8 @@ template <class FR>
 struct Blind3 {
     Fe<FR>* p[3];
     Fr4<FR> b[3];
+    Fe<FR>* lag[3];   // or null: the Lagrange-basis scalar vector of the wire (n values); b is appended at [n, n + d) - the scalars of
+                      // the blinding points [tau^(n+k)] - [tau^k] of the extended Lagrange table (backend_impl.h, round 1)
 };
 template <class FR>
 __global__ void blind3_kernel(Blind3<FR> a, uint32_t n, int d) {
@@ -47,8 +49,11 @@ __global__ void blind3_kernel(Blind3<FR> a, uint32_t n, int d) {
     Fe<FR>* p = a.p[blockIdx.x];
     if (i < d) {
         const Fe<FR> v = a.b[blockIdx.x].v[i];
-        p[i] = p[i] - v;
-        p[n + i] = v;
+        if (p) {
+            p[i] = p[i] - v;
+            p[n + i] = v;
+        }
+        if (a.lag[blockIdx.x]) a.lag[blockIdx.x][n + i] = v;
     }
 }
 

@@ -504,12 +504,14 @@ def roofline_from_stats(args, cv, st, pmc, issue=None):
             # from the SQ_INSTS_VALU pass above, wall time per wave instruction and SIMD from tools/ubench/valu_rates --json
             # (dependent v_mad_u64_u32 chain, 4 waves per SIMD), on (4 x CUs) SIMDs x 64 lanes
             ipa = pmc["valu_instructions_per_addition"]
-            ns = issue["mad_u64_dependent_ns_per_wave_inst_per_simd_4waves"]
+            ns = min(issue["mad_u64_dependent_ns_per_wave_inst_per_simd_4waves"], issue["mad_u64_dependent_ns_per_wave_inst_per_simd_8waves"])
             simds = 4 * (issue.get("compute_units") or 256)
             bound = simds * 64 / (ipa * ns * 1e-9)
             roofline["valu"].update({"instructions_per_addition": round(ipa, 1), "ns_per_wave_instruction_per_simd": round(ns, 4), "simds": simds,
                                      "issue_bound": round(bound / 1e9, 3), "frac": round(adds_per_s / bound, 4),
-                                     "basis": "this run: SQ_INSTS_VALU pass x 64 lanes / (pairs x windows) additions; tools/ubench/valu_rates --json"})
+                                     "issue_rates": issue,
+                                     "basis": "this run: SQ_INSTS_VALU pass x 64 lanes / (pairs x windows) additions; tools/ubench/valu_rates --json "
+                                              "(dependent v_mad_u64_u32 chain, the faster of 4 and 8 waves per SIMD; every instruction priced as a mad)"})
         if pmc:
             roofline["hbm_traffic_frac"] = round(pmc["hbm_bytes_per_pair"] * pairs_per_launch / (acc_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     return roofline

@@ -75,7 +75,13 @@ typedef struct {
     uint32_t nb_public;        /* VK NbPublicVariables */
     uint32_t nb_commitments;   /* BSB22 commitments (<= APK_MAX_COMMITMENTS) */
     const void* srs_g1;        /* n+3 G1 affine: canonical SRS  = gnark kzg.ProvingKey.G1 (setup/setup.go:113-114) */
-    const void* srs_g1_lagrange; /* n G1 affine: Lagrange SRS (setup/setup.go:124,138); NULL if nb_commitments == 0 */
+    const void* srs_g1_lagrange; /* n G1 affine: Lagrange SRS = gnark's ProvingKey.KzgLagrange (setup/setup.go:124,138), or NULL: the
+                                  * context then derives it from srs_g1 on the device (kzg.ToLagrangeG1) unless APK_WIRES_LAGRANGE=0
+                                  * and nb_commitments == 0.  It serves the BSB22 commitments and - round 5 - [L][R][O], which gnark
+                                  * commits over this basis: the scalars are then the witness values themselves (mostly 0 / 1 / small
+                                  * in real circuits: few non-zero digits).  APK_WIRES_LAGRANGE (read at apk_ctx_create): -1 = the
+                                  * context decides per proof from the wires' non-zero digits (default), 0 = always the canonical
+                                  * SRS (rounds 1-4), 1 = always the Lagrange SRS.  Same group elements, same proof bytes. */
     const void* ql;            /* trace columns in Lagrange form, n Fr each  = gnark plonk.Trace{Ql,Qr,Qm,Qo,Qk} */
     const void* qr;
     const void* qm;
@@ -112,7 +118,8 @@ typedef struct {
 int apk_ctx_get_vk(apk_ctx* ctx, apk_vk* out);
 
 /* ---- primitives (row a4 / a6 of SURVEY.md §8a) --------------------------------------------------------- */
-/* kzg.Commit: sum scalars[i] * SRS[i].  basis 0 = canonical SRS (len <= n+3), 1 = Lagrange SRS (len <= n).
+/* kzg.Commit: sum scalars[i] * SRS[i].  basis 0 = canonical SRS (len <= n+3), 1 = Lagrange SRS (len <= n; the context's table
+ * continues with the three blinding points [tau^(n+k)]G1 - [tau^k]G1 at indices n..n+2, so len <= n+3 is accepted).
  * scalars: host memory, `len` Fr in Montgomery form.  out: one G1 affine (apk_g1_bytes). */
 int apk_msm_g1(apk_ctx* ctx, int basis, const void* scalars, uint64_t len, void* out);
 /* same, scalars already resident in device memory (what bench.py times: inputs in HBM) */

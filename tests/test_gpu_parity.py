@@ -836,3 +836,44 @@ def _prove_resident(pk, dptr, pub, bl):
     pr = _lib.Proof()
     check(lib.apk_prove_device(pk.ctx, dptr[0], dptr[1], dptr[2], pub, bl, None, C.byref(pr)))
     return pr
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12-381"])
+def test_lagrange_basis_wire_commitments_are_the_same_group_elements(gpu, cname, monkeypatch):
+    """Round 5: [L][R][O] over the Lagrange SRS the way gnark commits them (setup/setup.go:124,138 builds that SRS for it) - one
+    MSM over the witness values + the blinding scalars on the points [tau^(n+k)] - [tau^k] - is the same group element as the
+    canonical-basis commitment of the blinded polynomial, so every proof stays byte-identical to the oracle's, whichever route a
+    context takes.  auto: a bit-heavy witness (workloads.skewed_circuit: ~80 % of the wire values in {0, 1}) takes the Lagrange
+    route from its first proof, uniform wires stay canonical; APK_WIRES_LAGRANGE = 1 / 0 force either (read when the context is
+    created).  The Lagrange table is derived on the device when the caller gives no Lagrange SRS, and taken from the caller's
+    (as gnark's ProvingKey.KzgLagrange) when it does - both are exercised."""
+    from algoplonk_amd import workloads
+    cv, ov = CURVES[cname]
+    log_n = 10
+    for kind, mode, given, expect_lag in (("bits", None, False, True), ("bits", None, True, True), ("bits", "0", False, False),
+                                          ("uniform", None, False, False), ("uniform", "1", True, True), ("uniform", "1", False, True)):
+        wl = (workloads.skewed_circuit if kind == "bits" else workloads.random_circuit)(cv, log_n, 0xB175)
+        n = wl.ccs.domain_size()
+        if mode is None:
+            monkeypatch.delenv("APK_WIRES_LAGRANGE", raising=False)
+        else:
+            monkeypatch.setenv("APK_WIRES_LAGRANGE", mode)
+        srs = ap_setup.unsafe_srs(cv, n, wl.tau, device=gpu, lagrange=given)
+        pk, vk = ap_plonk.Setup(wl.ccs, srs, device=gpu, slots=2)
+        oc = oracle_circuit_from_ccs(ov, wl.ccs)
+        opk = oplonk.setup(oc, oplonk.synthetic_srs(ov, n, wl.tau, materialize=False))
+        L, R, O = oplonk.solve_lro(oc, wl.solution)
+        want = oplonk.marshal_proof(ov, oplonk.prove(opk, L, R, O, wl.witness.public, wl.blinding))
+        pk.paths(reset=True)
+        for _ in range(3):
+            assert MarshalProof(ap_plonk.Prove(wl.ccs, pk, wl.witness, wl.blinding)) == want, (kind, mode, given)
+        got = pk.paths(reset=True)
+        assert got["proofs"] == 3 and got["msm_lagrange_wires"] == (3 if expect_lag else 0), (kind, mode, given, got)
+        # the extended Lagrange table through the primitive: basis 1, the n Lagrange points followed by the three blinding points
+        if given or mode != "0":
+            g = SplitMix64(5)
+            sc = [g.below(3) for _ in range(n)] + [g.fr(cv.r) for _ in range(3)]
+            f_at_tau = oplonk.poly_eval(oplonk.intt(sc[:n], ov.omega(n), cv.r), wl.tau, cv.r)
+            blind = sum(b * (pow(wl.tau, n + k, cv.r) - pow(wl.tau, k, cv.r)) for k, b in enumerate(sc[n:])) % cv.r
+            assert pk.msm(sc, basis=1) == ov.mul(ov.g1, (f_at_tau + blind) % cv.r)
+        pk.close()
