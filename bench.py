@@ -283,26 +283,31 @@ def pmc_traffic(curve: str, log_n: int, window: int, timeout_s: float = 420.0):
     env = dict(os.environ, TMPDIR="/tmp")
     if window:
         env["APK_MSM_WINDOW"] = str(window)
-    for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+    # (the HBM counters one per pass, as the guide prescribes; the three SQ instruction counters share a pass)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32"):
         d = tempfile.mkdtemp(prefix="apk_pmc_", dir="/tmp")
         try:
-            subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable,
+            subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + counter.split() + ["-d", d, "-o", "p", "--", sys.executable,
                             os.path.join(ROOT, "tools", "prof_msm.py"), str(log_n), "4", "0", curve], cwd="/tmp", env=env, capture_output=True,
                            timeout=timeout_s, check=True)
             dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("_results.db")]
             db = sqlite3.connect(dbs[0])
-            tot, launches = 0.0, set()
+            tots, launches = {}, set()
             for name, did, cname, val in db.execute("select kernel_name, dispatch_id, counter_name, value from counters_collection"):
-                if "msm_accumulate_kernel" in name and cname == counter:
-                    tot += val
+                if "msm_accumulate_kernel" in name and cname in counter.split():
+                    tots[cname] = tots.get(cname, 0.0) + val
                     launches.add(did)
-            out[counter] = (tot, len(launches))
+            for cname in counter.split():
+                if cname in tots:
+                    out[cname] = (tots[cname], len(launches))
         except Exception:
-            if counter == "SQ_INSTS_VALU":
+            if counter.startswith("SQ_"):
                 continue
             return None
         finally:
             shutil.rmtree(d, ignore_errors=True)
+    if "FETCH_SIZE" not in out or "WRITE_SIZE" not in out:
+        return None
     n_msm = 12                                     # prof_msm.py: 4 single MSMs + 8 VK commitments (two batches of 4)
     pairs = n_msm * (1 << log_n)
     fetch_kb, nl = out["FETCH_SIZE"]
@@ -316,6 +321,9 @@ def pmc_traffic(curve: str, log_n: int, window: int, timeout_s: float = 420.0):
         windows = (rbits + 1 + window - 1) // window
         res["valu_wave_instructions"] = out["SQ_INSTS_VALU"][0]
         res["valu_instructions_per_addition"] = out["SQ_INSTS_VALU"][0] * 64.0 / (pairs * windows)
+        if "SQ_INSTS_VALU_INT64" in out:          # the dynamic instruction mix: v_mad_u64_u32 and the 64-bit shifts / adds
+            res["valu_int64_share"] = out["SQ_INSTS_VALU_INT64"][0] / max(out["SQ_INSTS_VALU"][0], 1.0)
+            res["valu_int32_share"] = out.get("SQ_INSTS_VALU_INT32", (0.0, 0))[0] / max(out["SQ_INSTS_VALU"][0], 1.0)
     return res
 
 
@@ -504,14 +512,21 @@ def roofline_from_stats(args, cv, st, pmc, issue=None):
             # from the SQ_INSTS_VALU pass above, wall time per wave instruction and SIMD from tools/ubench/valu_rates --json
             # (dependent v_mad_u64_u32 chain, 4 waves per SIMD), on (4 x CUs) SIMDs x 64 lanes
             ipa = pmc["valu_instructions_per_addition"]
-            ns = min(issue["mad_u64_dependent_ns_per_wave_inst_per_simd_4waves"], issue["mad_u64_dependent_ns_per_wave_inst_per_simd_8waves"])
+            ns_mad = min(issue["mad_u64_dependent_ns_per_wave_inst_per_simd_4waves"], issue["mad_u64_dependent_ns_per_wave_inst_per_simd_8waves"])
+            ns, mix = ns_mad, "every instruction priced as a v_mad_u64_u32"
+            share64 = pmc.get("valu_int64_share")
+            if share64 is not None and 0.3 <= share64 <= 0.95 and issue.get("add_co_chain_ns_per_wave_inst_per_simd_8waves"):
+                # mix-weighted: the 64-bit integer instructions (SQ_INSTS_VALU_INT64: the mads and 64-bit shifts) at the mad's rate,
+                # the rest at the 32-bit add chain's
+                ns = share64 * ns_mad + (1.0 - share64) * issue["add_co_chain_ns_per_wave_inst_per_simd_8waves"]
+                mix = "%.1f %% 64-bit integer instructions at the mad rate, the rest at the 32-bit add-chain rate" % (100 * share64)
             simds = 4 * (issue.get("compute_units") or 256)
             bound = simds * 64 / (ipa * ns * 1e-9)
             roofline["valu"].update({"instructions_per_addition": round(ipa, 1), "ns_per_wave_instruction_per_simd": round(ns, 4), "simds": simds,
                                      "issue_bound": round(bound / 1e9, 3), "frac": round(adds_per_s / bound, 4),
                                      "issue_rates": issue,
                                      "basis": "this run: SQ_INSTS_VALU pass x 64 lanes / (pairs x windows) additions; tools/ubench/valu_rates --json "
-                                              "(dependent v_mad_u64_u32 chain, the faster of 4 and 8 waves per SIMD; every instruction priced as a mad)"})
+                                              "(dependent chains, the faster of 4 and 8 waves per SIMD); " + mix})
         if pmc:
             roofline["hbm_traffic_frac"] = round(pmc["hbm_bytes_per_pair"] * pairs_per_launch / (acc_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     return roofline

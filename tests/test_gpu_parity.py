@@ -134,10 +134,12 @@ def test_hip_prover_reproduces_golden_vectors(gpu, vec):
 
 
 @pytest.mark.parametrize("cname", ["bn254", "bls12-381"])
-def test_unsatisfied_witness_is_an_error_not_a_proof(gpu, cname):
+def test_unsatisfied_witness_is_an_error_not_a_proof(gpu, cname, monkeypatch):
     cv, ov = CURVES[cname]
     ccs, w, sol = random_chain_ccs(cv, 6, 5)
+    monkeypatch.setenv("APK_WIRES_LAGRANGE", "0")     # no Lagrange SRS given and none derived: basis 1 must be refused below
     pk, vk, opk, srs = _setup_pair(cv, ov, ccs, 3, gpu)
+    monkeypatch.delenv("APK_WIRES_LAGRANGE")
     L, R, O = frontend.wire_columns(ccs, sol)
     O[9] = (O[9] + 1) % cv.r
     out = _lib.Proof()

@@ -100,8 +100,10 @@ int main(int argc, char** argv) {
         int cus = 0;
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
         printf("{\"mad_u64_dependent_ns_per_wave_inst_per_simd_4waves\": %.4f, \"mad_u64_dependent_ns_per_wave_inst_per_simd_8waves\": %.4f, "
-               "\"mad_u64_independent_ns_per_wave_inst_per_simd_4waves\": %.4f, \"compute_units\": %d}\n",
-               ns_per_inst_per_simd<1>(4), ns_per_inst_per_simd<1>(8), ns_per_inst_per_simd<0>(4), cus);
+               "\"mad_u64_independent_ns_per_wave_inst_per_simd_4waves\": %.4f, \"add_co_chain_ns_per_wave_inst_per_simd_8waves\": %.4f, "
+               "\"lshl_add_u64_ns_per_wave_inst_per_simd_8waves\": %.4f, \"mov_b32_ns_per_wave_inst_per_simd_8waves\": %.4f, \"compute_units\": %d}\n",
+               ns_per_inst_per_simd<1>(4), ns_per_inst_per_simd<1>(8), ns_per_inst_per_simd<0>(4), ns_per_inst_per_simd<6>(8),
+               ns_per_inst_per_simd<3>(8), ns_per_inst_per_simd<2>(8), cus);
         return 0;
     }
     for (int w : {1, 2, 3, 4}) {
