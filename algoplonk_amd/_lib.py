@@ -35,7 +35,7 @@ SYMBOLS = [
     "apk_comm_transport", "apk_msm_g1_sharded", "apk_comm_split_begin", "apk_comm_split_end", "apk_comm_serve", "apk_comm_set_compute",
     "apk_comm_commit", "apk_comm_wires", "apk_comm_rccl_ranks", "apk_comm_rccl_selftest",
     "apk_comm_commit_local", "apk_comm_spmd_begin", "apk_comm_spmd_end", "apk_comm_allgather_device", "apk_comm_subcoset_active",
-    "apk_ctx_set_subcoset",
+    "apk_ctx_set_subcoset", "apk_comm_transport_reason", "apk_comm_link_probe", "apk_comm_phase_ms",
 ]
 
 
@@ -189,6 +189,9 @@ def _load() -> C.CDLL:
     lib.apk_comm_bind.argtypes = [vp, vp]
     lib.apk_comm_transport.argtypes = [vp]; lib.apk_comm_transport.restype = C.c_char_p
     lib.apk_comm_rccl_ranks.argtypes = [vp]
+    lib.apk_comm_transport_reason.argtypes = [vp]; lib.apk_comm_transport_reason.restype = C.c_char_p
+    lib.apk_comm_link_probe.argtypes = [vp, sz, sz, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.apk_comm_phase_ms.argtypes = [vp, C.POINTER(C.c_double), i32]
     lib.apk_comm_rccl_selftest.argtypes = [i32, C.POINTER(i32)]
     lib.apk_msm_g1_sharded.argtypes = [vp, vp, u64, vp]
     lib.apk_comm_split_begin.argtypes = [vp]

@@ -517,7 +517,7 @@ class CurveBackend : public Backend {
         // Round 4, with the two-launch form and the wave priorities: under LOAD it also pays from 2^13 bases (same box, proofs/s:
         // BN254 2^13 +1 %, 2^14 +3.5 %, 2^15 +4.6 %, BLS12-381 2^14 +3 %) while a LONE proof there is 2.5 - 4 % slower with it - so
         // below 2^16 bases it follows the load.
-        const bool sort2_want = sort2_env >= 0 ? sort2_env != 0 : (T.n_bases >= 65536u || (others_busy && T.n_bases >= 8192u));
+        const bool sort2_want = !one_level_ok() || (sort2_env >= 0 ? sort2_env != 0 : (T.n_bases >= 65536u || (others_busy && T.n_bases >= 8192u)));
         // Round 4: the packed entry's layout follows the context (MsmPartCfg, part_cfg_): the table index takes the bits it needs
         // and the partitions shrink until one fits the second level's LDS tile - BLS12-381 2^21 x 16 windows (26 index bits,
         // 2 048 partitions of 16 buckets) sorts in two levels as well.  The first level's slices are cut so that a slice's entries
@@ -526,16 +526,20 @@ class CurveBackend : public Backend {
         const uint32_t P = pc.P;
         uint32_t G2 = G;
         {
+            const uint32_t stage_max = part_stage_max();
             uint32_t sl2 = slice_eff ? slice_eff : 2048u;
-            if ((uint64_t)sl2 * W_ > MSM_PART_STAGE) sl2 = MSM_PART_STAGE / (uint32_t)W_;
+            if ((uint64_t)sl2 * W_ > stage_max) sl2 = stage_max / (uint32_t)W_;
             G2 = cdiv(maxlen, sl2);
-            if (G2 > 1024u && (uint64_t)cdiv(maxlen, 1024u) * W_ <= MSM_PART_STAGE) G2 = 1024u;   // 2^21 + 3 scalars: 1 024 slices of 2 049
+            if (G2 > 1024u && (uint64_t)cdiv(maxlen, 1024u) * W_ <= stage_max) G2 = 1024u;   // 2^21 + 3 scalars: 1 024 slices of 2 049
+            else if (G2 > MSM_PART_GMAX && (uint64_t)cdiv(maxlen, MSM_PART_GMAX) * W_ <= stage_max) G2 = MSM_PART_GMAX;
             if (G2 < 1) G2 = 1;
         }
         static const int small_scan_env = env_int("APK_MSM_PART_SMALL_SCAN", 1, 0, 1);   // 0: always the three-launch scan (tests)
         const bool small_scan = small_scan_env && a.batch * P <= 2048u && G2 <= 128u;
-        const bool sort2 = sort2_want && P >= 4 && s.sort_tmp.p && G2 <= 1024u &&
-                           (uint64_t)a.batch * G2 * P * 2 + (uint64_t)a.batch * P * (1 + MSM_PART_CHUNKS) <= (uint64_t)total_buckets * msm_G_max_;
+        const uint64_t counts_words = s.counts.bytes / 4;
+        const bool sort2 = sort2_want && P >= 4 && s.sort_tmp.p && G2 <= MSM_PART_GMAX &&
+                           (uint64_t)a.batch * G2 * P * 2 + (uint64_t)a.batch * P * (1 + MSM_PART_CHUNKS) <= counts_words;
+        if (!sort2 && !one_level_ok()) { set_error("msm: a %d-bit window sorts in two levels only, and this batch does not fit them (%u slices, %u partitions)", c_, G2, P); return APK_ERR_STATE; }
         if (sort2) { G = G2; gd = dim3(G, a.batch); }
         path(P_MSM_BATCHES);
         if (sort2) { path(P_SORT2); if (sort2_env < 0 && T.n_bases < 65536u) path(P_SORT2_LOAD); }
@@ -550,7 +554,8 @@ class CurveBackend : public Backend {
             // LDS stage of the first level: a slice's entries (<= slice x W words; slices that do not fit scatter in HBM)
             const uint32_t per_slice = cdiv(maxlen, G);
             uint32_t stage_cap = per_slice * (uint32_t)W_;
-            if (stage_cap > MSM_PART_STAGE) stage_cap = MSM_PART_STAGE;
+            if (stage_cap > part_stage_max()) stage_cap = part_stage_max();
+            const size_t cursors_lds = (size_t)(2 * P + 1) * 4;     // behind the stage in the first level's dynamic LDS
             // tile of the second level: the mean partition + 15 % (uniform scalars stay within 2 %); at 2^17 that is 74 KiB, so two
             // workgroups share a CU and the 384 partitions of a three-MSM batch run in one round instead of two.  Partitions
             // above it (skewed scalars) scatter in HBM.
@@ -563,21 +568,21 @@ class CurveBackend : public Backend {
             // BLS12-381 2^21 (1 024 slices x 1 024 partitions, 32 entries per run, two strided table loads per run) it took
             // 64 ms per 99 launches against the four-launch form's 21 (profiles/r04_kernel_trace_bls12381_2p21.txt, first cut).
             const bool fused = fused_env && !graphs_on /* a replayed capture would reuse one totals buffer */ && stage_cap / P >= 64u &&
-                               (uint64_t)per_slice * W_ <= MSM_PART_STAGE && s.ptot2.p &&
-                               (uint64_t)a.batch * G * (P + 1) <= (uint64_t)total_buckets * msm_G_max_ &&
+                               (uint64_t)per_slice * W_ <= part_stage_max() && s.ptot2.p &&
+                               (uint64_t)a.batch * G * (P + 1) <= counts_words &&
                                (uint64_t)a.batch * G * stage_cap * 4 <= s.sort_tmp.bytes;
             if (fused) {
                 path(P_SORT_FUSED);
                 uint32_t* pt_cur = ptr<uint32_t>(s.ptot2) + (size_t)(s.ptot_parity & 1u) * MSM_MAX_BATCH * MSM_PART_MAX;
                 uint32_t* pt_next = ptr<uint32_t>(s.ptot2) + (size_t)((s.ptot_parity & 1u) ^ 1u) * MSM_MAX_BATCH * MSM_PART_MAX;
                 s.ptot_parity ^= 1u;
-                msm_part1_kernel<FRP><<<gd, dth, (size_t)stage_cap * 4, st>>>(a, win_, pc, T.n_bases, G, ptr<uint32_t>(s.sort_tmp), stage_cap, pcounts, pt_cur);
+                msm_part1_kernel<FRP><<<gd, dth, (size_t)stage_cap * 4 + cursors_lds, st>>>(a, win_, pc, T.n_bases, G, ptr<uint32_t>(s.sort_tmp), stage_cap, pcounts, pt_cur);
                 KCHK();
                 msm_part_sort_runs_kernel<0><<<dim3(P, a.batch), 1024, (size_t)tile_cap * 4, st>>>(
                     ptr<uint32_t>(s.sort_tmp), stage_cap, pcounts, pt_cur, pt_next, pc, G, NB_, ptr<uint32_t>(s.hist), ptr<uint32_t>(s.sorted), tile_cap);
                 KCHK();
             } else {
-            msm_part_kernel<FRP, false><<<gd, dth, 0, st>>>(a, win_, pc, NB_, T.n_bases, G, pcounts, nullptr, nullptr, 0);
+            msm_part_kernel<FRP, false><<<gd, dth, cursors_lds, st>>>(a, win_, pc, NB_, T.n_bases, G, pcounts, nullptr, nullptr, 0);
             KCHK();
             if (small_scan) {
                 msm_part_scan_kernel<0><<<1, 1024, 0, st>>>(pcounts, runstart, ptot, a.batch, G, P);
@@ -597,7 +602,7 @@ class CurveBackend : public Backend {
                 pc1.run_lanes = 8;
                 while (pc1.run_lanes < 64 && pc1.run_lanes < mean_run) pc1.run_lanes <<= 1;
             }
-            msm_part_kernel<FRP, true><<<gd, dth, (size_t)stage_cap * 4, st>>>(a, win_, pc1, NB_, T.n_bases, G, pcounts, runstart, ptr<uint32_t>(s.sort_tmp),
+            msm_part_kernel<FRP, true><<<gd, dth, (size_t)stage_cap * 4 + cursors_lds, st>>>(a, win_, pc1, NB_, T.n_bases, G, pcounts, runstart, ptr<uint32_t>(s.sort_tmp),
                                                                                stage_cap);
             KCHK();
             msm_part_sort_kernel<0><<<dim3(P, a.batch), 1024, (size_t)tile_cap * 4, st>>>(ptr<uint32_t>(s.sort_tmp), runstart, ptot, pc, G, NB_,
@@ -611,7 +616,9 @@ class CurveBackend : public Backend {
         KCHK();
         }
         if (APK_PHASE(32)) {
-            const uint32_t nblk = cdiv(total_buckets, MSM_SCAN_BLOCK);   // <= 1024: total_buckets <= 4 * 2^15... checked at init
+            // `items` consecutive buckets per scan thread keep the block count at MSM_SCAN_MAX_BLOCKS (the totals step's LDS) up to 2^21 buckets
+            const uint32_t items = cdiv(total_buckets, (uint64_t)MSM_SCAN_BLOCK * MSM_SCAN_MAX_BLOCKS);
+            const uint32_t nblk = cdiv(total_buckets, (uint64_t)MSM_SCAN_BLOCK * items);
             uint32_t* blk_tot = ptr<uint32_t>(s.scan_blk);
             uint32_t* blk_bins = blk_tot + 3 * nblk;
             // APK_MSM_SCAN_FUSED=1: two launches - the last workgroup of the local scan runs the totals step.  Built and measured
@@ -623,21 +630,21 @@ class CurveBackend : public Backend {
             if (scan_fused) {
                 msm_scan_local_kernel<1><<<nblk, MSM_SCAN_BLOCK, 0, st>>>(ptr<uint32_t>(s.hist), total_buckets, unit, ptr<uint32_t>(s.offsets),
                                                                            ptr<uint32_t>(s.unit_off), ptr<uint32_t>(s.full_off), ptr<uint32_t>(s.rem_rank),
-                                                                           ptr<uint32_t>(s.merge_rank), blk_tot, blk_bins, nblk, scan_done);
+                                                                           ptr<uint32_t>(s.merge_rank), blk_tot, blk_bins, nblk, scan_done, items);
                 KCHK();
             } else {
                 msm_scan_local_kernel<0><<<nblk, MSM_SCAN_BLOCK, 0, st>>>(ptr<uint32_t>(s.hist), total_buckets, unit, ptr<uint32_t>(s.offsets),
                                                                            ptr<uint32_t>(s.unit_off), ptr<uint32_t>(s.full_off), ptr<uint32_t>(s.rem_rank),
-                                                                           ptr<uint32_t>(s.merge_rank), blk_tot, blk_bins, nblk, scan_done);
+                                                                           ptr<uint32_t>(s.merge_rank), blk_tot, blk_bins, nblk, scan_done, items);
                 KCHK();
                 msm_scan_totals_kernel<0><<<1, MSM_SCAN_BLOCK, 0, st>>>(blk_tot, blk_bins, nblk, total_buckets, ptr<uint32_t>(s.offsets),
                                                                          ptr<uint32_t>(s.unit_off), ptr<uint32_t>(s.full_off));
                 KCHK();
             }
-            msm_scan_apply_kernel<0><<<nblk, MSM_SCAN_BLOCK, 0, st>>>(blk_tot, blk_bins, ptr<uint32_t>(s.hist), ptr<uint32_t>(s.rem_rank),
+            msm_scan_apply_kernel<0><<<cdiv(total_buckets, MSM_SCAN_BLOCK), MSM_SCAN_BLOCK, 0, st>>>(blk_tot, blk_bins, ptr<uint32_t>(s.hist), ptr<uint32_t>(s.rem_rank),
                                                                       ptr<uint32_t>(s.merge_rank), nblk,
                                                                       total_buckets, unit, ptr<uint32_t>(s.offsets), ptr<uint32_t>(s.unit_off),
-                                                                      ptr<uint32_t>(s.full_off), ptr<uint32_t>(s.rem_list), ptr<uint32_t>(s.merge_list));
+                                                                      ptr<uint32_t>(s.full_off), ptr<uint32_t>(s.rem_list), ptr<uint32_t>(s.merge_list), items);
             KCHK();
         }
         if (!sort2 && APK_PHASE(64)) {
@@ -670,7 +677,8 @@ class CurveBackend : public Backend {
         static const int dyn_env = env_int("APK_MSM_COMBINE_DYN", 1, 0, 1);
         const bool dyn_lanes = dyn_env && !lean && APK_PHASE(32);
         if (dyn_lanes) { lanes_log += 2; if ((1u << lanes_log) > MSM_COMBINE_LANES) lanes_log = 4; }
-        const uint32_t* avg_partials = dyn_lanes ? ptr<uint32_t>(s.scan_blk) + (size_t)(3 + MSM_BINS) * cdiv(total_buckets, MSM_SCAN_BLOCK) : nullptr;
+        const uint32_t scan_nblk = cdiv(total_buckets, (uint64_t)MSM_SCAN_BLOCK * cdiv(total_buckets, (uint64_t)MSM_SCAN_BLOCK * MSM_SCAN_MAX_BLOCKS));
+        const uint32_t* avg_partials = dyn_lanes ? ptr<uint32_t>(s.scan_blk) + (size_t)(3 + MSM_BINS) * scan_nblk : nullptr;
         {   // light and heavy merge in one launch (the heavy blocks return at once when no bucket is skewed)
             const uint32_t normal_blocks = cdiv((uint64_t)total_buckets << lanes_log, 256);
             // the buckets in the order of their partial counts (merge_list): a wave's lanes run the same number of additions
@@ -839,7 +847,19 @@ class CurveBackend : public Backend {
         }
         const Pt* g = reinterpret_cast<const Pt*>(reinterpret_cast<const uint8_t*>(s.h_pinned) + 1024);
         Aff* o = reinterpret_cast<Aff*>(s.h_pinned);
-        for (uint32_t i = 0; i < s.pending_pts; i++) o[i] = g[i].to_affine();
+        // the batch's affine conversions share ONE field inversion (Montgomery's trick on the ZZZ coordinates; an inverse is
+        // unique, so the bytes are those of XYZZ::to_affine point by point): 3 of 4 host inversions of ~5 us leave the gap between
+        // a batch's results and the next round's launches
+        Fp pre[MSM_MAX_BATCH], acc = Fp::one();
+        for (uint32_t i = 0; i < s.pending_pts; i++) { pre[i] = acc; if (!g[i].is_inf()) acc = acc * g[i].ZZZ; }
+        Fp inv = s.pending_pts ? Fp::inv(acc) : acc;
+        for (uint32_t i = s.pending_pts; i-- > 0;) {
+            if (g[i].is_inf()) { o[i] = Aff::inf(); continue; }
+            const Fp zzz_inv = inv * pre[i];
+            inv = inv * g[i].ZZZ;
+            const Fp zz_inv = Fp::sqr(zzz_inv * g[i].ZZ);
+            o[i] = Aff{g[i].X * zz_inv, g[i].Y * zzz_inv};
+        }
         s.pending_pts = 0;
         return APK_OK;
     }
@@ -885,11 +905,22 @@ class CurveBackend : public Backend {
         CHK(s.scan_blk.alloc((size_t)(3 + MSM_BINS) * (cdiv(tb, MSM_SCAN_BLOCK) + 1) * 4));
         CHK(s.merge_rank.alloc((size_t)(tb + 1) * 4)); CHK(s.merge_list.alloc((size_t)(tb + 1) * 4));
         CHK(s.full_off.alloc((size_t)(tb + 1) * 4)); CHK(s.rem_rank.alloc((size_t)(tb + 1) * 4)); CHK(s.rem_list.alloc((size_t)(tb + 1) * 4));
-        CHK(s.counts.alloc((size_t)tb * msm_G_max_ * 4));
+        {   // counter arrays: [batch][G][NB] of the one-level sort, or what the two levels keep between their launches
+            // ([batch][G][P] counts + run starts, partition totals and chunk sums; or the fused form's [batch][G][P + 1] run tables)
+            uint32_t sl = part_stage_max() / (uint32_t)W_;       // run_msm_body's slice: APK_MSM_SLICE (2 048) scalars, or what the stage holds
+            const uint32_t sl_env = (uint32_t)env_int("APK_MSM_SLICE", 2048, 64, 1 << 20);
+            if (sl > sl_env) sl = sl_env;
+            if (sl < 1) sl = 1;
+            const uint64_t g2max = (uint64_t)cdiv(msm_bases_, sl) + 1u;
+            const uint64_t g2 = g2max > MSM_PART_GMAX ? MSM_PART_GMAX : g2max;
+            const uint64_t two_level = (uint64_t)batch * g2 * ((uint64_t)part_cfg_.P + 1) * 2 + (uint64_t)batch * part_cfg_.P * (2 + MSM_PART_CHUNKS);
+            const uint64_t one_level = one_level_ok() ? (uint64_t)tb * msm_G_max_ : 0;
+            CHK(s.counts.alloc((size_t)(one_level > two_level ? one_level : two_level) * 4));
+        }
         CHK(s.sorted.alloc(entries * 4));
-        if (env_int("APK_MSM_SORT2", -1, -1, 1) != 0 && part_cfg_.P >= 4 && (msm_bases_ >= 65536u || (many_slots_ && msm_bases_ >= 8192u) || env_int("APK_MSM_SORT2", -1, -1, 1) == 1))
+        if (!one_level_ok() || (env_int("APK_MSM_SORT2", -1, -1, 1) != 0 && part_cfg_.P >= 4 && (msm_bases_ >= 65536u || (many_slots_ && msm_bases_ >= 8192u) || env_int("APK_MSM_SORT2", -1, -1, 1) == 1)))
         {
-            CHK(s.sort_tmp.alloc((entries + (uint64_t)batch * 1024u * (uint64_t)W_ + 4096u) * 4));   // two-level sort: packed entries between the levels (slice-major runs: a few entries of slack per slice)
+            CHK(s.sort_tmp.alloc((entries + (uint64_t)batch * MSM_PART_GMAX * (uint64_t)W_ + 4096u) * 4));   // two-level sort: packed entries between the levels (slice-major runs: a few entries of slack per slice)
             CHK(s.ptot2.alloc((size_t)2 * MSM_MAX_BATCH * MSM_PART_MAX * 4));
             HIPCHK(hipMemset(s.ptot2.p, 0, (size_t)2 * MSM_MAX_BATCH * MSM_PART_MAX * 4));
         }
@@ -950,11 +981,29 @@ class CurveBackend : public Backend {
 
     // LDS of the sort kernels: 32-bit counters, or packed 16-bit pairs from 2^16 buckets (c = 17)
     size_t digits_lds_bytes() const { return NB_ >= MSM_PACKED_NB ? (size_t)NB_ * 2 : (size_t)NB_ * 4; }
+    // windows above 17 bits (2^17..2^19 buckets) have no one-level sort: their histogram does not fit the LDS.  They sort in two
+    // levels only (partitions of <= 256 buckets), whatever the load.
+    bool one_level_ok() const { return NB_ <= 65536u; }
+    // slices of the first level: the stage and its 2 P + 1 cursors share the 160 KiB
+    uint32_t part_stage_max() const { return msm_part_stage_max(part_cfg_.P ? part_cfg_.P : 4u); }
+    int set_sort_lds_limits() {
+        if (one_level_ok() && digits_lds_bytes() > 65536) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)digits_lds_bytes()));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)digits_lds_bytes()));
+        }
+        const int part_lds = (int)(MSM_LDS_WORDS - 63u) * 4;     // stage + cursors (msm_part_stage_max)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, part_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_kernel<FRP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, part_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_sort_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_TILE * 4));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part1_kernel<FRP>), hipFuncAttributeMaxDynamicSharedMemorySize, part_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_sort_runs_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_TILE * 4));
+        return APK_OK;
+    }
 
     int choose_window(int requested, int log_size, int slots = 1) {
         c_ = requested;
         if (c_ == 0) {
-            c_ = env_int("APK_MSM_WINDOW", 0, 0, 17);
+            c_ = env_int("APK_MSM_WINDOW", 0, 0, 20);
             if (c_ != 0 && c_ < 7) c_ = 7;
         }
         // measured flat between log2(n)-4 and log2(n)-2 (tools/sweep.sh).  c = 16 (128 KiB LDS histograms, 16 windows instead of
@@ -969,7 +1018,7 @@ class CurveBackend : public Backend {
             else if (slots > 2 && log_size == 14) c_ = 13;
             else if (slots > 2 && (log_size == 15 || log_size == 16)) c_ = 15;
         }
-        if (c_ < 7 || c_ > 17) { set_error("msm_window %d out of [7,17]", c_); return APK_ERR_ARG; }
+        if (c_ < 7 || c_ > 20) { set_error("msm_window %d out of [7,20]", c_); return APK_ERR_ARG; }
         // c = 17 counts in packed 16-bit halves: a sort slice (at most msm_G_max_ of them) must stay below 2^16 entries
         if (c_ == 17 && (uint64_t)msm_bases_ > (uint64_t)msm_G_max_ * 3072u) { set_error("msm_window 17 supports at most %u bases", msm_G_max_ * 3072u); return APK_ERR_ARG; }
         W_ = (FRP::BITS + 1 + c_ - 1) / c_;
@@ -1007,6 +1056,12 @@ class CurveBackend : public Backend {
                 part_cfg_.idx_bits = idx_bits; part_cfg_.pb_log = (uint32_t)pb_log; part_cfg_.P = NB_ >> pb_log; part_cfg_.run_lanes = 64;
             }
         }
+        if (!one_level_ok()) {
+            // 2^17..2^19 buckets: the two-level sort or nothing - its packed entry needs index bits + partition bits <= 31 and at
+            // most MSM_PART_MAX partitions, and the first level at most MSM_PART_GMAX slices whose entries fit the LDS stage
+            if (part_cfg_.P < 4) { set_error("msm_window %d: %u bases x %d windows leave no room for the partition bits of the two-level sort (index bits + partition bits <= 31, <= %u partitions)", c_, msm_bases_, W_, MSM_PART_MAX); return APK_ERR_ARG; }
+            if ((uint64_t)cdiv(msm_bases_, MSM_PART_GMAX) * W_ > part_stage_max()) { set_error("msm_window %d: %u bases need more than %u sort slices", c_, msm_bases_, MSM_PART_GMAX); return APK_ERR_ARG; }
+        }
         return APK_OK;
     }
 
@@ -1027,14 +1082,7 @@ class CurveBackend : public Backend {
         int lg = 0;
         while ((1ull << lg) < count) lg++;
         CHK(choose_window(msm_window, lg));
-        if (digits_lds_bytes() > 65536) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)digits_lds_bytes()));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)digits_lds_bytes()));
-        }
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_STAGE * 4));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_sort_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_TILE * 4));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part1_kernel<FRP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_STAGE * 4));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_sort_runs_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_TILE * 4));
+        CHK(set_sort_lds_limits());
         DevBuf srs;
         CHK(srs.alloc(count * sizeof(Aff)));
         HIPCHK(hipMemcpy(srs.p, bases, count * sizeof(Aff), hipMemcpyHostToDevice));
@@ -1140,14 +1188,7 @@ class CurveBackend : public Backend {
         }
         HIPCHK(hipDeviceSynchronize());
         srs.release();
-        if (digits_lds_bytes() > 65536) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)digits_lds_bytes()));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)digits_lds_bytes()));
-        }
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_STAGE * 4));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_sort_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_TILE * 4));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part1_kernel<FRP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_STAGE * 4));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_sort_runs_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_TILE * 4));
+        CHK(set_sort_lds_limits());
         // proving slots
         int nslots = d->slots > 0 ? d->slots : 1;
         // more than 16 concurrently active streams collapse the throughput (24: -25 %, 32: -40 %, 48: -55 % at 2^17); callers

@@ -187,6 +187,11 @@ struct apk_comm {
     bool spmd_on = false;           // replicated prover: this communicator's hooks sit on the bound context (apk_comm_spmd_begin)
     bool subcoset_on = false;       // replicated prover: round 3 on sub-cosets (apk_comm_spmd_begin)
     uint64_t steps = 0;
+    std::string why_not_rccl = "not bound";   // apk_comm_transport_reason: what kept the data plane off RCCL ("" when it is RCCL)
+    // where a schedule's time goes (apk_comm_phase_ms): this rank's share of the commitment MSMs, the partial sums' exchange, the
+    // sub-coset all-gather - host wall clock, summed since the last reset
+    double ms_msm = 0, ms_sums = 0, ms_gather = 0;
+    uint64_t n_commit_rounds = 0, n_gathers = 0;
     std::mutex step_mu;             // leader: one step at a time (a context with several slots proves concurrently, and every
                                     // proving thread calls the hooks; the workers serve the steps in the order they are announced)
 
@@ -313,6 +318,11 @@ static int ctl_allgather(apk_comm* c, const void* mine, void* all, size_t n) {
     CHK(send_all(c->peer[0], mine, n));
     return recv_all(c->peer[0], all, n * c->world);
 }
+
+struct WallMs {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 // Whatever this communicator installed on its bound context comes off again - on EVERY rank, for either schedule - before the
 // binding changes or the communicator dies: a hook left behind points at freed memory and the next apk_prove on that context
@@ -498,12 +508,20 @@ static int commit_round(apk_comm* c, int basis, uint32_t count, const uint32_t* 
             at += (size_t)(s.hi - s.lo) * APK_FR_BYTES;
         }
         std::vector<uint8_t> res(segs.size() * nb);
+        const WallMs t_msm;
         status = c->cp.msm_batch(CP_USER(c, msm_batch), basis, (uint32_t)segs.size(), ptrs, offs, ls, res.data());
+        c->ms_msm += t_msm.ms();
         if (status == APK_OK) for (size_t i = 0; i < segs.size(); i++) memcpy(mine.data() + 8 + segs[i].k * nb, res.data() + i * nb, nb);
         else err = apk_last_error();
     }
     memcpy(mine.data(), &status, 4);
-    CHK(sums_allgather(c, mine.data(), all.data(), rec));
+    {
+        const WallMs t_x;
+        const int xrc = sums_allgather(c, mine.data(), all.data(), rec);
+        c->ms_sums += t_x.ms();
+        c->n_commit_rounds++;
+        CHK(xrc);
+    }
     c->step_synced = true;                     // from here on every rank knows how the step ended
     for (int r = 0; r < c->world; r++) {
         int32_t st;
@@ -675,19 +693,26 @@ int apk_comm_bind(apk_comm* c, apk_ctx* ctx) {
     c->ipc = false;
     c->ctx = ctx;
     resolve_compute(c);
-    if (!ctx && !(c->have_user_cp && c->user_cp.msm_batch)) return APK_OK;     // unbound: call before the context is destroyed
+    if (!ctx && !(c->have_user_cp && c->user_cp.msm_batch)) { c->why_not_rccl = "not bound"; return APK_OK; }     // unbound: call before the context is destroyed
     // data plane: RCCL when every rank owns a different GPU; the ranks agree through the control plane
     c->rccl = false;
     int32_t dev = -1;
     if (ctx && !c->device_is_host) dev = ctx->be->device_ordinal();
     int32_t can = (c->world > 1 && dev >= 0 && env_int("APK_COMM_RCCL", 1, 0, 1) && g_rccl.load()) ? 1 : 0;
+    c->why_not_rccl = c->world == 1 ? "single rank" : dev < 0 ? "no device memory behind this rank (host compute table)" :
+                      !env_int("APK_COMM_RCCL", 1, 0, 1) ? "APK_COMM_RCCL=0" : !can ? "librccl.so could not be loaded" : "";
     std::vector<int32_t> devs(c->world), cans(c->world);
     CHK(ctl_allgather(c, &dev, devs.data(), 4));
     CHK(ctl_allgather(c, &can, cans.data(), 4));
     bool all_can = c->world > 1;
     for (int r = 0; r < c->world; r++) {
+        if (!cans[r] && c->why_not_rccl.empty()) { char b[96]; snprintf(b, sizeof b, "rank %d cannot use RCCL", r); c->why_not_rccl = b; }
         all_can = all_can && cans[r];
-        for (int q = 0; q < r; q++) if (devs[q] == devs[r]) all_can = false;   // RCCL refuses two ranks on one device (single node)
+        for (int q = 0; q < r; q++)
+            if (devs[q] == devs[r]) {   // RCCL refuses two ranks on one device (single node)
+                all_can = false;
+                if (c->why_not_rccl.empty()) { char b[96]; snprintf(b, sizeof b, "ranks %d and %d share device %d", q, r, devs[r]); c->why_not_rccl = b; }
+            }
     }
     if (all_can && !c->nccl) {
         // Nothing here may strand a peer: a rank that fails a step still takes part in the agreement that follows it, and one
@@ -724,8 +749,10 @@ int apk_comm_bind(apk_comm* c, apk_ctx* ctx) {
             if (!ok && c->nccl) { (void)g_rccl.CommDestroy(c->nccl); c->nccl = nullptr; }
         }
         all_can = ok != 0;
+        if (!ok && c->why_not_rccl.empty()) c->why_not_rccl = "RCCL bring-up failed on some rank (unique id, stream, ncclCommInitRank or the first all-gather)";
     }
     c->rccl = all_can && c->nccl;
+    if (c->rccl) c->why_not_rccl.clear();
     // HIP IPC when RCCL is not in use and every rank holds device memory: each rank exports its buffer once and the next rank
     // tries to map it - any refusal (no dmabuf IPC, containers without /dev/kfd sharing ...) and ALL ranks fall back to the TCP star
     c->ipc = false;
@@ -770,11 +797,19 @@ int apk_msm_g1_sharded(apk_comm* c, const void* d_scalars, uint64_t len, void* o
     std::string err;
     if (len) {
         const void* p[1] = {d_scalars}; const uint64_t off[1] = {0}, ls[1] = {len};
+        const WallMs t_msm;
         status = c->cp.msm_batch(CP_USER(c, msm_batch), 0, 1, p, off, ls, mine.data() + 8);
+        c->ms_msm += t_msm.ms();
         if (status != APK_OK) err = apk_last_error();
     }
     memcpy(mine.data(), &status, 4);
-    CHK(sums_allgather(c, mine.data(), all.data(), rec));      // the ONE exchange step: a 64/96-byte point per rank (ncclAllGather on RCCL)
+    {
+        const WallMs t_x;
+        const int xrc = sums_allgather(c, mine.data(), all.data(), rec);      // the ONE exchange step: a 64/96-byte point per rank (ncclAllGather on RCCL)
+        c->ms_sums += t_x.ms();
+        c->n_commit_rounds++;
+        CHK(xrc);
+    }
     std::vector<uint8_t> pts((size_t)c->world * nb);
     for (int r = 0; r < c->world; r++) {
         int32_t st;
@@ -825,9 +860,17 @@ int apk_comm_split_begin(apk_comm* c) {
 }
 
 // In-place all-gather of device memory: rank r's part sits at d_all + r * bytes on every rank when the call returns.
+static int allgather_device_impl(apk_comm* c, void* d_all, size_t bytes);
 int apk_comm_allgather_device(apk_comm* c, void* d_all, size_t bytes) {
     if (!c || !d_all) { set_error("comm: allgather_device: null argument"); return APK_ERR_ARG; }
     if (c->world == 1 || bytes == 0) return APK_OK;
+    const WallMs t;
+    const int rc = allgather_device_impl(c, d_all, bytes);
+    c->ms_gather += t.ms();
+    c->n_gathers++;
+    return rc;
+}
+static int allgather_device_impl(apk_comm* c, void* d_all, size_t bytes) {
     uint8_t* all = (uint8_t*)d_all;
     uint8_t* mine = all + (size_t)c->rank * bytes;
     if (c->rccl) {
@@ -940,6 +983,64 @@ int apk_comm_serve(apk_comm* c, uint64_t* steps_served) {
     }
     if (steps_served) *steps_served = c->steps;
     return APK_OK;
+}
+
+const char* apk_comm_transport_reason(const apk_comm* c) { return c ? c->why_not_rccl.c_str() : "null communicator"; }
+
+int apk_comm_phase_ms(apk_comm* c, double* out, int reset) {
+    if (!c || !out) { set_error("comm: phase_ms: null argument"); return APK_ERR_ARG; }
+    out[0] = c->ms_msm; out[1] = c->ms_sums; out[2] = c->ms_gather; out[3] = (double)c->n_commit_rounds; out[4] = (double)c->n_gathers;
+    if (reset) { c->ms_msm = c->ms_sums = c->ms_gather = 0; c->n_commit_rounds = c->n_gathers = 0; }
+    return APK_OK;
+}
+
+// One timed pass over the data plane as it came up (collective; after apk_comm_bind on a device context): a ring of ncclSend /
+// ncclRecv of `ring_bytes` (every rank sends to its right neighbour and receives from its left one, all links at once - RCCL
+// plane only, 0 elsewhere) and an in-place all-gather of `gather_bytes` per rank on whatever plane is active (ncclAllGather,
+// IPC pulls or the TCP star).  GB/s per rank = bytes this rank RECEIVED / wall time, the second of two passes (the first warms
+// the connections up).  The first multi-GPU run of this library reads its link rate from here (bench.py config.data_plane).
+int apk_comm_link_probe(apk_comm* c, size_t ring_bytes, size_t gather_bytes, double* ring_gbps, double* gather_gbps) {
+    if (!c || !ring_gbps || !gather_gbps) { set_error("comm: link_probe: null argument"); return APK_ERR_ARG; }
+    *ring_gbps = 0; *gather_gbps = 0;
+    if (c->world == 1 || !c->cp.alloc || c->device_is_host) return APK_OK;
+    const size_t need = (ring_bytes * 2 > gather_bytes * (size_t)c->world ? ring_bytes * 2 : gather_bytes * (size_t)c->world) + 256;
+    void* d = nullptr;
+    int32_t ok = c->cp.alloc(CP_USER(c, alloc), need, &d) == APK_OK ? 1 : 0;
+    std::vector<int32_t> oks(c->world);
+    CHK(ctl_allgather(c, &ok, oks.data(), 4));
+    for (int32_t v : oks) ok = ok && v;
+    int rc = APK_OK;
+    if (ok) {
+        if (c->rccl && ring_bytes) {
+            const int right = (c->rank + 1) % c->world, left = (c->rank + c->world - 1) % c->world;
+            for (int pass = 0; pass < 2 && rc == APK_OK; pass++) {
+                rc = ctl_allgather(c, &ok, oks.data(), 4);            // start together
+                const WallMs t;
+                if (rc == APK_OK && hipSetDevice(c->device) != hipSuccess) rc = APK_ERR_HIP;
+                if (rc == APK_OK) {
+                    ncclResult_t r = g_rccl.GroupStart();
+                    if (r == ncclSuccess) r = g_rccl.Send(d, ring_bytes, ncclUint8, right, c->nccl, c->stream);
+                    if (r == ncclSuccess) r = g_rccl.Recv((uint8_t*)d + ring_bytes, ring_bytes, ncclUint8, left, c->nccl, c->stream);
+                    const ncclResult_t e = g_rccl.GroupEnd();
+                    if (r != ncclSuccess || e != ncclSuccess) { set_error("comm: link probe: RCCL ring failed"); rc = APK_ERR_HIP; }
+                    else rc = stream_wait(c, "the link probe's ring");
+                }
+                if (pass == 1 && rc == APK_OK) *ring_gbps = (double)ring_bytes / (t.ms() * 1e6);
+            }
+        }
+        if (gather_bytes && rc == APK_OK)
+            for (int pass = 0; pass < 2 && rc == APK_OK; pass++) {
+                rc = ctl_allgather(c, &ok, oks.data(), 4);
+                const WallMs t;
+                if (rc == APK_OK) rc = allgather_device_impl(c, d, gather_bytes);
+                if (pass == 1 && rc == APK_OK) *gather_gbps = (double)gather_bytes * (c->world - 1) / (t.ms() * 1e6);
+            }
+    } else {
+        set_error("comm: link probe: a rank could not allocate its buffer");
+        rc = APK_ERR_HIP;
+    }
+    if (d) (void)c->cp.release(CP_USER(c, release), d);
+    return rc;
 }
 
 int apk_comm_rccl_ranks(const apk_comm* c) {

@@ -198,9 +198,15 @@ __global__ void __launch_bounds__(256) msm_colscan_kernel(uint32_t* __restrict__
 // bit 31 the sign.  Round 3 fixed idx_bits = 22 and pb_log = 8 (2^17 bases at 16 windows); round 4 picks them per context
 // (MsmPartCfg): the index takes the bits it needs (26 for BLS12-381 2^21 x 16 windows - BASELINE configs[4]) and the partition
 // count grows until a partition's entries fit the second level's LDS tile (2 048 partitions of 16 buckets there).
-constexpr uint32_t MSM_PART_MAX = 2048;     // partitions per MSM
+constexpr uint32_t MSM_PART_MAX = 4096;     // partitions per MSM (round 5: 2 048 -> 4 096 for the windows above 17 bits: 2^18 buckets in partitions of 64)
+constexpr uint32_t MSM_PART_GMAX = 2048;    // slices per MSM in the first level
+constexpr uint32_t MSM_LDS_WORDS = 40960;   // 160 KiB of LDS per workgroup
 constexpr uint32_t MSM_PART_TILE = 36864;   // most entries of a partition sorted in LDS (144 KiB); larger (skewed) partitions scatter in HBM
-constexpr uint32_t MSM_PART_STAGE = 35584;  // most entries of a slice staged in LDS by the first level (139 KiB beside its 20 KiB of cursors)
+constexpr uint32_t MSM_PART_STAGE = 35584;  // most entries of a slice staged in LDS by the first level (139 KiB) beside its cursors:
+// the stage and the two cursor arrays (2 P + 1 words) share the kernel's dynamic LDS - msm_part_stage_max(P) entries fit
+__host__ __device__ constexpr uint32_t msm_part_stage_max(uint32_t P) {
+    return MSM_LDS_WORDS - 2u * P - 1u - 63u < MSM_PART_STAGE ? MSM_LDS_WORDS - 2u * P - 1u - 63u : MSM_PART_STAGE;
+}
 constexpr uint32_t MSM_PART_COUNTERS = 1024; // second level: counters per workgroup (wave-private sets while 2^pb_log <= 64)
 struct MsmPartCfg {
     uint32_t idx_bits, pb_log;   // idx_bits + pb_log <= 31
@@ -216,9 +222,11 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part_kernel(MsmBatchAr
                                                                      uint32_t stage_cap) {                   // SCATTER: entries the LDS stage holds
     wave_priority<APK_PRIO_SORT>();
     using Fr = Fe<FR>;
-    __shared__ uint32_t cur[MSM_PART_MAX], lstart[MSM_PART_MAX + 1];
+    // dynamic LDS: [stage: stage_cap words (0 in the count pass)][cur: P][lstart: P + 1]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t* stage = reinterpret_cast<uint32_t*>(smem_raw);
+    uint32_t* cur = stage + (SCATTER ? stage_cap : 0u);
+    uint32_t* lstart = cur + pc.P;
     const uint32_t g = blockIdx.x, b = blockIdx.y;
     const uint32_t P = pc.P, pb_log = pc.pb_log, pb_mask = (1u << pc.pb_log) - 1u;
     const size_t row = ((size_t)b * G + g) * P;
@@ -573,9 +581,11 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part1_kernel(MsmBatchA
                                                                       uint32_t* __restrict__ ptot) {                   // [batch][P], zero on entry
     wave_priority<APK_PRIO_SORT>();
     using Fr = Fe<FR>;
-    __shared__ uint32_t cur[MSM_PART_MAX], lstart[MSM_PART_MAX + 1];
+    // dynamic LDS: [stage: cap words][cur: P][lstart: P + 1]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t* stage = reinterpret_cast<uint32_t*>(smem_raw);
+    uint32_t* cur = stage + cap;
+    uint32_t* lstart = cur + pc.P;
     const uint32_t g = blockIdx.x, b = blockIdx.y;
     const uint32_t P = pc.P, pb_log = pc.pb_log, pb_mask = (1u << pc.pb_log) - 1u;
     for (uint32_t k = threadIdx.x; k < P; k += blockDim.x) cur[k] = 0u;
@@ -803,6 +813,7 @@ __global__ void __launch_bounds__(1024) msm_part_sort_runs_kernel(const uint32_t
 // scans the totals -> blocks add their base.
 constexpr int MSM_SCAN_BLOCK = 1024;
 constexpr int MSM_SCAN_MAX_BLOCKS = 256;   // MSM_MAX_BATCH * 2^16 buckets / MSM_SCAN_BLOCK
+constexpr int MSM_SCAN_ITEMS_MAX = 8;      // consecutive buckets per thread of the local scan: 256 blocks x 1024 x 8 = 2^21 = MSM_MAX_BATCH * 2^19 buckets (c = 20)
 // The same counting sort orders ALL buckets by their number of unit partials (merge_list, most partials first; counts from
 // MSM_MERGE_BINS - 1 up share the last bin): msm_combine_kernel walks the buckets in that order, so the lanes of a wave merge the
 // same number of partials.  In bucket order a wave waited for its bucket with the most partials (3..6 at c = 16: 73 % lane
@@ -868,19 +879,27 @@ __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_local_kernel(const ui
                                                                          uint32_t* __restrict__ merge_rank,
                                                                          uint32_t* __restrict__ block_tot /* [3][nblocks] */,
                                                                          uint32_t* __restrict__ block_bins /* [nblocks][MSM_BINS] */, uint32_t nblocks,
-                                                                         uint32_t* __restrict__ done) {
+                                                                         uint32_t* __restrict__ done, uint32_t items /* 1..MSM_SCAN_ITEMS_MAX */) {
     wave_priority<APK_PRIO_SORT>();
     __shared__ uint32_t s_cnt[MSM_SCAN_BLOCK];
     __shared__ uint32_t s_unit[MSM_SCAN_BLOCK];
     __shared__ uint32_t s_full[MSM_SCAN_BLOCK];
     __shared__ uint32_t s_bins[MSM_BINS];
-    const uint32_t t = threadIdx.x, i = blockIdx.x * MSM_SCAN_BLOCK + t;
+    const uint32_t t = threadIdx.x, i0 = (blockIdx.x * MSM_SCAN_BLOCK + t) * items;   // this thread's `items` consecutive buckets
     if (t < MSM_BINS) s_bins[t] = 0;
     __syncthreads();
-    const uint32_t h = i < total ? hist[i] : 0u, hf = h / unit, rem = h - hf * unit, hu = hf + (rem ? 1u : 0u);
-    if (rem) rem_rank[i] = atomicAdd(&s_bins[rem], 1u);   // rank of this bucket among the block's buckets with the same remainder
-    if (i < total) merge_rank[i] = atomicAdd(&s_bins[MSM_UNIT_MAX + min(hu, (uint32_t)MSM_MERGE_BINS - 1u)], 1u);   // ... with the same number of partials
-    s_cnt[t] = h; s_unit[t] = hu; s_full[t] = hf;
+    uint32_t hv[MSM_SCAN_ITEMS_MAX], sh = 0, su = 0, sf = 0;
+#pragma unroll
+    for (int it = 0; it < MSM_SCAN_ITEMS_MAX; it++) {
+        const uint32_t i = i0 + (uint32_t)it;
+        const bool in = (uint32_t)it < items && i < total;
+        const uint32_t h = in ? hist[i] : 0u, hf = h / unit, rem = h - hf * unit, hu = hf + (rem ? 1u : 0u);
+        hv[it] = h;
+        if (rem) rem_rank[i] = atomicAdd(&s_bins[rem], 1u);   // rank of this bucket among the block's buckets with the same remainder
+        if (in) merge_rank[i] = atomicAdd(&s_bins[MSM_UNIT_MAX + min(hu, (uint32_t)MSM_MERGE_BINS - 1u)], 1u);   // ... with the same number of partials
+        sh += h; su += hu; sf += hf;
+    }
+    s_cnt[t] = sh; s_unit[t] = su; s_full[t] = sf;
     __syncthreads();
     for (uint32_t d = 1; d < MSM_SCAN_BLOCK; d <<= 1) {
         uint32_t vc = 0, vu = 0, vf = 0;
@@ -889,7 +908,18 @@ __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_local_kernel(const ui
         s_cnt[t] += vc; s_unit[t] += vu; s_full[t] += vf;
         __syncthreads();
     }
-    if (i < total) { offsets[i] = s_cnt[t] - h; unit_off[i] = s_unit[t] - hu; full_off[i] = s_full[t] - hf; }   // exclusive, block-local
+    {   // exclusive, block-local: the thread's base, then its buckets one after the other
+        uint32_t ro = s_cnt[t] - sh, ru = s_unit[t] - su, rf = s_full[t] - sf;
+#pragma unroll
+        for (int it = 0; it < MSM_SCAN_ITEMS_MAX; it++) {
+            const uint32_t i = i0 + (uint32_t)it;
+            if ((uint32_t)it < items && i < total) {
+                const uint32_t h = hv[it], hf = h / unit, hu = hf + (h - hf * unit ? 1u : 0u);
+                offsets[i] = ro; unit_off[i] = ru; full_off[i] = rf;
+                ro += h; ru += hu; rf += hf;
+            }
+        }
+    }
     if (t == MSM_SCAN_BLOCK - 1) {
         block_tot[blockIdx.x] = s_cnt[t]; block_tot[nblocks + blockIdx.x] = s_unit[t]; block_tot[2 * nblocks + blockIdx.x] = s_full[t];
     }
@@ -930,16 +960,17 @@ __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_apply_kernel(const ui
                                                                          uint32_t nblocks, uint32_t total, uint32_t unit,
                                                                          uint32_t* __restrict__ offsets, uint32_t* __restrict__ unit_off,
                                                                          uint32_t* __restrict__ full_off, uint32_t* __restrict__ rem_list,
-                                                                         uint32_t* __restrict__ merge_list) {
+                                                                         uint32_t* __restrict__ merge_list, uint32_t items) {
     wave_priority<APK_PRIO_SORT>();
-    const uint32_t i = blockIdx.x * MSM_SCAN_BLOCK + threadIdx.x;
+    const uint32_t i = blockIdx.x * MSM_SCAN_BLOCK + threadIdx.x;     // one bucket per thread here; its scan block held `items` per thread
     if (i >= total) return;
-    offsets[i] += block_tot[blockIdx.x];
-    unit_off[i] += block_tot[nblocks + blockIdx.x];
-    full_off[i] += block_tot[2 * nblocks + blockIdx.x];
+    const uint32_t blk = i / (MSM_SCAN_BLOCK * items);
+    offsets[i] += block_tot[blk];
+    unit_off[i] += block_tot[nblocks + blk];
+    full_off[i] += block_tot[2 * nblocks + blk];
     const uint32_t h = hist[i], hf = h / unit, rem = h - hf * unit, hu = hf + (rem ? 1u : 0u);
-    if (rem) rem_list[block_bins[blockIdx.x * MSM_BINS + rem] + rem_rank[i]] = i;
-    merge_list[block_bins[blockIdx.x * MSM_BINS + MSM_UNIT_MAX + min(hu, (uint32_t)MSM_MERGE_BINS - 1u)] + merge_rank[i]] = i;
+    if (rem) rem_list[block_bins[blk * MSM_BINS + rem] + rem_rank[i]] = i;
+    merge_list[block_bins[blk * MSM_BINS + MSM_UNIT_MAX + min(hu, (uint32_t)MSM_MERGE_BINS - 1u)] + merge_rank[i]] = i;
 }
 
 // ---- bucket accumulation: one lane per work unit ---------------------------------------------------------

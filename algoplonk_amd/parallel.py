@@ -164,6 +164,24 @@ class Comm:
         """ncclCommCount of the data plane's RCCL communicator (0 unless the transport is "rccl")."""
         return lib.apk_comm_rccl_ranks(self._c)
 
+    @property
+    def transport_reason(self) -> str:
+        """Why the data plane is not RCCL ("" when it is): apk_comm_transport_reason."""
+        return lib.apk_comm_transport_reason(self._c).decode()
+
+    def link_probe(self, ring_bytes: int = 64 << 20, gather_bytes: int = 32 << 20) -> dict:
+        """One timed ring of ncclSend / ncclRecv and one all-gather over the data plane as it came up (apk_comm_link_probe,
+        collective): what the first run on a multi-GPU node reads its link rate from."""
+        ring, gather = C.c_double(0), C.c_double(0)
+        check(lib.apk_comm_link_probe(self._c, ring_bytes, gather_bytes, C.byref(ring), C.byref(gather)))
+        return {"ring_send_recv_gbps": round(ring.value, 2), "ring_bytes": ring_bytes, "allgather_gbps_received": round(gather.value, 2),
+                "allgather_bytes_per_rank": gather_bytes}
+
+    def phase_ms(self, reset: bool = False) -> dict:
+        out = (C.c_double * 5)()
+        check(lib.apk_comm_phase_ms(self._c, out, int(reset)))
+        return {"msm_ms": out[0], "sums_exchange_ms": out[1], "subcoset_gather_ms": out[2], "commit_rounds": int(out[3]), "gathers": int(out[4])}
+
     def barrier(self) -> None:
         check(lib.apk_comm_barrier(self._c))
 

@@ -195,7 +195,7 @@ class Ranks:
         def go():
             try:
                 self.comm.bind(ctx)
-                res["transport"], res["rccl_ranks"] = self.comm.transport, self.comm.rccl_ranks
+                res.update(self.plane_report())
                 self.comm.bind(None)
             except Exception as e:  # reported, never fatal for a line that is already measured
                 res["transport"], res["rccl_ranks"], res["error"] = "unavailable", 0, str(e)[:200]
@@ -209,6 +209,22 @@ class Ranks:
         return res
 
     hung = False
+
+    def plane_report(self) -> dict:
+        """What the data plane came up as, measured (collective: every rank calls it after apk_comm_bind).  RCCL on every rank ->
+        "rccl"; anything else is reported as "fallback:<transport>:<why>" so that a line timed over the TCP star or IPC cannot be
+        mistaken for an xGMI measurement.  link_gbps: one timed 64 MiB ncclSend/ncclRecv ring + one 32 MiB-per-rank all-gather
+        (apk_comm_link_probe) - the per-link rate DESIGN.md's multi-GPU projections assume (48 GB/s) and no box of the build could
+        measure."""
+        t, n = self.comm.transport, self.comm.rccl_ranks
+        rep = {"transport": t if (t == "rccl" and n == self.world) else "fallback:%s:%s" % (t, self.comm.transport_reason or "?"),
+               "rccl_ranks": n}
+        if self.world > 1:
+            try:
+                rep["link_gbps"] = self.comm.link_probe()
+            except Exception as e:
+                rep["link_gbps"] = {"error": str(e)[:160]}
+        return rep
 
     def close(self):
         if self.hung:
@@ -363,6 +379,7 @@ def bench_prove_spmd(args, cv, rk) -> None:
     srs = setup.unsafe_srs(cv, n, wl.tau, device=rk.local_rank)
     pk, vk = plonk.Setup(wl.ccs, srs, device=rk.local_rank, msm_window=args.msm_window, slots=1)
     rk.comm.bind(pk.ctx)
+    plane = rk.plane_report()
     L, R, O = frontend.wire_columns(wl.ccs, wl.solution)
     dptr = []
     for v in (L, R, O):
@@ -380,9 +397,20 @@ def bench_prove_spmd(args, cv, rk) -> None:
     step()                                    # single-GPU reference proof (no hook) for the byte comparison
     want = MarshalProof(plonk.Proof(cv, proof))
     rk.comm.spmd_begin()
-    elapsed = rk.timed(step, args.steps, args.warmup)
+    for _ in range(args.warmup):
+        step()
+    rk.comm.phase_ms(reset=True)
+    elapsed = rk.timed(step, args.steps, 0)
+    ph = rk.comm.phase_ms(reset=True)
     got = MarshalProof(plonk.Proof(cv, proof))
     rk.comm.spmd_end()
+    # this rank's time per proof by phase (host wall clock): its share of the commitment MSMs, the exchanges, everything else
+    # (transforms, quotient, grand product, openings, transcript) - to be read against DESIGN.md section 6's projection
+    per = 1.0 / max(args.steps, 1)
+    phases = {"msm_ms": round(ph["msm_ms"] * per, 3), "sums_exchange_ms": round(ph["sums_exchange_ms"] * per, 3),
+              "subcoset_gather_ms": round(ph["subcoset_gather_ms"] * per, 3),
+              "non_msm_ms": round(elapsed * 1e3 * per - (ph["msm_ms"] + ph["sums_exchange_ms"] + ph["subcoset_gather_ms"]) * per, 3),
+              "commit_rounds_per_proof": round(ph["commit_rounds"] * per, 2), "subcoset_split": bool(ph["gathers"])}
     same = 1.0 if got == want else 0.0
     same = -rk.comm.max(-same)                # every rank must hold the single-GPU proof
     if rk.rank == 0:
@@ -393,7 +421,8 @@ def bench_prove_spmd(args, cv, rk) -> None:
             "config": {"workload": wl.name + ", one proof at a time", "log_n": args.log_n, "curve": cv.name,
                        "parallelism": "replicated prover x%d: commitments by index range from every rank's own polynomials (all-gather of partial sums), nothing scattered" % rk.world,
                        "world_size": rk.world, "backend": "libapk comm: tcp control plane, %s data plane" % rk.comm.transport,
-                       "rccl_ranks": rk.comm.rccl_ranks},
+                       "rccl_ranks": rk.comm.rccl_ranks, "data_plane": plane},
+            "phase_ms_per_proof_rank0": phases,
             "proof_sha256_prefix": hashlib.sha256(got).hexdigest()[:16], "matches_single_gpu_proof": same == 1.0}), flush=True)
     rk.comm.bind(None)
     pk.close()
@@ -414,6 +443,7 @@ def bench_prove_split(args, cv, rk) -> None:
     srs = setup.unsafe_srs(cv, n, wl.tau, device=rk.local_rank)
     pk, vk = plonk.Setup(wl.ccs, srs, device=rk.local_rank, msm_window=args.msm_window, slots=1)
     rk.comm.bind(pk.ctx)
+    plane = rk.plane_report()
     line = None
     if rk.rank == 0:
         L, R, O = frontend.wire_columns(wl.ccs, wl.solution)
@@ -449,7 +479,7 @@ def bench_prove_split(args, cv, rk) -> None:
                        "parallelism": "commitment batches dealt by index range x%d (scatter + all-gather of partial sums)%s, transcript on rank 0"
                                       % (rk.world, ", wires dealt by polynomial" if os.environ.get("APK_SPLIT_WIRES") == "1" else ""),
                        "world_size": rk.world, "backend": "libapk comm: tcp control plane, %s data plane" % rk.comm.transport,
-                       "rccl_ranks": rk.comm.rccl_ranks},
+                       "rccl_ranks": rk.comm.rccl_ranks, "data_plane": plane},
             "proof_sha256_prefix": hashlib.sha256(got).hexdigest()[:16], "matches_single_gpu_proof": got == want,
         }
     else:
@@ -776,6 +806,7 @@ def bench_sharded_msm(args, cv, rk) -> None:
     bases = srs.g1[: n * 2 * cv.fp_bytes]
     sm = parallel.ShardedMsm(cv, bases, device=rk.local_rank, comm=rk.comm, msm_window=args.msm_window)
     sm.upload(scalars)                            # this rank's slice of the scalars resident in HBM
+    plane = rk.plane_report()
     d = sm._d
     out = C.create_string_buffer(2 * cv.fp_bytes)
     res = [b""]
@@ -811,7 +842,7 @@ def bench_sharded_msm(args, cv, rk) -> None:
             "data": "synthetic", "config": {"workload": "%s single MSM 2^%d sharded by index range" % (cv.name, args.log_n),
                                             "parallelism": "index-range x%d + all-gather of %d-byte points" % (rk.world, 2 * cv.fp_bytes),
                                             "world_size": rk.world, "backend": ("libapk comm: tcp control plane, %s data plane" % rk.comm.transport) if rk.world > 1 else "single process",
-                                            "rccl_ranks": rk.comm.rccl_ranks},
+                                            "rccl_ranks": rk.comm.rccl_ranks, "data_plane": plane},
             "result_sha256_prefix": hashlib.sha256(res[0]).hexdigest()[:16],
             "roofline": roofline_from_stats(args, cv, st, pmc, valu_issue_rate() if pmc else None), "cpu_baseline": cpu_baseline}), flush=True)
     rk.close()

@@ -90,7 +90,8 @@ typedef struct {
     const int64_t* perm;       /* 3n entries = gnark Trace.S */
     const void* qcp[APK_MAX_COMMITMENTS];               /* n Fr each */
     uint32_t commitment_constraint_index[APK_MAX_COMMITMENTS]; /* VK CommitmentConstraintIndexes */
-    int msm_window;            /* signed-digit window bits (7..17); 0 = choose from n and slots */
+    int msm_window;            /* signed-digit window bits (7..20; 18..20 = 2^17..2^19 buckets, two-level sort only: needs
+                                * bases x windows < 2^(31 - partition bits)); 0 = choose from n and slots */
     int slots;                 /* concurrent proofs in flight on this context; 0 = 1; capped at 16 (more callers wait their turn) */
 } apk_circuit_desc;
 
@@ -228,6 +229,18 @@ int apk_comm_bind(apk_comm* comm, apk_ctx* ctx);
 const char* apk_comm_transport(const apk_comm* comm);      /* "rccl", "ipc" or "tcp" (after apk_comm_bind) */
 /* Size of the RCCL communicator behind the data plane (ncclCommCount): `world` when the transport is "rccl", 0 otherwise. */
 int apk_comm_rccl_ranks(const apk_comm* comm);
+/* Why the data plane is NOT RCCL after apk_comm_bind ("" when it is): "single rank", "APK_COMM_RCCL=0", "librccl.so could not be
+ * loaded", "ranks q and r share device d", "RCCL bring-up failed ..." - bench.py prints it as "fallback:<why>" instead of silently
+ * timing the TCP star. */
+const char* apk_comm_transport_reason(const apk_comm* comm);
+/* One timed pass over the data plane as it came up (collective, after apk_comm_bind on a device context): a ring of grouped
+ * ncclSend / ncclRecv of ring_bytes (RCCL plane only; 0 elsewhere) and an in-place all-gather of gather_bytes per rank on the active
+ * plane.  GB/s = bytes this rank received / wall time of the second of two passes.  This is how the first run on a multi-GPU node
+ * reports its per-link rate (DESIGN.md section 6 prices its projections at 48 GB/s per xGMI link, unmeasured). */
+int apk_comm_link_probe(apk_comm* comm, size_t ring_bytes, size_t gather_bytes, double* ring_gbps, double* gather_gbps);
+/* Where a schedule's time went on this rank since the last reset, host wall clock: out[0] = this rank's commitment MSMs (ms),
+ * out[1] = the partial sums' exchange, out[2] = the sub-coset all-gather, out[3] = commitment rounds, out[4] = gathers. */
+int apk_comm_phase_ms(apk_comm* comm, double* out5, int reset);
 /* A world-1 RCCL communicator on `device` driven through every RCCL call of the data plane (unique id, ncclCommInitRank, a grouped
  * ncclSend / ncclRecv to itself on a non-blocking stream, ncclAllGather, ncclCommCount, ncclCommDestroy), results checked byte for
  * byte.  One-GPU boxes cannot run two RCCL ranks (RCCL refuses two ranks per device): this is how that branch's init, stream

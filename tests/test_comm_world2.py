@@ -147,6 +147,13 @@ def _split_worker(rank, world, port, q):
         C.memmove(C.addressof(buf2) + rank * 4096, bytes([(rank * 31 + i) & 0xFF for i in range(4096)]), 4096)
         comm.allgather_device(C.addressof(buf2), 4096)
         assert buf2.raw == b"".join(bytes([(r * 31 + i) & 0xFF for i in range(4096)]) for r in range(world)), "allgather_device"
+        # round 5: a schedule says where its time went and why its data plane is not RCCL - on every rank
+        ph = comm.phase_ms(reset=True)
+        assert ph["commit_rounds"] >= 3 and ph["msm_ms"] > 0 and ph["sums_exchange_ms"] > 0 and ph["gathers"] == 1, ph
+        assert comm.phase_ms()["commit_rounds"] == 0
+        assert comm.transport == "tcp" and "host compute table" in comm.transport_reason, comm.transport_reason
+        probe = comm.link_probe(1 << 16, 1 << 16)                 # no device memory on this tier: nothing to time
+        assert probe["ring_send_recv_gbps"] == 0.0 and probe["allgather_gbps_received"] == 0.0, probe
         comm.close()
         # a rank that fails its share fails the step on EVERY rank, with its rank named
         comm = parallel.Comm(rank, world, "127.0.0.1", port + 1)

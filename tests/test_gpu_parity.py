@@ -155,7 +155,8 @@ def test_unsatisfied_witness_is_an_error_not_a_proof(gpu, cname, monkeypatch):
     pk.close()
 
 
-@pytest.mark.parametrize("cname,window", [("bn254", 7), ("bn254", 9), ("bn254", 12), ("bn254", 16), ("bn254", 17), ("bls12-381", 8), ("bls12-381", 13), ("bls12-381", 17)])
+@pytest.mark.parametrize("cname,window", [("bn254", 7), ("bn254", 9), ("bn254", 12), ("bn254", 16), ("bn254", 17), ("bn254", 18), ("bn254", 20),
+                                          ("bls12-381", 8), ("bls12-381", 13), ("bls12-381", 17), ("bls12-381", 19), ("bls12-381", 20)])
 def test_msm_window_sizes_and_skewed_scalars(gpu, cname, window):
     """Every window width gives the same group element; skewed inputs (all ones, two distinct values, tiny values)
     stress the bucket work-unit split (full units, sorted remainder units, heavy buckets)."""
