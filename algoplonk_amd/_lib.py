@@ -35,7 +35,7 @@ SYMBOLS = [
     "apk_comm_transport", "apk_msm_g1_sharded", "apk_comm_split_begin", "apk_comm_split_end", "apk_comm_serve", "apk_comm_set_compute",
     "apk_comm_commit", "apk_comm_wires", "apk_comm_rccl_ranks", "apk_comm_rccl_selftest",
     "apk_comm_commit_local", "apk_comm_spmd_begin", "apk_comm_spmd_end", "apk_comm_allgather_device", "apk_comm_subcoset_active",
-    "apk_ctx_set_subcoset", "apk_comm_transport_reason", "apk_comm_link_probe", "apk_comm_phase_ms",
+    "apk_ctx_set_subcoset", "apk_comm_transport_reason", "apk_comm_link_probe", "apk_comm_phase_ms", "apk_ctx_msm_window",
 ]
 
 
@@ -178,6 +178,7 @@ def _load() -> C.CDLL:
     lib.apk_stats_enable.argtypes = [vp, i32]
     lib.apk_stats_read.argtypes = [vp, C.POINTER(Stats), i32]
     lib.apk_paths_read.argtypes = [vp, C.POINTER(PathCounts), i32]
+    lib.apk_ctx_msm_window.argtypes = [vp]
     lib.apk_ctx_set_wire_hook.argtypes = [vp, WIRE_HOOK, vp]
     lib.apk_coset_ntt_device.argtypes = [vp, vp, u64, vp]
     lib.apk_comm_create.argtypes = [i32, i32, C.c_char_p, i32, C.POINTER(vp)]

@@ -369,6 +369,7 @@ int apk_device_upload(apk_ctx* ctx, void* d, const void* s, size_t b) { NEED_CTX
 int apk_device_download(apk_ctx* ctx, void* d, const void* s, size_t b) { NEED_CTX(); return ctx->be->dev_download(d, s, b); }
 int apk_stats_enable(apk_ctx* ctx, int en) { NEED_CTX(); return ctx->be->stats_enable(en); }
 int apk_stats_read(apk_ctx* ctx, apk_stats* out, int reset) { NEED_CTX(); if (!out) { set_error("null out"); return APK_ERR_ARG; } return ctx->be->stats_read(out, reset); }
+int apk_ctx_msm_window(apk_ctx* ctx) { if (!ctx || !ctx->be) return 0; return ctx->be->msm_window(); }
 int apk_paths_read(apk_ctx* ctx, apk_path_counts* out, int reset) { NEED_CTX(); if (!out) { set_error("null out"); return APK_ERR_ARG; } return ctx->be->paths_read(out, reset); }
 
 int apk_g1_mul_batch(int curve, int device, const void* base, const void* scalars, uint64_t count, void* out) {

@@ -27,6 +27,7 @@ struct Backend {
     virtual int set_wire_hook(apk_wire_hook fn, void* user) = 0;
     virtual int set_subcoset(int k, int G, apk_gather_hook fn, void* user) = 0;
     virtual int device_ordinal() = 0;
+    virtual int msm_window() = 0;         // the signed-digit window width the context's tables were built for
     virtual uint64_t domain_size() = 0;   // n; 0 on an MSM-only context
     virtual int coset_ntt_dev(const void* d_in, uint64_t len, void* d_out) = 0;
     virtual int ntt(int which, int inverse, int coset, void* data) = 0;

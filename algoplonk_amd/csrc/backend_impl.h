@@ -25,6 +25,7 @@
 #include "kernels_poly.h"
 #include "kernels_setup.h"
 #include "host_msm.h"
+#include "slot_gate.h"
 #include "sha256.h"
 
 namespace apk {
@@ -134,7 +135,7 @@ class CurveBackend : public Backend {
     struct Slot {
         hipStream_t stream = nullptr;
         hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
-        bool busy = false;
+        size_t index = 0;          // position in slots_ = the slot's number at the gate
         // polynomials
         DevBuf wl, wr, wo;             // L,R,O Lagrange (n)
         DevBuf cl, cr, co, cz;         // blinded canonical (n+3 capacity)
@@ -208,8 +209,8 @@ class CurveBackend : public Backend {
     std::atomic<uint32_t> proof_seq_{0};
     Aff vk_pts_[8 + APK_MAX_COMMITMENTS];
     std::vector<Slot*> slots_;
+    SlotGate gate_;            // who proves on which slot; its busy count picks the load-dependent kernel forms (slot_gate.h)
     std::mutex mu_;
-    std::condition_variable cv_;
     // intra-proof multi-GPU (apk_ctx_set_commit_hook): the prover's commitments go through the host's hook instead of this GPU
     apk_commit_hook hook_ = nullptr;
     void* hook_user_ = nullptr;
@@ -286,12 +287,7 @@ class CurveBackend : public Backend {
         if (max_s > tile_log) max_s = tile_log;
         const int passes = (log_n + max_s - 1) / max_s;
         bool busy_now = false;     // other proofs in flight on this context (the choice of run_msm_body's lean forms)
-        if (slots_.size() > 2 && log_n >= 17 && log_n <= 19) {
-            std::lock_guard<std::mutex> lk(mu_);
-            int busy = 0;
-            for (Slot* t : slots_) busy += t->busy ? 1 : 0;
-            busy_now = busy > 1;
-        }
+        if (slots_.size() > 2 && log_n >= 17 && log_n <= 19) busy_now = gate_.busy() > 1;
         NttBatch nb{};
         for (int i = 0; i < count; i++) { nb.in[i] = ins[i]; nb.out[i] = outs[i]; nb.in_len[i] = in_lens[i]; }
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -468,12 +464,7 @@ class CurveBackend : public Backend {
         // forms of the tail kernels win (fewer, longer chains: every lane of a wave does useful additions); a lone proof keeps
         // the short-chain forms.
         bool others_busy = false;
-        if (slots_.size() > 2) {
-            std::lock_guard<std::mutex> lk(mu_);
-            int busy = 0;
-            for (Slot* t : slots_) busy += t->busy ? 1 : 0;
-            others_busy = busy > 1;
-        }
+        if (slots_.size() > 2) others_busy = gate_.busy() > 1;
         static const int graphs_on = env_int("APK_MSM_GRAPH", 0, 0, 1);   // a captured batch must not depend on the moment of capture:
         if (graphs_on) others_busy = false;                               // neither its unit nor its kernel forms
         // Small batches (a lone 2^14 MSM: 360 k entries) do not even give every SIMD one wave at 16 entries per lane, and a lone
@@ -806,12 +797,7 @@ class CurveBackend : public Backend {
         static const int on = env_int("APK_TAIL_FILL", 1, 0, 2);
         static const int graphs = env_int("APK_MSM_GRAPH", 0, 0, 1);
         if (!on || graphs || hook_ || wire_hook_ || stats_on_ || !qk_direct_ || sc_.on()) return 0;
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            int busy = 0;
-            for (Slot* t : slots_) busy += t->busy ? 1 : 0;
-            if (busy != 1) return 0;
-        }
+        if (gate_.busy() != 1) return 0;
         if (!s.side) {
             // lowest priority: the tail kernels on the main stream are the critical path, the transforms only have to be done
             // by the time the next round's challenge is known
@@ -943,20 +929,12 @@ class CurveBackend : public Backend {
         return APK_OK;
     }
 
-    Slot* acquire() {
-        std::unique_lock<std::mutex> lk(mu_);
-        for (;;) {
-            for (Slot* s : slots_)
-                if (!s->busy) { s->busy = true; return s; }
-            cv_.wait(lk);
-        }
-    }
+    Slot* acquire() { return slots_[gate_.acquire()]; }
     void release(Slot* s) {
         // an error return between a side-stream launch and the next sync leaves transforms in flight: whoever gets the slot next
         // is ordered behind them
         if (s->side_pending) { s->side_pending = false; (void)hipStreamWaitEvent(s->stream, s->ev_side, 0); }
-        { std::lock_guard<std::mutex> lk(mu_); s->busy = false; }
-        cv_.notify_one();
+        gate_.release(s->index);
     }
     struct SlotGuard {
         CurveBackend* b; Slot* s;
@@ -1005,6 +983,17 @@ class CurveBackend : public Backend {
         if (c_ == 0) {
             c_ = env_int("APK_MSM_WINDOW", 0, 0, 20);
             if (c_ != 0 && c_ < 7) c_ = 7;
+        }
+        if (c_ == 0 && log_size >= 20) {
+            // Round 5, from 2^20 bases: the widest window the two-level sort's packed entry has room for - 19 bits (14 windows
+            // instead of 16) up to 2^21 bases, 18 (15 windows) at 2^22 - else 16.  Same box, one MSM at a time / config 5 with four
+            // proofs in flight (profiles/r05_msm_size_sweep.json): BN254 2^20 1.73 -> 1.63 ms, 2^21 3.16 -> 2.97, 2^22 6.15 -> 6.01;
+            // BLS12-381 2^20 3.32 -> 3.18, 2^21 6.26 -> 5.73 ms and 17.2 -> 18.6 proofs/s (c = 18: 17.8); c = 20 loses again at
+            // 2^20 (1.79 / 3.41 ms: 2^19 buckets per MSM in the reduction) and does not fit the entry at 2^21.
+            for (int cand : {19, 18}) {
+                if (choose_window(cand, log_size, slots) == APK_OK) return APK_OK;
+            }
+            c_ = 16;
         }
         // measured flat between log2(n)-4 and log2(n)-2 (tools/sweep.sh).  c = 16 (128 KiB LDS histograms, 16 windows instead of
         // 17) pays from 2^21 up on any context, and from 2^17 up on throughput contexts: at 2^17 with 16 slots +1.4 % proofs/s
@@ -1089,7 +1078,9 @@ class CurveBackend : public Backend {
         CHK(build_tables(nullptr, ptr<Aff>(srs), (uint32_t)count, tab_can_));
         HIPCHK(hipDeviceSynchronize());
         Slot* s = new Slot();
+        s->index = slots_.size();
         slots_.push_back(s);
+        gate_.resize(slots_.size());
         CHK(alloc_slot(*s));
         return APK_OK;
     }
@@ -1198,9 +1189,11 @@ class CurveBackend : public Backend {
         many_slots_ = nslots > 2;
         for (int i = 0; i < nslots; i++) {
             Slot* s = new Slot();
+            s->index = slots_.size();
             slots_.push_back(s);
             CHK(alloc_slot(*s));
         }
+        gate_.resize(slots_.size());
         CHK(setup_trace(d));
         return APK_OK;
     }
@@ -1310,6 +1303,7 @@ class CurveBackend : public Backend {
         return APK_OK;
     }
     int device_ordinal() override { return device_; }
+    int msm_window() override { return c_; }
     uint64_t domain_size() override { return msm_only_ ? 0 : n_; }
     // 4n coset evaluations of a canonical polynomial, device memory in and out; COMPLETE when the call returns.  Inside a hook of
     // this context it runs on the prover's own stream (see msm_batch), otherwise on a free slot.
@@ -1966,15 +1960,11 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         // combination; with many proofs in flight the callers' own threads already keep the host busy
         static const int lc_threads = env_int("APK_HOST_LINCOMB_THREADS", 4, 1, 8);
         HostPool* pool = nullptr;
-        if (lc_threads > 1) {
+        if (lc_threads > 1 && gate_.busy() <= 2) {
             std::lock_guard<std::mutex> lk2(mu_);
-            int busy = 0;
-            for (Slot* t : slots_) busy += t->busy ? 1 : 0;
-            if (busy <= 2) {
-                if (!lc_pool_) lc_pool_.reset(new HostPool(lc_threads - 1));
-                pool = lc_pool_.get();
-                path(P_LINCOMB_POOL);
-            }
+            if (!lc_pool_) lc_pool_.reset(new HostPool(lc_threads - 1));
+            pool = lc_pool_.get();
+            path(P_LINCOMB_POOL);
         }
         lin_com = host_lincomb<FRP, FPP>(lp, lk, (int)lin_terms.size(), pool);
         if (stats_on_) lincomb_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lc).count();

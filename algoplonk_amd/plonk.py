@@ -109,6 +109,11 @@ class ProvingKey:
     def enable_stats(self, on: bool = True) -> None:
         check(lib.apk_stats_enable(self.ctx, int(on)))
 
+    @property
+    def msm_window(self) -> int:
+        """The signed-digit window width of the context's tables (apk_ctx_msm_window)."""
+        return lib.apk_ctx_msm_window(self.ctx)
+
     def paths(self, reset: bool = False) -> dict:
         """Which forms of the load-dependent kernels the context has taken so far (apk_paths_read)."""
         pc = _lib.PathCounts()

@@ -509,11 +509,16 @@ def launcher_selftest(args) -> None:
 
 
 def window_bits(args) -> int:
-    """the library's default (backend_impl.h choose_window): 16 from 2^21 up, and from 2^17 up on contexts with more than 2 slots"""
+    """the window the timed context used: asked of the library (apk_ctx_msm_window) by the mode and parked in args; the formula
+    below only stands in before a context exists (backend_impl.h choose_window)"""
     if args.msm_window:
         return args.msm_window
+    if getattr(args, "window_used", 0):
+        return args.window_used
     throughput = args.mode == "prove" and args.inflight > 2
-    return 16 if args.log_n >= 21 or (args.log_n >= 17 and throughput) else min(15, max(8, args.log_n - 2))
+    if args.log_n >= 20:
+        return 19 if args.log_n <= 21 else 18 if args.log_n == 22 else 16
+    return 16 if (args.log_n >= 17 and throughput) else min(15, max(8, args.log_n - 2))
 
 
 def roofline_from_stats(args, cv, st, pmc, issue=None):
@@ -583,6 +588,7 @@ def bench_prove(args, cv, rk) -> None:
     n = ccs.domain_size()
     srs = setup.unsafe_srs(cv, n, tau, device=rk.local_rank, lagrange=bool(args.bsb22))
     pk, vk = plonk.Setup(ccs, srs, device=rk.local_rank, msm_window=args.msm_window, slots=args.inflight)
+    args.window_used = pk.msm_window
     if args.bsb22:
         solution, pi2_host = plonk.solve_with_commitments(ccs, pk, witness, hiding=[(0xA193 + k, 0x3910A + k) for k in range(args.bsb22)])
     else:
@@ -806,6 +812,7 @@ def bench_sharded_msm(args, cv, rk) -> None:
     bases = srs.g1[: n * 2 * cv.fp_bytes]
     sm = parallel.ShardedMsm(cv, bases, device=rk.local_rank, comm=rk.comm, msm_window=args.msm_window)
     sm.upload(scalars)                            # this rank's slice of the scalars resident in HBM
+    args.window_used = lib.apk_ctx_msm_window(sm._ctx)
     plane = rk.plane_report()
     d = sm._d
     out = C.create_string_buffer(2 * cv.fp_bytes)

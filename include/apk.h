@@ -96,6 +96,8 @@ typedef struct {
 } apk_circuit_desc;
 
 int apk_ctx_create(const apk_circuit_desc* desc, apk_ctx** out);
+/* the window width the context chose (msm_window = 0) or was given; 0 for a null context */
+int apk_ctx_msm_window(apk_ctx* ctx);
 void apk_ctx_destroy(apk_ctx* ctx);
 /* MSM-only context over an arbitrary base set (`count` G1 affine, host memory): windowed tables + one MSM
  * workspace, no circuit.  Used to shard ONE large MSM by index range across GPUs (BASELINE.json configs[3]):

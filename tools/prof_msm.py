@@ -34,8 +34,7 @@ pr = _lib.Proof()
 for _ in range(n_proofs):
     check(lib.apk_prove_device(pk.ctx, d[0], d[1], d[2], cv.fr_vector(wl.witness.public), cv.fr_vector(wl.blinding), None, C.byref(pr)))
 if os.environ.get("APK_PROF_FACTS"):
-    # a default (one-slot, latency) context: window = backend_impl.h choose_window unless APK_MSM_WINDOW says otherwise
-    c = int(os.environ.get("APK_MSM_WINDOW", "0")) or (16 if log_n >= 21 else min(15, max(8, log_n - 2)))
+    c = pk.msm_window                                    # what the context chose (or APK_MSM_WINDOW)
     windows = (cv.r.bit_length() + 1 + c - 1) // c
     msms = 8 + n_msm + 9 * n_proofs           # Setup's 8 VK commitments + the single MSMs + 9 commitments per proof
     json.dump({"curve": cv.name, "log_n": log_n, "n": n, "single_msms": n_msm, "proofs": n_proofs, "msms_total": msms,

@@ -1,0 +1,98 @@
+// Sanitizer tier (SURVEY.md section 5 "race detection"): the host-side threading of libapk that has no GPU in it, hammered from
+// many threads under -fsanitize=thread (or address).  Built and run by `make -C algoplonk_amd/csrc SAN=thread san-check`
+// (tests/test_sanitizers.py runs it in the CPU tier).  What runs here is the library's own code, not a model of it:
+//   * SlotGate (slot_gate.h)   - 32 callers on 4 / 16 slots: every slot has one owner at a time, the busy count is never torn
+//   * HostPool + host_lincomb (host_msm.h) - the [lin] combination on the context's parked threads, 32 callers racing for the pool;
+//     every result must be the single-threaded one
+// Exit code 0 = no mismatch (the sanitizer reports races on its own and fails the run through TSAN_OPTIONS=halt_on_error=1).
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../algoplonk_amd/csrc/ff_params.h"
+#include "../../algoplonk_amd/csrc/host_msm.h"
+#include "../../algoplonk_amd/csrc/slot_gate.h"
+
+using namespace apk;
+
+template <class FRP, class FPP>
+static int hammer_lincomb(const char* name, const uint32_t* gx, const uint32_t* gy) {
+    using Fr = Fe<FRP>;
+    using Fp = Fe<FPP>;
+    using Aff = Affine<FPP>;
+    using Pt = XYZZ<FPP>;
+    // a few distinct points: multiples of the generator
+    Aff g;
+    for (int i = 0; i < Fp::N; i++) { g.x.l[i] = gx[i]; g.y.l[i] = gy[i]; }
+    g.x = Fp::to_mont(g.x); g.y = Fp::to_mont(g.y);
+    constexpr int COUNT = 11;
+    Aff pts[COUNT];
+    Fr ks[COUNT];
+    Pt run = Pt::from_affine(g);
+    for (int i = 0; i < COUNT; i++) {
+        pts[i] = run.to_affine();
+        run = Pt::dbl(run); run.madd(g);
+        Fr k = Fr::zero();
+        for (int w = 0; w < Fr::N; w++) k.l[w] = 0x9e3779b9u * (uint32_t)(i * 8 + w + 1) ^ 0x7f4a7c15u;
+        k.l[Fr::N - 1] &= 0x0fffffffu;
+        ks[i] = Fr::to_mont(k);
+    }
+    const Aff want = host_lincomb<FRP, FPP>(pts, ks, COUNT, nullptr);
+    HostPool pool(3);
+    std::atomic<int> bad{0}, pooled{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < 32; t++)
+        th.emplace_back([&] {
+            for (int r = 0; r < 6; r++) {
+                const Aff got = host_lincomb<FRP, FPP>(pts, ks, COUNT, &pool);
+                if (memcmp(&got, &want, sizeof got) != 0) bad++;
+                pooled++;
+            }
+        });
+    for (auto& t : th) t.join();
+    printf("%s: %d combinations from 32 threads on a 3-worker pool, %d mismatches\n", name, pooled.load(), bad.load());
+    return bad.load();
+}
+
+static int hammer_gate(int slots) {
+    SlotGate gate;
+    gate.resize((size_t)slots);
+    std::vector<std::atomic<int>> owner((size_t)slots);
+    for (auto& o : owner) o = 0;
+    std::atomic<int> bad{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < 32; t++)
+        th.emplace_back([&, t] {
+            for (int r = 0; r < 400; r++) {
+                const size_t i = gate.acquire();
+                if (owner[i].fetch_add(1) != 0) bad++;          // two owners of one slot
+                const int b = gate.busy();
+                if (b < 1 || b > slots) bad++;
+                if ((r + t) % 7 == 0) std::this_thread::yield();
+                owner[i].fetch_sub(1);
+                gate.release(i);
+            }
+        });
+    for (auto& t : th) t.join();
+    if (gate.busy() != 0) bad++;
+    printf("slot gate, %d slots: 32 callers x 400 rounds, %d violations\n", slots, bad.load());
+    return bad.load();
+}
+
+int main() {
+    int bad = 0;
+    bad += hammer_gate(4);
+    bad += hammer_gate(16);
+    // generators: BN254 (1, 2); BLS12-381 G1 generator (canonical little-endian 32-bit words)
+    static const uint32_t bn_x[8] = {1, 0, 0, 0, 0, 0, 0, 0}, bn_y[8] = {2, 0, 0, 0, 0, 0, 0, 0};
+    static const uint32_t bls_x[12] = {0xdb22c6bb, 0xfb3af00a, 0xf97a1aef, 0x6c55e83f, 0x171bac58, 0xa14e3a3f, 0x9774b905, 0xc3688c4f,
+                                       0x4fa9ac0f, 0x2695638c, 0x3197d794, 0x17f1d3a7};
+    static const uint32_t bls_y[12] = {0x46c5e7e1, 0x0caa2329, 0xa2888ae4, 0xd03cc744, 0x2c04b3ed, 0x00db18cb, 0xd5d00af6, 0xfcf5e095,
+                                       0x741d8ae4, 0xa09e30ed, 0xe3aaa0f1, 0x08b3f481};
+    bad += hammer_lincomb<FrBN254, FpBN254>("BN254", bn_x, bn_y);
+    bad += hammer_lincomb<FrBLS12381, FpBLS12381>("BLS12-381", bls_x, bls_y);
+    printf(bad ? "SAN HAMMER FAILED\n" : "SAN HAMMER OK\n");
+    return bad ? 1 : 0;
+}
