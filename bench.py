@@ -731,6 +731,10 @@ def bench_prove(args, cv, rk) -> None:
             "round_ms": [round(x / max(st.proofs, 1), 3) for x in st.round_ms],
             "host_lincomb_ms": round(st.host_lincomb_ms / max(st.proofs, 1), 3),
             "witness_bits": witness_bits,
+            # every run-time knob that was set for this run (none = the library's defaults): a line is reproducible from its command
+            # line plus this
+            "env_knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("APK_") and k != "APK_COMM_TOKEN"},
+            "msm_window": pk.msm_window,
             # the timed region's own output: the last proof of each of the `inflight` callers, made under load
             "proofs_under_load_identical": under_load_identical, "proofs_under_load_checked": len(load_hashes),
             "proofs_under_load_match_lone_proof": loaded_ok, "proofs_under_load_ok_on_all_ranks": all_ok,

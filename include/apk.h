@@ -277,6 +277,10 @@ int apk_comm_wires(apk_comm* comm, uint32_t count, const void* const* d_canonica
  * them - nothing is scattered (the leader / worker split above moves 604 MB per BLS12-381 2^21 proof out of rank 0) and the
  * Fiat-Shamir transcripts of the ranks stay identical, so every rank returns the same proof.  One proof at a time per
  * communicator.  apk_comm_commit_local is the step the hook runs (exposed for the tests of the seam). */
+/* The sub-coset split of round 3 is ON by default in this mode for worlds of 2, 4 and 8 (APK_SPMD_SUBCOSET=0 switches it off) on
+ * the strength of ELEMENT COUNTS only (24 n transformed elements per proof against 4 n + 20 n / G) and a projected 48 GB/s per xGMI
+ * link: no box of the build had two GPUs.  bench.py --mode prove-spmd prints the measured link rate (apk_comm_link_probe) and the
+ * per-phase times (apk_comm_phase_ms) so that the first multi-GPU run can confirm or overturn that default. */
 int apk_comm_spmd_begin(apk_comm* comm);
 int apk_comm_spmd_end(apk_comm* comm);
 int apk_comm_commit_local(apk_comm* comm, int basis, uint32_t count, const void* const* d_scalars, const uint32_t* lens, void* out_points);

@@ -457,7 +457,9 @@ def test_skewed_scalars_at_full_size_are_correct_and_not_pathological(gpu):
     check(lib.apk_device_free(ctx, d))
     lib.apk_ctx_destroy(ctx)
     print("skewed MSM times (ms):", {k: round(v * 1e3, 3) for k, v in times.items()})
-    assert max(times.values()) < 2.0 * times["uniform"] + 0.0002, times
+    # a guard against a pathological path (a serialised heavy bucket was 9x uniform once), not a performance figure: wall-clock
+    # ratios on a shared box do not belong in the parity tier, so the bound is far from the measured 1.0 - 1.8x
+    assert max(times.values()) < 6.0 * times["uniform"] + 0.001, times
 
 
 @pytest.mark.parametrize("cname,log_n", [("bls12-381", 17), ("bn254", 16)])
