@@ -6,7 +6,7 @@ O=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout 400 python bench.py > $O/${TAG}_bench_bn254_2p17.log 2>&1; tail -1 $O/${TAG}_bench_bn254_2p17.log > $O/${TAG}_bench_bn254_2p17.json
 timeout 300 python bench.py --curve bls12_381 --log-n 14 > $O/${TAG}_bench_bls12381_2p14.log 2>&1; tail -1 $O/${TAG}_bench_bls12381_2p14.log > $O/${TAG}_bench_bls12381_2p14.json
-timeout 300 python bench.py --curve bls12_381 --log-n 21 --bsb22 1 --inflight 4 --steps 4 --warmup 1 --no-pmc --no-cpu-baseline > $O/${TAG}_bench_bls12381_2p21_bsb22.log 2>&1; tail -1 $O/${TAG}_bench_bls12381_2p21_bsb22.log > $O/${TAG}_bench_bls12381_2p21_bsb22.json
+timeout 1500 python bench.py --curve bls12_381 --log-n 21 --bsb22 1 --inflight 4 --steps 4 --warmup 1 $BLS21_FLAGS > $O/${TAG}_bench_bls12381_2p21_bsb22.log 2>&1; tail -1 $O/${TAG}_bench_bls12381_2p21_bsb22.log > $O/${TAG}_bench_bls12381_2p21_bsb22.json
 timeout 200 python bench.py --mode msm-sharded --steps 50 > $O/${TAG}_bench_msm_sharded.log 2>&1; tail -1 $O/${TAG}_bench_msm_sharded.log > $O/${TAG}_bench_msm_sharded.json
 timeout 200 python bench.py --mode prove-split --curve bls12_381 --log-n 21 --steps 5 --warmup 1 > $O/${TAG}_bench_prove_split_2p21.log 2>&1; tail -1 $O/${TAG}_bench_prove_split_2p21.log > $O/${TAG}_bench_prove_split_2p21.json
 # kernel traces: one proof at a time (sequential) and the bench's 32 callers (saturated)
@@ -39,5 +39,9 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_IN
   PMC_ENV=APK_MSM_WINDOW=16 pmc_pass bn254_2p17_c16 "$C" 17 4 0
 done
 python tools/pmc_accumulate.py $O $TAG $O/${TAG}_pmc_msm_accumulate.json > $O/${TAG}_pmc_accumulate.log 2>&1
+# one MSM at a time over the sizes and the window widths (round 5: 18..20 bits from 2^20 bases)
+timeout 900 python tools/msm_size_sweep.py 11 24 bn254 $O/${TAG}_msm_size_sweep.json > $O/${TAG}_msm_size_sweep.log 2>&1
+timeout 600 python tools/msm_size_sweep.py 19 22 bn254 $O/${TAG}_msm_window_sweep_bn254.json 16,18,19,20 > $O/${TAG}_msm_window_sweep_bn254.log 2>&1
+timeout 600 python tools/msm_size_sweep.py 19 21 bls12_381 $O/${TAG}_msm_window_sweep_bls12381.json 16,18,19,20 > $O/${TAG}_msm_window_sweep_bls12381.log 2>&1
 rm -rf $O/${TAG}_kt1 $O/${TAG}_kt24 $O/${TAG}_ktbls $O/${TAG}_facts_*.json
 ls -la $O | grep ${TAG} | tail -40
