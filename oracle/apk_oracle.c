@@ -583,3 +583,7 @@ int orc_prove(const orc_circuit* C, const void* Lp, const void* Rp, const void* 
     domain_free(&d0); domain_free(&d1);
     return rc;
 }
+
+/* the performance-first twin of orc_prove / orc_msm (same bytes; bench.py's cpu_baseline): orc_fast_setup / orc_fast_prove /
+ * orc_fast_free / orc_msm_fast */
+#include "fast_prover.c"

@@ -24,6 +24,10 @@ def load() -> C.CDLL:
     lib.orc_msm.argtypes = [C.c_int, vp, vp, C.c_uint64, C.c_int, vp]
     lib.orc_ntt.argtypes = [C.c_int, vp, C.c_uint64, C.c_int, C.c_int]
     lib.orc_prove.argtypes = [C.POINTER(Circuit), vp, vp, vp, vp, vp, C.c_int, vp, C.POINTER(C.c_uint64), vp]
+    lib.orc_msm_fast.argtypes = [C.c_int, vp, vp, C.c_uint64, C.c_int, vp]
+    lib.orc_fast_setup.argtypes = [C.POINTER(Circuit), C.c_int, C.POINTER(vp)]
+    lib.orc_fast_prove.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp, C.POINTER(C.c_uint64), vp]
+    lib.orc_fast_free.argtypes = [vp]; lib.orc_fast_free.restype = None
     return lib
 
 
@@ -43,3 +47,39 @@ def prove(lib, curve_id: int, n: int, nb_public: int, srs: bytes, cols, perm, L:
     rc = lib.orc_prove(C.byref(c), L, R, O, pub, blinding, threads, blob, C.byref(ln), ch)
     del keep
     return rc, blob.raw[: ln.value], [int.from_bytes(ch.raw[32 * i: 32 * i + 32], "big") for i in range(5)]
+
+
+class FastProver:
+    """The performance-first host prover (oracle/fast_prover.c): circuit-only work once, then proofs with the bytes of `prove`."""
+
+    def __init__(self, lib, curve_id: int, n: int, nb_public: int, srs: bytes, cols, perm, threads: int = 1):
+        self.lib = lib
+        self._keep = [srs] + list(cols)
+        permarr = (C.c_int64 * len(perm))(*perm)
+        c = Circuit()
+        c.curve, c.n, c.nb_public = curve_id, n, nb_public
+        c.srs = C.cast(C.c_char_p(srs), C.c_void_p)
+        c.ql, c.qr, c.qm, c.qo, c.qk = (C.cast(C.c_char_p(x), C.c_void_p) for x in cols)
+        c.perm = C.cast(permarr, C.c_void_p)
+        self._ctx = C.c_void_p()
+        rc = lib.orc_fast_setup(C.byref(c), threads, C.byref(self._ctx))
+        if rc != 0:
+            raise RuntimeError("orc_fast_setup returned %d" % rc)
+
+    def prove(self, L: bytes, R: bytes, O: bytes, pub: bytes, blinding: bytes, threads: int = 1):
+        blob = C.create_string_buffer(1200)
+        ln = C.c_uint64(0)
+        ch = C.create_string_buffer(160)
+        rc = self.lib.orc_fast_prove(self._ctx, L, R, O, pub, blinding, threads, blob, C.byref(ln), ch)
+        return rc, blob.raw[: ln.value], [int.from_bytes(ch.raw[32 * i: 32 * i + 32], "big") for i in range(5)]
+
+    def close(self):
+        if self._ctx:
+            self.lib.orc_fast_free(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -67,3 +67,53 @@ def test_c_prover_flags_unsatisfied_witness(clib):
                               [cv.fr_vector(x) for x in (tr.ql, tr.qr, tr.qm, tr.qo, tr.qk)], tr.perm, cv.fr_vector(L),
                               cv.fr_vector(R), cv.fr_vector(O), cv.fr_vector(w.public), cv.fr_vector(blinding(cv, 1)))
     assert rc == 4
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12-381"])
+def test_fast_msm_matches_the_plain_one(clib, cname):
+    """oracle/fast_msm_tmpl.h (batch-affine Pippenger, signed digits, thread pool - bench.py's cpu_baseline) against orc_msm, byte
+    for byte: uniform scalars, the skewed inputs that drive its conflict queue (all equal: every point of a window in ONE bucket),
+    doublings and cancellations (repeated bases with equal / opposite scalars), zeros, lengths that leave chunks ragged."""
+    cv, ov = CURVES[cname]
+    n = 600
+    tau = tau_from_seed(5, cv.r)
+    srs = oplonk.synthetic_srs(ov, 1024, tau, materialize=True)
+    pts = list(srs.g1[:n])
+    g = SplitMix64(11)
+    cases = {"uniform": (pts, [g.fr(cv.r) for _ in range(n)]), "ones": (pts, [1] * n), "minus_one": (pts, [cv.r - 1] * n),
+             "zeros_mostly": (pts, [0 if i % 7 else g.fr(cv.r) for i in range(n)]), "short": (pts[:3], [5, 0, cv.r - 2]),
+             "same_base_doubling": ([pts[1]] * 64, [3] * 64), "same_base_cancel": ([pts[1]] * 64, [3 if i % 2 else cv.r - 3 for i in range(64)]),
+             "small": (pts, [g.below(1 << 12) for _ in range(n)])}
+    for name, (bases, sc) in cases.items():
+        want, got = C.create_string_buffer(2 * cv.fp_bytes), C.create_string_buffer(2 * cv.fp_bytes)
+        b, s = cv.g1_vector(bases), cv.fr_vector(sc)
+        assert clib.orc_msm(cv.abi, b, s, len(sc), 2, want) == 0
+        for threads in (1, 3, 8):
+            assert clib.orc_msm_fast(cv.abi, b, s, len(sc), threads, got) == 0
+            assert got.raw == want.raw, (name, threads)
+
+
+@pytest.mark.parametrize("cname,log_n", [("bn254", 6), ("bn254", 11), ("bls12-381", 5), ("bls12-381", 10)])
+def test_fast_prover_gives_the_bytes_of_the_plain_one(clib, cname, log_n):
+    """oracle/fast_prover.c - circuit-only work once, parallel FFTs, batch-affine MSMs, quotient on one coset, [lin] from
+    commitments, lin(zeta) from the verifier's identity - must return orc_prove's proof and challenges (and through the test
+    above this one, the golden vectors' and the Python oracle's), at several thread counts and on repeated use of one context."""
+    cv, ov = CURVES[cname]
+    ccs, w, sol = random_chain_ccs(cv, log_n, 41 + log_n)
+    n = ccs.domain_size()
+    srs = oplonk.synthetic_srs(ov, n, tau_from_seed(9, cv.r), materialize=True)
+    tr = frontend.build_trace(ccs)
+    L, R, O = frontend.wire_columns(ccs, sol)
+    cols = [cv.fr_vector(x) for x in (tr.ql, tr.qr, tr.qm, tr.qo, tr.qk)]
+    args = (cv.fr_vector(L), cv.fr_vector(R), cv.fr_vector(O), cv.fr_vector(w.public))
+    fp = c_oracle.FastProver(clib, cv.abi, n, ccs.GetNbPublicVariables(), cv.g1_vector(srs.g1), cols, tr.perm, threads=4)
+    for seed, threads in ((1, 1), (2, 4), (3, 7)):
+        bl = cv.fr_vector(blinding(cv, seed))
+        rc, want, wch = c_oracle.prove(clib, cv.abi, n, ccs.GetNbPublicVariables(), cv.g1_vector(srs.g1), cols, tr.perm, *args, bl, threads=2)
+        rc2, got, gch = fp.prove(*args, bl, threads=threads)
+        assert rc == 0 and rc2 == 0 and got == want and gch == wch, (seed, threads)
+    # an unsatisfied witness is reported, like orc_prove does
+    bad = list(O)
+    bad[5] = (bad[5] + 1) % cv.r
+    assert fp.prove(cv.fr_vector(L), cv.fr_vector(R), cv.fr_vector(bad), cv.fr_vector(w.public), cv.fr_vector(blinding(cv, 1)), threads=2)[0] == 4
+    fp.close()
