@@ -567,13 +567,15 @@ class CurveBackend : public Backend {
                 uint32_t* pt_cur = ptr<uint32_t>(s.ptot2) + (size_t)(s.ptot_parity & 1u) * MSM_MAX_BATCH * MSM_PART_MAX;
                 uint32_t* pt_next = ptr<uint32_t>(s.ptot2) + (size_t)((s.ptot_parity & 1u) ^ 1u) * MSM_MAX_BATCH * MSM_PART_MAX;
                 s.ptot_parity ^= 1u;
-                msm_part1_kernel<FRP><<<gd, dth, (size_t)stage_cap * 4 + cursors_lds, st>>>(a, win_, pc, T.n_bases, G, ptr<uint32_t>(s.sort_tmp), stage_cap, pcounts, pt_cur);
+                if (a.plain) msm_part1_kernel<FRP, true><<<gd, dth, (size_t)stage_cap * 4 + cursors_lds, st>>>(a, win_, pc, T.n_bases, G, ptr<uint32_t>(s.sort_tmp), stage_cap, pcounts, pt_cur);
+                else msm_part1_kernel<FRP, false><<<gd, dth, (size_t)stage_cap * 4 + cursors_lds, st>>>(a, win_, pc, T.n_bases, G, ptr<uint32_t>(s.sort_tmp), stage_cap, pcounts, pt_cur);
                 KCHK();
                 msm_part_sort_runs_kernel<0><<<dim3(P, a.batch), 1024, (size_t)tile_cap * 4, st>>>(
                     ptr<uint32_t>(s.sort_tmp), stage_cap, pcounts, pt_cur, pt_next, pc, G, NB_, ptr<uint32_t>(s.hist), ptr<uint32_t>(s.sorted), tile_cap);
                 KCHK();
             } else {
-            msm_part_kernel<FRP, false><<<gd, dth, cursors_lds, st>>>(a, win_, pc, NB_, T.n_bases, G, pcounts, nullptr, nullptr, 0);
+            if (a.plain) msm_part_kernel<FRP, false, true><<<gd, dth, cursors_lds, st>>>(a, win_, pc, NB_, T.n_bases, G, pcounts, nullptr, nullptr, 0);
+            else msm_part_kernel<FRP, false, false><<<gd, dth, cursors_lds, st>>>(a, win_, pc, NB_, T.n_bases, G, pcounts, nullptr, nullptr, 0);
             KCHK();
             if (small_scan) {
                 msm_part_scan_kernel<0><<<1, 1024, 0, st>>>(pcounts, runstart, ptot, a.batch, G, P);
@@ -593,22 +595,24 @@ class CurveBackend : public Backend {
                 pc1.run_lanes = 8;
                 while (pc1.run_lanes < 64 && pc1.run_lanes < mean_run) pc1.run_lanes <<= 1;
             }
-            msm_part_kernel<FRP, true><<<gd, dth, (size_t)stage_cap * 4 + cursors_lds, st>>>(a, win_, pc1, NB_, T.n_bases, G, pcounts, runstart, ptr<uint32_t>(s.sort_tmp),
-                                                                               stage_cap);
+            if (a.plain) msm_part_kernel<FRP, true, true><<<gd, dth, (size_t)stage_cap * 4 + cursors_lds, st>>>(a, win_, pc1, NB_, T.n_bases, G, pcounts, runstart, ptr<uint32_t>(s.sort_tmp), stage_cap);
+            else msm_part_kernel<FRP, true, false><<<gd, dth, (size_t)stage_cap * 4 + cursors_lds, st>>>(a, win_, pc1, NB_, T.n_bases, G, pcounts, runstart, ptr<uint32_t>(s.sort_tmp), stage_cap);
             KCHK();
             msm_part_sort_kernel<0><<<dim3(P, a.batch), 1024, (size_t)tile_cap * 4, st>>>(ptr<uint32_t>(s.sort_tmp), runstart, ptot, pc, G, NB_,
                                                                                           ptr<uint32_t>(s.hist), ptr<uint32_t>(s.sorted), tile_cap);
             KCHK();
             }
         } else if (APK_PHASE(1)) {
-        msm_digits_kernel<FRP, false><<<gd, dth, lds, st>>>(a, win_, NB_, T.n_bases, G, ptr<uint32_t>(s.counts), nullptr, nullptr);
+        if (a.plain) msm_digits_kernel<FRP, false, true><<<gd, dth, lds, st>>>(a, win_, NB_, T.n_bases, G, ptr<uint32_t>(s.counts), nullptr, nullptr);
+        else msm_digits_kernel<FRP, false, false><<<gd, dth, lds, st>>>(a, win_, NB_, T.n_bases, G, ptr<uint32_t>(s.counts), nullptr, nullptr);
         KCHK();
         msm_colscan_kernel<0><<<cdiv(total_buckets, 256), 256, 0, st>>>(ptr<uint32_t>(s.counts), NB_, G, total_buckets, ptr<uint32_t>(s.hist));
         KCHK();
         }
         if (APK_PHASE(32)) {
             // `items` consecutive buckets per scan thread keep the block count at MSM_SCAN_MAX_BLOCKS (the totals step's LDS) up to 2^21 buckets
-            const uint32_t items = cdiv(total_buckets, (uint64_t)MSM_SCAN_BLOCK * MSM_SCAN_MAX_BLOCKS);
+            uint32_t items = 1;
+            while (items < (uint32_t)MSM_SCAN_ITEMS_MAX && (uint64_t)MSM_SCAN_BLOCK * MSM_SCAN_MAX_BLOCKS * items < total_buckets) items <<= 1;   // 1, 2, 4, 8
             const uint32_t nblk = cdiv(total_buckets, (uint64_t)MSM_SCAN_BLOCK * items);
             uint32_t* blk_tot = ptr<uint32_t>(s.scan_blk);
             uint32_t* blk_bins = blk_tot + 3 * nblk;
@@ -618,20 +622,19 @@ class CurveBackend : public Backend {
             // slowest of them instead of on an idle CU.  Off; three launches stay.
             static const int scan_fused = env_int("APK_MSM_SCAN_FUSED", 0, 0, 1);
             uint32_t* scan_done = ptr<uint32_t>(s.done_count) + MSM_MAX_BATCH;
-            if (scan_fused) {
-                msm_scan_local_kernel<1><<<nblk, MSM_SCAN_BLOCK, 0, st>>>(ptr<uint32_t>(s.hist), total_buckets, unit, ptr<uint32_t>(s.offsets),
-                                                                           ptr<uint32_t>(s.unit_off), ptr<uint32_t>(s.full_off), ptr<uint32_t>(s.rem_rank),
-                                                                           ptr<uint32_t>(s.merge_rank), blk_tot, blk_bins, nblk, scan_done, items);
+#define APK_SCAN_LOCAL(F, I) msm_scan_local_kernel<F, I><<<nblk, MSM_SCAN_BLOCK, 0, st>>>(ptr<uint32_t>(s.hist), total_buckets, unit, ptr<uint32_t>(s.offsets), \
+                ptr<uint32_t>(s.unit_off), ptr<uint32_t>(s.full_off), ptr<uint32_t>(s.rem_rank), ptr<uint32_t>(s.merge_rank), blk_tot, blk_bins, nblk, scan_done)
+            if (scan_fused && items == 1) {
+                APK_SCAN_LOCAL(1, 1);
                 KCHK();
             } else {
-                msm_scan_local_kernel<0><<<nblk, MSM_SCAN_BLOCK, 0, st>>>(ptr<uint32_t>(s.hist), total_buckets, unit, ptr<uint32_t>(s.offsets),
-                                                                           ptr<uint32_t>(s.unit_off), ptr<uint32_t>(s.full_off), ptr<uint32_t>(s.rem_rank),
-                                                                           ptr<uint32_t>(s.merge_rank), blk_tot, blk_bins, nblk, scan_done, items);
+                if (items == 1) APK_SCAN_LOCAL(0, 1); else if (items == 2) APK_SCAN_LOCAL(0, 2); else if (items == 4) APK_SCAN_LOCAL(0, 4); else APK_SCAN_LOCAL(0, 8);
                 KCHK();
                 msm_scan_totals_kernel<0><<<1, MSM_SCAN_BLOCK, 0, st>>>(blk_tot, blk_bins, nblk, total_buckets, ptr<uint32_t>(s.offsets),
                                                                          ptr<uint32_t>(s.unit_off), ptr<uint32_t>(s.full_off));
                 KCHK();
             }
+#undef APK_SCAN_LOCAL
             msm_scan_apply_kernel<0><<<cdiv(total_buckets, MSM_SCAN_BLOCK), MSM_SCAN_BLOCK, 0, st>>>(blk_tot, blk_bins, ptr<uint32_t>(s.hist), ptr<uint32_t>(s.rem_rank),
                                                                       ptr<uint32_t>(s.merge_rank), nblk,
                                                                       total_buckets, unit, ptr<uint32_t>(s.offsets), ptr<uint32_t>(s.unit_off),
@@ -639,8 +642,8 @@ class CurveBackend : public Backend {
             KCHK();
         }
         if (!sort2 && APK_PHASE(64)) {
-        msm_digits_kernel<FRP, true><<<gd, dth, lds, st>>>(a, win_, NB_, T.n_bases, G, ptr<uint32_t>(s.counts), ptr<uint32_t>(s.offsets),
-                                                            ptr<uint32_t>(s.sorted));
+        if (a.plain) msm_digits_kernel<FRP, true, true><<<gd, dth, lds, st>>>(a, win_, NB_, T.n_bases, G, ptr<uint32_t>(s.counts), ptr<uint32_t>(s.offsets), ptr<uint32_t>(s.sorted));
+        else msm_digits_kernel<FRP, true, false><<<gd, dth, lds, st>>>(a, win_, NB_, T.n_bases, G, ptr<uint32_t>(s.counts), ptr<uint32_t>(s.offsets), ptr<uint32_t>(s.sorted));
         KCHK();
         }
         if (stats_on_) HIPCHK(hipEventRecord(s.ev2, st));
@@ -668,7 +671,9 @@ class CurveBackend : public Backend {
         static const int dyn_env = env_int("APK_MSM_COMBINE_DYN", 1, 0, 1);
         const bool dyn_lanes = dyn_env && !lean && APK_PHASE(32);
         if (dyn_lanes) { lanes_log += 2; if ((1u << lanes_log) > MSM_COMBINE_LANES) lanes_log = 4; }
-        const uint32_t scan_nblk = cdiv(total_buckets, (uint64_t)MSM_SCAN_BLOCK * cdiv(total_buckets, (uint64_t)MSM_SCAN_BLOCK * MSM_SCAN_MAX_BLOCKS));
+        uint32_t scan_items = 1;
+        while (scan_items < (uint32_t)MSM_SCAN_ITEMS_MAX && (uint64_t)MSM_SCAN_BLOCK * MSM_SCAN_MAX_BLOCKS * scan_items < total_buckets) scan_items <<= 1;
+        const uint32_t scan_nblk = cdiv(total_buckets, (uint64_t)MSM_SCAN_BLOCK * scan_items);
         const uint32_t* avg_partials = dyn_lanes ? ptr<uint32_t>(s.scan_blk) + (size_t)(3 + MSM_BINS) * scan_nblk : nullptr;
         {   // light and heavy merge in one launch (the heavy blocks return at once when no bucket is skewed)
             const uint32_t normal_blocks = cdiv((uint64_t)total_buckets << lanes_log, 256);
@@ -966,14 +971,20 @@ class CurveBackend : public Backend {
     uint32_t part_stage_max() const { return msm_part_stage_max(part_cfg_.P ? part_cfg_.P : 4u); }
     int set_sort_lds_limits() {
         if (one_level_ok() && digits_lds_bytes() > 65536) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)digits_lds_bytes()));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)digits_lds_bytes()));
+            const int dl = (int)digits_lds_bytes();
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, dl));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, dl));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, dl));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_digits_kernel<FRP, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, dl));
         }
         const int part_lds = (int)(MSM_LDS_WORDS - 63u) * 4;     // stage + cursors (msm_part_stage_max)
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, part_lds));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_kernel<FRP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, part_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_kernel<FRP, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, part_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_kernel<FRP, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, part_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_kernel<FRP, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, part_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_kernel<FRP, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, part_lds));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_sort_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_TILE * 4));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part1_kernel<FRP>), hipFuncAttributeMaxDynamicSharedMemorySize, part_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part1_kernel<FRP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, part_lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part1_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, part_lds));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&msm_part_sort_runs_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_PART_TILE * 4));
         return APK_OK;
     }

@@ -30,7 +30,15 @@ constexpr int MSM_UNIT_MIN = 16, MSM_UNIT_MAX = 64;
 constexpr int MSM_UNIT_SMALL = 4;                       // shortest unit of a batch that cannot fill the SIMDs at MSM_UNIT_MIN
 constexpr uint64_t MSM_SMALL_ENTRIES = 1ull << 20;      // ... and the most entries such a batch has (16 x 65 536 lanes)
 constexpr int MSM_COMBINE_LANES = 16;
-constexpr uint32_t MSM_HEAVY_UNITS = 512;  // unit partials above which a bucket is merged by a whole workgroup
+constexpr uint32_t MSM_HEAVY_UNITS = 512;  // unit partials above which a bucket is ALWAYS merged by a whole workgroup
+// ... and below it when the bucket is far above what its lanes are sized for: heavy from max(32, 4 x per_lane x lanes) partials.
+// (Round 5: on a sparse input - Lagrange-basis wires of a bit-heavy witness - most buckets hold ONE partial, so the merge runs one
+// lane per bucket, and the bucket of the digit 1 with ~500 partials was walked by that one lane: 2.8 ms of a lone BLS12-381 2^14
+// proof.  Uniform inputs never get there: their buckets agree with the average.)
+__device__ __forceinline__ uint32_t msm_heavy_threshold(int lanes_log, uint32_t per_lane) {
+    const uint32_t t = (4u * per_lane) << lanes_log;
+    return t < 32u ? 32u : (t > MSM_HEAVY_UNITS ? MSM_HEAVY_UNITS : t);
+}
 
 // Signed-digit windows.  Widths differ by at most one bit (c or c-1) so the BITS+1 scalar bits are spread evenly:
 // with equal widths the top window can be left with 1-3 significant bits, and every scalar then lands in the same
@@ -68,7 +76,10 @@ struct MsmBatchArgs {
 #endif
 constexpr uint32_t MSM_PACKED_NB = APK_MSM_PACKED_NB;
 constexpr int MSM_DIGITS_THREADS = 1024;  // per sort workgroup: the slice's LDS atomics and scattered stores are latency-bound
-template <class FR, bool SCATTER>
+// PLAIN (every sort kernel): the table holds the bases themselves, so the scalars leave the Montgomery form before they are recoded
+// (MsmBatchArgs::plain).  A template parameter, not a run-time test: as a uniform branch the compiler computed the conversion on
+// BOTH paths and selected (msm_part1_kernel 28 -> 40 VGPRs, +44 % time under load at BLS12-381 2^14: round 5 A/B against round 4).
+template <class FR, bool SCATTER, bool PLAIN = false>
 __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_digits_kernel(MsmBatchArgs a, MsmWindows win, uint32_t nb, uint32_t n_max, uint32_t G,
                                                          uint32_t* __restrict__ counts,         // [batch][G][nb]
                                                          const uint32_t* __restrict__ offsets,  // SCATTER only
@@ -92,7 +103,7 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_digits_kernel(MsmBatch
         // Montgomery product per scalar to leave the form (it was ~45 % of the two passes' instructions).
 #ifndef APK_MSM_NO_RINV
         Fr s = reinterpret_cast<const Fr*>(a.scalars[b])[i];
-        if (a.plain) s = Fr::from_mont(s);        // uniform
+        if constexpr (PLAIN) s = Fr::from_mont(s);
 #else
         Fr s = Fr::from_mont(reinterpret_cast<const Fr*>(a.scalars[b])[i]);
 #endif
@@ -214,7 +225,7 @@ struct MsmPartCfg {
     uint32_t run_lanes;          // first level's copy-out: lanes per (slice, partition) run (8..64, a power of two >= the mean run)
 };
 
-template <class FR, bool SCATTER>
+template <class FR, bool SCATTER, bool PLAIN = false>
 __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part_kernel(MsmBatchArgs a, MsmWindows win, MsmPartCfg pc, uint32_t nb, uint32_t n_max, uint32_t G,
                                                                      uint32_t* __restrict__ pcounts,         // [batch][G][P]   (!SCATTER: out, SCATTER: in)
                                                                      const uint32_t* __restrict__ runstart,  // [batch][G][P]   (SCATTER: in)
@@ -262,7 +273,7 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part_kernel(MsmBatchAr
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
 #ifndef APK_MSM_NO_RINV
         Fr s = reinterpret_cast<const Fr*>(a.scalars[b])[i];      // Montgomery form as it is: the tables hold R^-1 * P
-        if (a.plain) s = Fr::from_mont(s);                        // ... unless they hold P itself (uniform)
+        if constexpr (PLAIN) s = Fr::from_mont(s);                // ... unless they hold P itself
 #else
         Fr s = Fr::from_mont(reinterpret_cast<const Fr*>(a.scalars[b])[i]);
 #endif
@@ -574,7 +585,7 @@ __global__ void __launch_bounds__(256) msm_density_kernel(MsmBatchArgs a, MsmWin
 }
 
 constexpr int MSM_PART1_HOLD = 3;   // scalars a lane keeps in registers between the two passes (2 049 per slice / 1 024 lanes)
-template <class FR>
+template <class FR, bool PLAIN = false>
 __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part1_kernel(MsmBatchArgs a, MsmWindows win, MsmPartCfg pc, uint32_t n_max, uint32_t G,
                                                                       uint32_t* __restrict__ tmp, uint32_t cap,       // cap entries per slice
                                                                       uint32_t* __restrict__ runtab,                   // [batch][G][P + 1]
@@ -600,7 +611,8 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part1_kernel(MsmBatchA
         int it = 0;
         for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x, it++) {
 #ifndef APK_MSM_NO_RINV
-            const Fr s = a.plain ? Fr::from_mont(sc[i]) : sc[i];
+            Fr s = sc[i];
+            if constexpr (PLAIN) s = Fr::from_mont(s);
 #else
             const Fr s = Fr::from_mont(sc[i]);
 #endif
@@ -644,7 +656,8 @@ __global__ void __launch_bounds__(MSM_DIGITS_THREADS) msm_part1_kernel(MsmBatchA
                 for (int h = 0; h < MSM_PART1_HOLD; h++) if (h == it) s = held[h];
             } else {
 #ifndef APK_MSM_NO_RINV
-                s = a.plain ? Fr::from_mont(sc[i]) : sc[i];
+                s = sc[i];
+                if constexpr (PLAIN) s = Fr::from_mont(s);
 #else
                 s = Fr::from_mont(sc[i]);
 #endif
@@ -872,14 +885,15 @@ __device__ __forceinline__ void msm_scan_totals_body(uint32_t* __restrict__ bloc
 }
 // FUSED = 1: the workgroup that finishes last (an agent-scope counter, reset by that workgroup; no spinning) goes on to run the
 // totals step, so the scan is two launches; FUSED = 0: msm_scan_totals_kernel follows as a launch of its own.
-template <int FUSED>
+template <int FUSED, int ITEMS = 1>   // ITEMS = consecutive buckets per thread: 1 (up to 2^18 buckets, the code of rounds 1-4), 2, 4 or 8
 __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_local_kernel(const uint32_t* __restrict__ hist, uint32_t total, uint32_t unit,
                                                                          uint32_t* __restrict__ offsets, uint32_t* __restrict__ unit_off,
                                                                          uint32_t* __restrict__ full_off, uint32_t* __restrict__ rem_rank,
                                                                          uint32_t* __restrict__ merge_rank,
                                                                          uint32_t* __restrict__ block_tot /* [3][nblocks] */,
                                                                          uint32_t* __restrict__ block_bins /* [nblocks][MSM_BINS] */, uint32_t nblocks,
-                                                                         uint32_t* __restrict__ done, uint32_t items /* 1..MSM_SCAN_ITEMS_MAX */) {
+                                                                         uint32_t* __restrict__ done) {
+    constexpr uint32_t items = ITEMS;
     wave_priority<APK_PRIO_SORT>();
     __shared__ uint32_t s_cnt[MSM_SCAN_BLOCK];
     __shared__ uint32_t s_unit[MSM_SCAN_BLOCK];
@@ -888,11 +902,11 @@ __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_local_kernel(const ui
     const uint32_t t = threadIdx.x, i0 = (blockIdx.x * MSM_SCAN_BLOCK + t) * items;   // this thread's `items` consecutive buckets
     if (t < MSM_BINS) s_bins[t] = 0;
     __syncthreads();
-    uint32_t hv[MSM_SCAN_ITEMS_MAX], sh = 0, su = 0, sf = 0;
+    uint32_t hv[ITEMS], sh = 0, su = 0, sf = 0;
 #pragma unroll
-    for (int it = 0; it < MSM_SCAN_ITEMS_MAX; it++) {
+    for (int it = 0; it < ITEMS; it++) {
         const uint32_t i = i0 + (uint32_t)it;
-        const bool in = (uint32_t)it < items && i < total;
+        const bool in = i < total;
         const uint32_t h = in ? hist[i] : 0u, hf = h / unit, rem = h - hf * unit, hu = hf + (rem ? 1u : 0u);
         hv[it] = h;
         if (rem) rem_rank[i] = atomicAdd(&s_bins[rem], 1u);   // rank of this bucket among the block's buckets with the same remainder
@@ -911,9 +925,9 @@ __global__ void __launch_bounds__(MSM_SCAN_BLOCK) msm_scan_local_kernel(const ui
     {   // exclusive, block-local: the thread's base, then its buckets one after the other
         uint32_t ro = s_cnt[t] - sh, ru = s_unit[t] - su, rf = s_full[t] - sf;
 #pragma unroll
-        for (int it = 0; it < MSM_SCAN_ITEMS_MAX; it++) {
+        for (int it = 0; it < ITEMS; it++) {
             const uint32_t i = i0 + (uint32_t)it;
-            if ((uint32_t)it < items && i < total) {
+            if (i < total) {
                 const uint32_t h = hv[it], hf = h / unit, hu = hf + (h - hf * unit ? 1u : 0u);
                 offsets[i] = ro; unit_off[i] = ru; full_off[i] = rf;
                 ro += h; ru += hu; rf += hf;
@@ -1068,7 +1082,8 @@ __device__ __forceinline__ PT shfl_down_point(const PT& p, int delta, int width)
 constexpr uint32_t MSM_HEAVY_BLOCKS = 128;
 template <class FP>
 __device__ __forceinline__ void msm_combine_heavy_body(const XYZZ<FP, FeU<FP>>* __restrict__ partial, const uint32_t* __restrict__ unit_off,
-                                                       uint32_t total_buckets, XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum, uint32_t blk, uint32_t nblk);
+                                                       uint32_t total_buckets, XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum, uint32_t blk, uint32_t nblk,
+                                                       uint32_t heavy);
 
 // lanes per bucket of the merge: as many as bring the partials per lane down to `per_lane`, from the bucket scan's own count of
 // partials per non-empty bucket (avg_partials; null: the host's choice stands), at most 2^max_log
@@ -1090,11 +1105,12 @@ __global__ void __launch_bounds__(256) msm_combine_kernel(const XYZZ<FP, FeU<FP>
                                                           const uint32_t* __restrict__ avg_partials, uint32_t per_lane) {
     wave_priority<APK_PRIO_TAIL>();
     using PT = XYZZ<FP, FeU<FP>>;
+    lanes_log = msm_combine_lanes(lanes_log, avg_partials, per_lane);
+    const uint32_t heavy = msm_heavy_threshold(lanes_log, per_lane);
     if (blockIdx.x >= normal_blocks) {   // block-uniform
-        msm_combine_heavy_body<FP>(partial, unit_off, total_buckets, bucket_sum, blockIdx.x - normal_blocks, gridDim.x - normal_blocks);
+        msm_combine_heavy_body<FP>(partial, unit_off, total_buckets, bucket_sum, blockIdx.x - normal_blocks, gridDim.x - normal_blocks, heavy);
         return;
     }
-    lanes_log = msm_combine_lanes(lanes_log, avg_partials, per_lane);
     if ((uint64_t)blockIdx.x * blockDim.x >= ((uint64_t)total_buckets << lanes_log)) return;   // the grid was sized for the most lanes
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t LANES = 1u << lanes_log;
@@ -1105,7 +1121,7 @@ __global__ void __launch_bounds__(256) msm_combine_kernel(const XYZZ<FP, FeU<FP>
     PT acc = PT::inf();
     uint32_t beg = 0, end = 0;
     if (slot < total_buckets) { beg = unit_off[k]; end = unit_off[k + 1]; }
-    if (end - beg > MSM_HEAVY_UNITS) end = beg;   // skewed bucket: left to msm_combine_heavy_kernel
+    if (end - beg > heavy) end = beg;   // skewed bucket: left to the heavy blocks
     for (uint32_t u = beg + lane; u < end; u += LANES) acc.add_lazy(partial[u]);
     // all lanes of the wave take part in every shuffle; groups with nothing to add see infinities
     const uint32_t n_units = end - beg;
@@ -1116,7 +1132,7 @@ __global__ void __launch_bounds__(256) msm_combine_kernel(const XYZZ<FP, FeU<FP>
             if (lane < (uint32_t)d && n_units > (uint32_t)d) acc.add_lazy(o);
         }
     }
-    if (slot < total_buckets && lane == 0 && unit_off[k + 1] - unit_off[k] <= MSM_HEAVY_UNITS) bucket_sum[k] = acc;
+    if (slot < total_buckets && lane == 0 && unit_off[k + 1] - unit_off[k] <= heavy) bucket_sum[k] = acc;
 }
 
 // Skewed inputs (e.g. a Lagrange-basis commitment of a witness full of ones): a bucket with more than MSM_HEAVY_UNITS unit
@@ -1125,7 +1141,8 @@ __global__ void __launch_bounds__(256) msm_combine_kernel(const XYZZ<FP, FeU<FP>
 // costs microseconds when there are none (uniform scalars never produce one).
 template <class FP>
 __device__ __forceinline__ void msm_combine_heavy_body(const XYZZ<FP, FeU<FP>>* __restrict__ partial, const uint32_t* __restrict__ unit_off,
-                                                       uint32_t total_buckets, XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum, uint32_t blk, uint32_t nblk) {
+                                                       uint32_t total_buckets, XYZZ<FP, FeU<FP>>* __restrict__ bucket_sum, uint32_t blk, uint32_t nblk,
+                                                       uint32_t heavy) {
     using PT = XYZZ<FP, FeU<FP>>;
     __shared__ PT sm[256];
     const uint32_t t = threadIdx.x;
@@ -1134,11 +1151,11 @@ __device__ __forceinline__ void msm_combine_heavy_body(const XYZZ<FP, FeU<FP>>* 
     // the common case has no heavy bucket at all: every thread looks at its own buckets first (one round of loads instead of
     // a serial walk over the slice), and the block only walks the slice if somebody saw one
     bool any = false;
-    for (uint32_t k = k0 + t; k < k1; k += 256) any |= unit_off[k + 1] - unit_off[k] > MSM_HEAVY_UNITS;
+    for (uint32_t k = k0 + t; k < k1; k += 256) any |= unit_off[k + 1] - unit_off[k] > heavy;
     if (!__syncthreads_or(any)) return;
     for (uint32_t k = k0; k < k1; k++) {
         const uint32_t beg = unit_off[k], end = unit_off[k + 1];
-        if (end - beg <= MSM_HEAVY_UNITS) continue;   // uniform across the block
+        if (end - beg <= heavy) continue;   // uniform across the block
         PT acc = PT::inf();
         for (uint32_t u = beg + t; u < end; u += 256) acc.add_lazy(partial[u]);
         sm[t] = acc;
@@ -1269,11 +1286,12 @@ __global__ void __launch_bounds__(256) msm_combine_quad_kernel(const XYZZ<FP, Fe
                                                                const uint32_t* __restrict__ avg_partials, uint32_t per_lane) {
     wave_priority<APK_PRIO_TAIL>();
     using PT = XYZZ<FP, FeU<FP>>;
+    lanes_log = msm_combine_lanes(lanes_log, avg_partials, per_lane);
+    const uint32_t heavy = msm_heavy_threshold(lanes_log, per_lane);
     if (blockIdx.x >= normal_blocks) {   // block-uniform
-        msm_combine_heavy_body<FP>(partial, unit_off, total_buckets, bucket_sum, blockIdx.x - normal_blocks, gridDim.x - normal_blocks);
+        msm_combine_heavy_body<FP>(partial, unit_off, total_buckets, bucket_sum, blockIdx.x - normal_blocks, gridDim.x - normal_blocks, heavy);
         return;
     }
-    lanes_log = msm_combine_lanes(lanes_log, avg_partials, per_lane);
     if ((uint64_t)blockIdx.x * blockDim.x >= (((uint64_t)total_buckets << lanes_log) << 2)) return;
     const uint32_t gq = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;      // the quad's number
     const int q = threadIdx.x & 3;
@@ -1285,7 +1303,7 @@ __global__ void __launch_bounds__(256) msm_combine_quad_kernel(const XYZZ<FP, Fe
     PT acc = PT::inf();
     uint32_t beg = 0, end = 0;
     if (slot < total_buckets) { beg = unit_off[k]; end = unit_off[k + 1]; }
-    if (end - beg > MSM_HEAVY_UNITS) end = beg;
+    if (end - beg > heavy) end = beg;
     for (uint32_t u = beg + lane; u < end; u += LANES) quad_tree_add(acc, partial[u], q);
     const uint32_t n_units = end - beg;
     uint64_t need = __ballot(n_units > 1);
@@ -1295,7 +1313,7 @@ __global__ void __launch_bounds__(256) msm_combine_quad_kernel(const XYZZ<FP, Fe
             if (lane < (uint32_t)d && n_units > (uint32_t)d) quad_tree_add(acc, o, q);
         }
     }
-    if (slot < total_buckets && lane == 0 && q == 0 && unit_off[k + 1] - unit_off[k] <= MSM_HEAVY_UNITS) bucket_sum[k] = acc;
+    if (slot < total_buckets && lane == 0 && q == 0 && unit_off[k + 1] - unit_off[k] <= heavy) bucket_sum[k] = acc;
 }
 
 // Row / column sums for throughput contexts: one lane per operation while a level still has more than 16 additions to do
