@@ -550,9 +550,15 @@ def roofline_from_stats(args, cv, st, pmc, issue=None):
             ns_mad = min(issue["mad_u64_dependent_ns_per_wave_inst_per_simd_4waves"], issue["mad_u64_dependent_ns_per_wave_inst_per_simd_8waves"])
             ns, mix = ns_mad, "every instruction priced as a v_mad_u64_u32"
             share64 = pmc.get("valu_int64_share")
-            if share64 is not None and 0.3 <= share64 <= 0.95 and issue.get("add_co_chain_ns_per_wave_inst_per_simd_8waves"):
-                # mix-weighted: the 64-bit integer instructions (SQ_INSTS_VALU_INT64: the mads and 64-bit shifts) at the mad's rate,
-                # the rest at the 32-bit add chain's
+            if share64 is not None and 0.3 <= share64 <= 0.95 and issue.get("mix_75pct_mad_ns_per_wave_inst_per_simd"):
+                # priced at the rate of an INTERLEAVED stream with this run's share of 64-bit integer instructions (SQ_INSTS_VALU_INT64:
+                # the mads and 64-bit shifts): mads and simple adds overlap in the pipeline, so the stream issues faster than the sum of
+                # its classes - interpolated between the ubench's 50 %, 75 % and 100 % mad streams (best of 2 / 4 / 8 waves per SIMD)
+                pts = [(0.5, issue["mix_50pct_mad_ns_per_wave_inst_per_simd"]), (0.75, issue["mix_75pct_mad_ns_per_wave_inst_per_simd"]), (1.0, ns_mad)]
+                lo, hi = (pts[0], pts[1]) if share64 <= 0.75 else (pts[1], pts[2])
+                ns = lo[1] + (hi[1] - lo[1]) * (share64 - lo[0]) / (hi[0] - lo[0])
+                mix = "%.1f %% 64-bit integer instructions, priced at the ubench's interleaved mad / add streams" % (100 * share64)
+            elif share64 is not None and 0.3 <= share64 <= 0.95 and issue.get("add_co_chain_ns_per_wave_inst_per_simd_8waves"):
                 ns = share64 * ns_mad + (1.0 - share64) * issue["add_co_chain_ns_per_wave_inst_per_simd_8waves"]
                 mix = "%.1f %% 64-bit integer instructions at the mad rate, the rest at the 32-bit add-chain rate" % (100 * share64)
             simds = 4 * (issue.get("compute_units") or 256)
@@ -692,13 +698,22 @@ def bench_prove(args, cv, rk) -> None:
             # (the PMC passes profile the MSMs of a circuit of the same size and curve WITHOUT the commitment: the accumulate
             # kernel's traffic and instruction count per pair do not depend on the circuit)
             pmc = pmc_traffic(args.curve, args.log_n, window_bits(args), timeout_s=420.0 if args.log_n < 20 else 1500.0)
-        if not args.no_cpu_baseline and not args.bsb22:
+        if not args.no_cpu_baseline:
             probe = go_probe()
             cpu_baseline = gnark_cpu_baseline(probe, args.curve, args.log_n, args.cpu_baseline_seconds)
             if cpu_baseline is None:
                 try:
                     from bench_cpu import cpu_baseline_prove
-                    cpu_baseline = cpu_baseline_prove(wl, srs, args.cpu_baseline_seconds)
+                    if args.bsb22:
+                        # the host ports have no BSB22 path: they prove the random circuit of the SAME size and curve without the
+                        # commitment (one sparse Lagrange-basis MSM, one more polynomial through rounds 1 / 3 / 4: ~4 % of a proof's
+                        # work) - said in `sample`; no proof hash to compare
+                        wl_cpu = workloads.random_circuit(cv, args.log_n, seed)
+                        cpu_baseline = cpu_baseline_prove(wl_cpu, srs, args.cpu_baseline_seconds)
+                        cpu_baseline["sample"] += "; WITHOUT the BSB22 commitment of the GPU's workload (the ports have no BSB22 path)"
+                        cpu_baseline.pop("proof_sha256_prefix", None)
+                    else:
+                        cpu_baseline = cpu_baseline_prove(wl, srs, args.cpu_baseline_seconds)
                 except Exception as e:  # the baseline is reported, never required for the GPU number
                     cpu_baseline = {"value": None, "unit": "proofs/sec", "cores": 0, "kind": "port", "sample": "unavailable: %s" % e}
             cpu_baseline["go_probe"] = probe

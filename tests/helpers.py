@@ -68,6 +68,8 @@ def check_bench_line(d: dict, tol: float = 0.01) -> None:
         close(v["bucket_additions_per_s"], rf["pairs_per_launch"] * v["windows"] / t / 1e9, "valu.bucket_additions_per_s")
         if "issue_bound" in v:
             close(v["frac"], v["bucket_additions_per_s"] / v["issue_bound"], "valu.frac")
-            assert v["frac"] <= 1.05, "an addition rate above the kernel's own issue bound means the bound's basis is stale"
+            # the bound prices this run's instruction count at rates a micro-benchmark measured on the same box: an estimate of the
+            # issue limit, good to a few percent - a rate far above it means its basis is stale
+            assert v["frac"] <= 1.12, "an addition rate far above the kernel's own issue bound means the bound's basis is stale"
             if "instructions_per_addition" in v:      # round 5: both factors of the bound are on the line
                 close(v["issue_bound"], v["simds"] * 64 / (v["instructions_per_addition"] * v["ns_per_wave_instruction_per_simd"]), "valu.issue_bound")

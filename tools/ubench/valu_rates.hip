@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdint.h>
 #include <string.h>
+#include <math.h>
 
 #define REP 64
 #define OUTER 256
@@ -34,6 +35,12 @@ __global__ void k(uint32_t* out, uint32_t seed) {
             } else if (KIND == 5) {  // v_mul_lo_u32 + v_mul_hi_u32 independent
                 asm volatile("v_mul_lo_u32 %0, %2, %3\n v_mul_hi_u32 %1, %2, %3\n v_mul_lo_u32 %4, %2, %3\n v_mul_hi_u32 %5, %2, %3"
                              : "=v"(m0), "=v"(m1) : "v"(a), "v"(b), "v"(m2), "v"(m3));
+            } else if (KIND == 7) {  // the accumulate loop's mix, 75 % 64-bit: 3 dependent mads + 1 add, twice over two accumulators... counted as 4
+                asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_add_u32 %1, %1, %2"
+                             : "+v"(c0), "+v"(m0) : "v"(a), "v"(b) : "vcc");
+            } else if (KIND == 8) {  // 50 % 64-bit: 2 dependent mads + 2 adds
+                asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_add_u32 %1, %1, %2\n v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_add_u32 %1, %1, %3"
+                             : "+v"(c0), "+v"(m0) : "v"(a), "v"(b) : "vcc");
             } else if (KIND == 6) {  // v_add_co / v_addc chain x4
                 asm volatile("v_add_co_u32 %0, vcc, %0, %1\n v_addc_co_u32 %1, vcc, %1, %2, vcc\n v_addc_co_u32 %2, vcc, %2, %3, vcc\n v_addc_co_u32 %3, vcc, %3, %0, vcc"
                              : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3) : : "vcc");
@@ -101,9 +108,12 @@ int main(int argc, char** argv) {
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
         printf("{\"mad_u64_dependent_ns_per_wave_inst_per_simd_4waves\": %.4f, \"mad_u64_dependent_ns_per_wave_inst_per_simd_8waves\": %.4f, "
                "\"mad_u64_independent_ns_per_wave_inst_per_simd_4waves\": %.4f, \"add_co_chain_ns_per_wave_inst_per_simd_8waves\": %.4f, "
-               "\"lshl_add_u64_ns_per_wave_inst_per_simd_8waves\": %.4f, \"mov_b32_ns_per_wave_inst_per_simd_8waves\": %.4f, \"compute_units\": %d}\n",
+               "\"lshl_add_u64_ns_per_wave_inst_per_simd_8waves\": %.4f, \"mov_b32_ns_per_wave_inst_per_simd_8waves\": %.4f, "
+               "\"mix_75pct_mad_ns_per_wave_inst_per_simd\": %.4f, \"mix_50pct_mad_ns_per_wave_inst_per_simd\": %.4f, \"compute_units\": %d}\n",
                ns_per_inst_per_simd<1>(4), ns_per_inst_per_simd<1>(8), ns_per_inst_per_simd<0>(4), ns_per_inst_per_simd<6>(8),
-               ns_per_inst_per_simd<3>(8), ns_per_inst_per_simd<2>(8), cus);
+               ns_per_inst_per_simd<3>(8), ns_per_inst_per_simd<2>(8),
+               fmin(fmin(ns_per_inst_per_simd<7>(2), ns_per_inst_per_simd<7>(4)), ns_per_inst_per_simd<7>(8)),
+               fmin(fmin(ns_per_inst_per_simd<8>(2), ns_per_inst_per_simd<8>(4)), ns_per_inst_per_simd<8>(8)), cus);
         return 0;
     }
     for (int w : {1, 2, 3, 4}) {
