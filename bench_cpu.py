@@ -7,13 +7,43 @@ import os
 import time
 
 
+def effective_cores():
+    """CPUs this process can actually use: the smaller of the visible CPUs, the affinity mask and the cgroup CPU quota.  The GPU
+    boxes of this build show 256 CPUs (2 x EPYC 9575F) behind a quota of 16 (`cpu.max` = 1600000 100000): 256 threads there are
+    sixteen cores' worth of time slices, and rounds 1-4 reported `cores: 256` for what 16 could do."""
+    n = os.cpu_count() or 1
+    info = {"visible_cpus": n}
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            info["cgroup_cpu_max"] = "%s %s" % (quota, period)
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except Exception:
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            info["cgroup_cfs_quota"] = "%d %d" % (q, per)
+            n = min(n, max(1, q // per))
+    except Exception:
+        pass
+    return n, info
+
+
 def cpu_baseline_prove(wl, srs, budget_s: float = 20.0, threads: int = 0):
     from algoplonk_amd import frontend
     from oracle import c_oracle
 
     lib = c_oracle.load()
     cv = wl.curve
-    cores = threads or (os.cpu_count() or 1)
+    eff, cpu_info = effective_cores()
+    cores = threads or eff
     tr = frontend.build_trace(wl.ccs)
     L, R, O = frontend.wire_columns(wl.ccs, wl.solution)
     cols = [cv.fr_vector(x) for x in (tr.ql, tr.qr, tr.qm, tr.qo, tr.qk)]
@@ -42,7 +72,7 @@ def cpu_baseline_prove(wl, srs, budget_s: float = 20.0, threads: int = 0):
     rc, fblob, _ = fp.prove(*pargs, threads=cores)
     if rc != 0 or fblob != blob:
         raise RuntimeError("the fast host prover disagrees with the oracle (rc %d)" % rc)
-    plans = [p for p in (1, 4, 16, 64) if p <= max(1, cores // 2)] or [1]
+    plans = [p for p in (1, 2, 4, 8) if p <= max(1, cores // 2)] or [1]
     best = None
     slice_s = max(2.0, (budget_s - plain_s - setup_s) / len(plans))
     for P in plans:
@@ -79,9 +109,9 @@ def cpu_baseline_prove(wl, srs, budget_s: float = 20.0, threads: int = 0):
     rate, P, per, done, el = best
     return {"value": round(rate, 5), "unit": "proofs/sec", "cores": cores, "kind": "port",
             "sample": "%d proof(s) of the same %s in %.1f s, oracle/fast_prover.c (batch-affine Pippenger, parallel FFTs, circuit-only work "
-                      "hoisted: %.1f s once): %d concurrent proofs x %d pthreads (best of %s); every proof's bytes = the clarity-first oracle's"
-                      % (done, wl.name, el, setup_s, P, per, [t["concurrent_proofs"] for t in tried[1:]]),
-            "tried": tried, "proof_sha256_prefix": sha}
+                      "hoisted: %.1f s once): %d concurrent proofs x %d pthreads on %d usable cores (best of %s); every proof's bytes = the "
+                      "clarity-first oracle's" % (done, wl.name, el, setup_s, P, per, cores, [t["concurrent_proofs"] for t in tried[1:]]),
+            "tried": tried, "proof_sha256_prefix": sha, "cpu": cpu_info}
 
 
 def cpu_baseline_msm(cv, bases: bytes, scalars: bytes, n: int, budget_s: float = 20.0, threads: int = 0):
@@ -91,7 +121,8 @@ def cpu_baseline_msm(cv, bases: bytes, scalars: bytes, n: int, budget_s: float =
     from oracle import c_oracle
 
     lib = c_oracle.load()
-    cores = threads or (os.cpu_count() or 1)
+    eff, cpu_info = effective_cores()
+    cores = threads or eff
     out, ref = C.create_string_buffer(2 * cv.fp_bytes), C.create_string_buffer(2 * cv.fp_bytes)
     # the clarity-first Pippenger once (the checker and the lower bracket), then the performance-first one (oracle/fast_msm_tmpl.h:
     # batch-affine, signed digits, thread pool) for the budget
@@ -111,5 +142,5 @@ def cpu_baseline_msm(cv, bases: bytes, scalars: bytes, n: int, budget_s: float =
     return {"value": round(done * n / el / 1e6, 4), "unit": "Mscalar/s", "cores": cores, "kind": "port",
             "sample": "%d MSM(s) of 2^%d pairs in %.1f s, oracle/fast_msm_tmpl.h (batch-affine Pippenger) with %d pthreads; the clarity-first "
                       "orc_msm took %.2f s for one and gives the same point" % (done, n.bit_length() - 1, el, cores, plain_s),
-            "clarity_first_mscalar_per_s": round(n / plain_s / 1e6, 4),
+            "clarity_first_mscalar_per_s": round(n / plain_s / 1e6, 4), "cpu": cpu_info,
             "result": out.raw}

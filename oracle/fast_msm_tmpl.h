@@ -115,12 +115,19 @@ static void CN(fm_task)(void* arg, int t) {
     const size_t nbk = (size_t)1 << (c - 1);
     const size_t per = (J->n + J->nchunk - 1) / J->nchunk;
     const size_t lo = (size_t)ch * per < J->n ? (size_t)ch * per : J->n, hi = lo + per < J->n ? lo + per : J->n;
-    CN(fm_acc)* A = (CN(fm_acc)*)malloc(sizeof(CN(fm_acc)));
-    A->B = (CN(aff)*)calloc(nbk, sizeof(CN(aff)));
-    A->in_batch = (uint8_t*)calloc(nbk, 1);
+    /* the task's working set lives in the WORKER's scratch (fp_scratch: grown once per thread, reused by every task it runs):
+     * a malloc / free of a few hundred KB per task is an mmap / munmap pair, and with 256 threads of one process in them the
+     * kernel's address-space lock was where the time went (64 concurrent proofs took 41 s each before this) */
+    const size_t need = sizeof(CN(fm_acc)) + nbk * sizeof(CN(aff)) + nbk + FM_QUEUE * (sizeof(uint32_t) + sizeof(CN(aff))) + 256;
+    uint8_t* mem = (uint8_t*)fp_scratch(need);
+    CN(fm_acc)* A = (CN(fm_acc)*)mem; mem += (sizeof(CN(fm_acc)) + 63) & ~(size_t)63;
+    A->B = (CN(aff)*)mem; mem += nbk * sizeof(CN(aff));
+    uint32_t* qk = (uint32_t*)mem; mem += FM_QUEUE * sizeof(uint32_t);
+    CN(aff)* qp = (CN(aff)*)mem; mem += FM_QUEUE * sizeof(CN(aff));
+    A->in_batch = mem;
+    memset(A->B, 0, nbk * sizeof(CN(aff)));
+    memset(A->in_batch, 0, nbk);
     A->nb = 0;
-    uint32_t* qk = (uint32_t*)malloc(FM_QUEUE * sizeof(uint32_t));
-    CN(aff)* qp = (CN(aff)*)malloc(FM_QUEUE * sizeof(CN(aff)));
     int nq = 0;
     for (size_t i = lo; i < hi; i++) {
         if (CN(aff_is_inf)(&J->pts[i])) continue;
@@ -162,7 +169,6 @@ static void CN(fm_task)(void* arg, int t) {
         CN(jac_add)(F, &sum, &sum, &run);
     }
     J->part[t] = sum;
-    free(qk); free(qp); free(A->B); free(A->in_batch); free(A);
 }
 
 /* window width for `threads` workers: the tasks (windows x chunks) should be a few per worker, and a task's bucket reduction

@@ -15,6 +15,9 @@
  * exact task graph.  The number it produces is reported as a PORT, never as gnark.
  */
 #include <stdatomic.h>
+#include <malloc.h>
+static void* fp_scratch(size_t need);
+static void fp_scratch_release(void);
 
 /* ---- persistent pool: run(fn, count) hands out task indices from an atomic counter; the caller takes part ---------------------- */
 typedef struct fp_pool {
@@ -39,7 +42,7 @@ static void* fp_worker(void* a) {
     pthread_mutex_lock(&P->mu);
     for (;;) {
         while (!P->stop && P->gen == seen) pthread_cond_wait(&P->wake, &P->mu);
-        if (P->stop) { pthread_mutex_unlock(&P->mu); return NULL; }
+        if (P->stop) { pthread_mutex_unlock(&P->mu); fp_scratch_release(); return NULL; }
         seen = P->gen;
         pthread_mutex_unlock(&P->mu);
         fp_drain(P);
@@ -74,6 +77,20 @@ static void fp_pool_run(fp_pool* P, task_fn fn, void* arg, int count) {
     while (P->active) pthread_cond_wait(&P->done, &P->mu);
     pthread_mutex_unlock(&P->mu);
 }
+
+/* per-thread scratch for the tasks' working sets: grows, is reused, is freed when a pool worker exits (the calling thread keeps
+ * its own for its lifetime) */
+static __thread void* fp_tls_mem;
+static __thread size_t fp_tls_cap;
+static void* fp_scratch(size_t need) {
+    if (fp_tls_cap < need) {
+        free(fp_tls_mem);
+        fp_tls_cap = need + need / 4 + 4096;
+        fp_tls_mem = malloc(fp_tls_cap);
+    }
+    return fp_tls_mem;
+}
+static void fp_scratch_release(void) { free(fp_tls_mem); fp_tls_mem = NULL; fp_tls_cap = 0; }
 
 /* ---- the fast MSM for both curves ------------------------------------------------------------------------------------------- */
 #define FPN(x) f4_##x
@@ -227,6 +244,11 @@ void orc_fast_free(fp_ctx* X) {
 
 int orc_fast_setup(const orc_circuit* C, int threads, fp_ctx** out) {
     orc_init();
+    {   /* many threads of ONE process allocate and free multi-megabyte buffers per proof: keep them inside malloc's arenas instead
+         * of an mmap / munmap pair each (the address-space lock serialises those across all threads) */
+        static int tuned = 0;
+        if (!tuned) { tuned = 1; mallopt(M_MMAP_THRESHOLD, 32 << 20); mallopt(M_TRIM_THRESHOLD, 1 << 30); mallopt(M_ARENA_MAX, 256);   /* 32 MiB = glibc's cap */ }
+    }
     const int cv = C->curve;
     if (cv != 0 && cv != 1) return 1;
     if (threads < 1) threads = 1;

@@ -7,6 +7,21 @@ from algoplonk_amd import ecc, frontend, plonk as ap_plonk, setup as ap_setup
 from oracle import curves as ocurves, plonk as oplonk
 from oracle.prng import SplitMix64
 
+def oracle_threads() -> int:
+    """pthreads for the C oracle: the CPUs this process may really use (the GPU boxes show 256 CPUs behind a cgroup quota of 16;
+    256 threads there are throttled time slices, not parallelism)."""
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 CURVES = {"bn254": (ecc.BN254, ocurves.BN254), "bls12-381": (ecc.BLS12_381, ocurves.BLS12_381)}
 
 

@@ -9,7 +9,7 @@ from algoplonk_amd._lib import lib, check
 from oracle import plonk as oplonk
 from oracle.prng import SplitMix64, tau_from_seed
 
-from helpers import CURVES, blinding, oracle_circuit_from_ccs, oracle_vk_from_product, random_chain_ccs
+from helpers import CURVES, blinding, oracle_circuit_from_ccs, oracle_vk_from_product, random_chain_ccs, oracle_threads
 
 pytestmark = pytest.mark.gpu
 
@@ -233,7 +233,7 @@ def test_full_size_proof_is_accepted_by_the_transcribed_verifier(gpu, cname, log
     rc, cblob, cch = c_oracle.prove(c_oracle.load(), cv.abi, n, wl.ccs.GetNbPublicVariables(), srs.g1,
                                     [cv.fr_vector(x) for x in (tr.ql, tr.qr, tr.qm, tr.qo, tr.qk)], tr.perm, cv.fr_vector(L),
                                     cv.fr_vector(R), cv.fr_vector(O), cv.fr_vector(wl.witness.public), cv.fr_vector(wl.blinding),
-                                    threads=os.cpu_count() or 1)
+                                    threads=oracle_threads())
     assert rc == 0 and blob == cblob
     ch = proof.challenges
     assert [ch[k] for k in ("gamma", "beta", "alpha", "zeta", "gamma_kzg")] == cch
@@ -249,7 +249,7 @@ def test_full_size_proof_is_accepted_by_the_transcribed_verifier(gpu, cname, log
     sc = cv.fr_vector([g.fr(cv.r) for _ in range(n + 3)])
     want, got = C.create_string_buffer(2 * cv.fp_bytes), C.create_string_buffer(2 * cv.fp_bytes)
     for length in (n + 3, n + 2, n):
-        assert clib.orc_msm(cv.abi, srs.g1, sc, length, os.cpu_count() or 1, want) == 0
+        assert clib.orc_msm(cv.abi, srs.g1, sc, length, oracle_threads(), want) == 0
         check(lib.apk_msm_g1(pk.ctx, 0, sc, length, got))
         assert got.raw == want.raw, ("msm", length)
     for which, size in ((0, n), (1, 4 * n)):
@@ -520,7 +520,7 @@ def test_largest_size_bls12_381_2p21_with_bsb22_proof_verifies(gpu):
     sc = bytes(raw)
     want, got = C.create_string_buffer(2 * cv.fp_bytes), C.create_string_buffer(2 * cv.fp_bytes)
     for length in (n + 3, n):
-        assert clib.orc_msm(cv.abi, srs.g1, sc, length, os.cpu_count() or 1, want) == 0
+        assert clib.orc_msm(cv.abi, srs.g1, sc, length, oracle_threads(), want) == 0
         check(lib.apk_msm_g1(pk.ctx, 0, sc, length, got))
         assert got.raw == want.raw, ("msm at 2^21", length)
     pk.close()
@@ -786,7 +786,7 @@ def test_proofs_under_load_match_the_c_oracle(gpu, cname, log_n):
     rc, want, _ = c_oracle.prove(c_oracle.load(), cv.abi, n, wl.ccs.GetNbPublicVariables(), srs.g1,
                                  [cv.fr_vector(x) for x in (tr.ql, tr.qr, tr.qm, tr.qo, tr.qk)], tr.perm, cv.fr_vector(L),
                                  cv.fr_vector(R), cv.fr_vector(O), cv.fr_vector(wl.witness.public), cv.fr_vector(wl.blinding),
-                                 threads=os.cpu_count() or 1)
+                                 threads=oracle_threads())
     assert rc == 0
     dptr = []
     for b in (cv.fr_vector(v) for v in (L, R, O)):

@@ -13,7 +13,7 @@ from algoplonk_amd._lib import lib, check
 from oracle import c_oracle, plonk as oplonk
 from oracle.prng import SplitMix64, tau_from_seed
 
-from helpers import CURVES
+from helpers import CURVES, oracle_threads
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
@@ -97,7 +97,7 @@ def test_real_ethereum_srs_2p14_matches_c_oracle(gpu):
     rc, cblob, _ = c_oracle.prove(clib, cv.abi, n, wl.ccs.GetNbPublicVariables(), srs.g1,
                                   [cv.fr_vector(x) for x in (tr.ql, tr.qr, tr.qm, tr.qo, tr.qk)], tr.perm, cv.fr_vector(L),
                                   cv.fr_vector(R), cv.fr_vector(O), cv.fr_vector(wl.witness.public), cv.fr_vector(wl.blinding),
-                                  threads=os.cpu_count() or 1)
+                                  threads=oracle_threads())
     assert rc == 0 and blob == cblob
     # (1b) the transcribed verifier accepts it with the REAL pairing check against the G2 points of the ceremony's
     # vk.bin (templateLogicSigBLS12_381.go:366-371) - nobody knows tau here
