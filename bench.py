@@ -709,7 +709,7 @@ def bench_prove(args, cv, rk) -> None:
                         # commitment (one sparse Lagrange-basis MSM, one more polynomial through rounds 1 / 3 / 4: ~4 % of a proof's
                         # work) - said in `sample`; no proof hash to compare
                         wl_cpu = workloads.random_circuit(cv, args.log_n, seed)
-                        cpu_baseline = cpu_baseline_prove(wl_cpu, srs, args.cpu_baseline_seconds)
+                        cpu_baseline = cpu_baseline_prove(wl_cpu, srs, args.cpu_baseline_seconds, check_against_plain=args.log_n <= 18)
                         cpu_baseline["sample"] += "; WITHOUT the BSB22 commitment of the GPU's workload (the ports have no BSB22 path)"
                         cpu_baseline.pop("proof_sha256_prefix", None)
                     else:
