@@ -166,6 +166,7 @@ class CurveBackend : public Backend {
         // moment the batch's accumulate kernel is done, beside the reduction tail that would otherwise have the GPU to itself
         hipStream_t side = nullptr;
         hipEvent_t ev_acc = nullptr, ev_side = nullptr;
+        hipEvent_t ev_sync = nullptr;   // blocking-wait event (hipEventBlockingSync): the host thread sleeps instead of spinning
         int mark_acc = 0; bool side_pending = false;   // mark_acc: 1 = event behind the accumulate kernel, 2 = in front of the batch
     };
 
@@ -260,6 +261,7 @@ class CurveBackend : public Backend {
             if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }
             if (s->ev_acc) (void)hipEventDestroy(s->ev_acc);
             if (s->ev_side) (void)hipEventDestroy(s->ev_side);
+            if (s->ev_sync) (void)hipEventDestroy(s->ev_sync);
             if (s->stream) (void)hipStreamDestroy(s->stream);
             delete s;
         }
@@ -817,8 +819,25 @@ class CurveBackend : public Backend {
     int side_begin(Slot& s) { HIPCHK(hipStreamWaitEvent(s.side, s.ev_acc, 0)); return APK_OK; }
     int side_end(Slot& s) { HIPCHK(hipEventRecord(s.ev_side, s.side)); s.side_pending = true; return APK_OK; }
 
-    int sync_results(Slot& s) {
+    // Wait for the slot's stream.  hipStreamSynchronize spins on the host (ROCm's default with many CPUs visible): right for a lone
+    // proof (its six waits are on the critical path), wrong when 16 proving threads spin at once - on the GPU boxes of this build
+    // the container's CPU quota is 16 cores for 256 visible CPUs, and N ranks of an N-GPU node share whatever the node grants.
+    // With other proofs in flight the thread therefore SLEEPS on an event created with hipEventBlockingSync (the wake-up latency
+    // hides behind the other proofs).  APK_SYNC_BLOCKING: -1 by load (default), 0 never, 1 always.
+    int wait_stream(Slot& s) {
+        static const int mode = env_int("APK_SYNC_BLOCKING", -1, -1, 1);
+        const bool blocking = mode > 0 || (mode < 0 && slots_.size() > 2 && gate_.busy() > 2);
+        if (blocking && s.ev_sync) {
+            HIPCHK(hipEventRecord(s.ev_sync, s.stream));
+            HIPCHK(hipEventSynchronize(s.ev_sync));
+            return APK_OK;
+        }
         HIPCHK(hipStreamSynchronize(s.stream));
+        return APK_OK;
+    }
+
+    int sync_results(Slot& s) {
+        CHK(wait_stream(s));
         // whatever the main stream is handed from here on runs behind the side stream's transforms
         if (s.side_pending) { s.side_pending = false; HIPCHK(hipStreamWaitEvent(s.stream, s.ev_side, 0)); }
         if (s.hook_pending) {
@@ -861,6 +880,7 @@ class CurveBackend : public Backend {
         HIPCHK(hipEventCreate(&s.ev1));
         HIPCHK(hipEventCreate(&s.ev2));
         HIPCHK(hipEventCreate(&s.ev3));
+        if (hipEventCreateWithFlags(&s.ev_sync, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); s.ev_sync = nullptr; }
         HIPCHK(hipHostMalloc(&s.h_pinned, 4096, hipHostMallocDefault));
         const size_t fn = (size_t)n_ * sizeof(Fr), fn3 = (size_t)(n_ + 4) * sizeof(Fr), f4 = (size_t)n4_ * sizeof(Fr);
         if (msm_only_) {
