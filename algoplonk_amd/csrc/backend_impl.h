@@ -1298,7 +1298,7 @@ class CurveBackend : public Backend {
             a.scalars[b] = d_scalars[b]; a.len[b] = (uint32_t)lens[b]; a.offset[b] = (uint32_t)offsets[b];
         }
         CHK(run_msm(s, T, a, reinterpret_cast<Aff*>(s.h_pinned)));
-        HIPCHK(hipStreamSynchronize(s.stream));
+        CHK(wait_stream(s));
         const Pt* gsum = reinterpret_cast<const Pt*>(reinterpret_cast<const uint8_t*>(s.h_pinned) + 1024);
         for (uint32_t b = 0; b < count; b++) { const Aff r = gsum[b].to_affine(); memcpy(reinterpret_cast<uint8_t*>(out) + b * sizeof(Aff), &r, sizeof r); }
         s.pending_pts = 0;
