@@ -2,6 +2,8 @@
 # Same-box, interleaved comparison of two CHECKOUTS of the repo (each with its own built libapk.so and bench.py) - for comparing
 # rounds whose C-ABI differs (tools/ab_libs.sh swaps only the library under one bench.py).
 # usage: tools/ab_trees.sh ROUNDS "bench args" treeA treeB ...      (trees relative to the repo root; "." = this tree)
+# The other tree: `git worktree add ab/r04 <commit> && make -C ab/r04/algoplonk_amd/csrc -j3 && make -C ab/r04/oracle` (ab/ is
+# git-ignored and travels to the GPU box with the snapshot; `git worktree remove ab/r04` afterwards).
 R=$1; ARGS=$2; shift 2
 cd "$GRAFT_REPO_ROOT"
 for i in $(seq $R); do
