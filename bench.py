@@ -703,15 +703,12 @@ def bench_prove(args, cv, rk) -> None:
             cpu_baseline = gnark_cpu_baseline(probe, args.curve, args.log_n, args.cpu_baseline_seconds)
             if cpu_baseline is None:
                 try:
-                    from bench_cpu import cpu_baseline_prove
+                    from bench_cpu import cpu_baseline_prove, cpu_baseline_prove_ccs
                     if args.bsb22:
-                        # the host ports have no BSB22 path: they prove the random circuit of the SAME size and curve without the
-                        # commitment (one sparse Lagrange-basis MSM, one more polynomial through rounds 1 / 3 / 4: ~4 % of a proof's
-                        # work) - said in `sample`; no proof hash to compare
-                        wl_cpu = workloads.random_circuit(cv, args.log_n, seed)
-                        cpu_baseline = cpu_baseline_prove(wl_cpu, srs, args.cpu_baseline_seconds, check_against_plain=args.log_n <= 18)
-                        cpu_baseline["sample"] += "; WITHOUT the BSB22 commitment of the GPU's workload (the ports have no BSB22 path)"
-                        cpu_baseline.pop("proof_sha256_prefix", None)
+                        # the performance-first host prover has the BSB22 path (held to oracle/plonk.py by tests/test_oracle_c.py):
+                        # the GPU's very workload, commitments included - its proof hash is compared with the GPU's below
+                        cpu_baseline = cpu_baseline_prove_ccs(cv, name, ccs, srs, solution, witness.public, blinding, pi2_host,
+                                                              args.cpu_baseline_seconds)
                     else:
                         cpu_baseline = cpu_baseline_prove(wl, srs, args.cpu_baseline_seconds)
                 except Exception as e:  # the baseline is reported, never required for the GPU number

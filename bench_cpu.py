@@ -37,18 +37,32 @@ def effective_cores():
 
 
 def cpu_baseline_prove(wl, srs, budget_s: float = 20.0, threads: int = 0, check_against_plain: bool = True):
+    return cpu_baseline_prove_ccs(wl.curve, wl.name, wl.ccs, srs, wl.solution, wl.witness.public, wl.blinding, (), budget_s, threads,
+                                  check_against_plain)
+
+
+def cpu_baseline_prove_ccs(cv, name, ccs, srs, solution, public, blinding, pi2_cols=(), budget_s: float = 20.0, threads: int = 0,
+                           check_against_plain: bool = True):
+    """The same leg for any constraint system, BSB22 commitments included (`pi2_cols` = the committed columns the solver made:
+    the performance-first prover recomputes their commitments over the Lagrange SRS and must arrive at the GPU's bytes; the
+    clarity-first C oracle has no BSB22 path, so it is skipped there)."""
     from algoplonk_amd import frontend
     from oracle import c_oracle
 
     lib = c_oracle.load()
-    cv = wl.curve
     eff, cpu_info = effective_cores()
     cores = threads or eff
-    tr = frontend.build_trace(wl.ccs)
-    L, R, O = frontend.wire_columns(wl.ccs, wl.solution)
+    tr = frontend.build_trace(ccs)
+    L, R, O = frontend.wire_columns(ccs, solution)
     cols = [cv.fr_vector(x) for x in (tr.ql, tr.qr, tr.qm, tr.qo, tr.qk)]
-    args = (lib, cv.abi, tr.n, wl.ccs.GetNbPublicVariables(), srs.g1, cols, tr.perm, cv.fr_vector(L), cv.fr_vector(R),
-            cv.fr_vector(O), cv.fr_vector(wl.witness.public), cv.fr_vector(wl.blinding))
+    nbc = len(ccs.commitments)
+    if nbc:
+        check_against_plain = False
+        if not srs.g1_lagrange:
+            raise RuntimeError("BSB22 circuit without a Lagrange SRS")
+    args = (lib, cv.abi, tr.n, ccs.GetNbPublicVariables(), srs.g1, cols, tr.perm, cv.fr_vector(L), cv.fr_vector(R),
+            cv.fr_vector(O), cv.fr_vector(public), cv.fr_vector(blinding))
+    pi2_b = [cv.fr_vector(p) for p in pi2_cols]
     # Two host provers, both ports (neither is gnark): the clarity-first orc_prove - the parity oracle, one proof for the hash and
     # as the lower bracket - and the performance-first orc_fast_prove (oracle/fast_prover.c: circuit-only work hoisted into a
     # context, batch-affine Pippenger, parallel FFTs, one-coset quotient), held to orc_prove's bytes by tests/test_oracle_c.py and
@@ -67,11 +81,13 @@ def cpu_baseline_prove(wl, srs, budget_s: float = 20.0, threads: int = 0, check_
         tried.append({"prover": "oracle/apk_oracle.c orc_prove (clarity-first)", "concurrent_proofs": 1, "threads_each": cores, "proofs": 1,
                       "seconds": round(plain_s, 2), "proofs_per_sec": round(1.0 / plain_s, 4)})
     t0 = time.perf_counter()
-    fp = c_oracle.FastProver(lib, cv.abi, tr.n, wl.ccs.GetNbPublicVariables(), srs.g1, cols, tr.perm, threads=cores)
+    fp = c_oracle.FastProver(lib, cv.abi, tr.n, ccs.GetNbPublicVariables(), srs.g1, cols, tr.perm, threads=cores,
+                             qcp=[cv.fr_vector(q) for q in tr.qcp[:nbc]], cci=[cidx for _, cidx in ccs.commitments],
+                             srs_lagrange=srs.g1_lagrange if nbc else None)
     setup_s = time.perf_counter() - t0
     pargs = args[7:]
     t0 = time.perf_counter()
-    rc, fblob, _ = fp.prove(*pargs, threads=cores)
+    rc, fblob, _ = fp.prove(*pargs, threads=cores, pi2=pi2_b)
     first_s = time.perf_counter() - t0
     if rc != 0 or (blob is not None and fblob != blob):
         raise RuntimeError("the fast host prover disagrees with the oracle (rc %d)" % rc)
@@ -90,7 +106,7 @@ def cpu_baseline_prove(wl, srs, budget_s: float = 20.0, threads: int = 0, check_
 
         def worker(i, per=per, stop=stop):
             while True:
-                rc_, b_, _ = fp.prove(*pargs, threads=per)
+                rc_, b_, _ = fp.prove(*pargs, threads=per, pi2=pi2_b)
                 if rc_ != 0 or b_ != blob:
                     bad.append(rc_)
                     return
@@ -116,8 +132,10 @@ def cpu_baseline_prove(wl, srs, budget_s: float = 20.0, threads: int = 0, check_
     rate, P, per, done, el = best
     return {"value": round(rate, 5), "unit": "proofs/sec", "cores": cores, "kind": "port",
             "sample": "%d proof(s) of the same %s in %.1f s, oracle/fast_prover.c (batch-affine Pippenger, parallel FFTs, circuit-only work "
-                      "hoisted: %.1f s once): %d concurrent proofs x %d pthreads on %d usable cores (best of %s); every proof's bytes = the "
-                      "clarity-first oracle's" % (done, wl.name, el, setup_s, P, per, cores, [t["concurrent_proofs"] for t in tried[1:]]),
+                      "hoisted: %.1f s once): %d concurrent proofs x %d pthreads on %d usable cores (best of %s); %s"
+                      % (done, name, el, setup_s, P, per, cores, [t["concurrent_proofs"] for t in tried if "fast" in t["prover"]],
+                         "every proof's bytes = the clarity-first oracle's" if check_against_plain else
+                         "every proof's bytes = its first proof's (the clarity-first oracle was not run: size, or a BSB22 circuit it has no path for)"),
             "tried": tried, "proof_sha256_prefix": sha, "cpu": cpu_info}
 
 

@@ -201,6 +201,35 @@ static void fp_scale(int curve, fr_t* a, size_t n, const fr_t* tab, const fr_t* 
     fp_pool_run(pool, fp_scale_task, &J, (int)((n + J.per - 1) / J.per));
 }
 
+#define FP_MAX_INJ 10
+/* orc_circuit + the BSB22 part of gnark's trace and proving key */
+typedef struct {
+    orc_circuit base;
+    uint32_t nb_commit;                /* <= 2 */
+    uint32_t cci[2];                   /* VK CommitmentConstraintIndexes */
+    const void* qcp[2];                /* Lagrange, n Fr each */
+    const void* srs_lagrange;          /* n G1 affine */
+} orc_circuit_ex;
+
+/* gnark fr.Hash(msg, "BSB22-Plonk", 1) = expand_msg_xmd(sha256, 48 bytes) mod r, as the verifier recomputes it
+ * (templateLogicSigBN254.go:386-397) */
+static void fp_hash_fr(const fr_field* F, fr_t* out, const uint8_t* msg, size_t len) {
+    static const uint8_t dst_prime[12] = {'B', 'S', 'B', '2', '2', '-', 'P', 'l', 'o', 'n', 'k', 0x0b};
+    const uint8_t zeros[64] = {0}, lib[3] = {0x00, 0x30, 0x00}, one = 1, two = 2;
+    uint8_t b0[32], b1[32], b2[32], x[32], lo[32] = {0};
+    sha_t h;
+    sha_init(&h); sha_update(&h, zeros, 64); sha_update(&h, msg, len); sha_update(&h, lib, 3); sha_update(&h, dst_prime, 12); sha_final(&h, b0);
+    sha_init(&h); sha_update(&h, b0, 32); sha_update(&h, &one, 1); sha_update(&h, dst_prime, 12); sha_final(&h, b1);
+    for (int i = 0; i < 32; i++) x[i] = b0[i] ^ b1[i];
+    sha_init(&h); sha_update(&h, x, 32); sha_update(&h, &two, 1); sha_update(&h, dst_prime, 12); sha_final(&h, b2);
+    memcpy(lo + 16, b2, 16);
+    fr_t hi, lw, t128, t; memset(&t, 0, sizeof t); t.l[2] = 1;       /* 2^128 */
+    f4_to_mont(F, &t128, &t);
+    fr_from_be_reduce(F, &hi, b1); fr_from_be_reduce(F, &lw, lo);
+    f4_mul(F, &hi, &hi, &t128);
+    f4_add(F, out, &hi, &lw);
+}
+
 /* ---- the context: what depends on the circuit only ---------------------------------------------------------------------------- */
 enum { FQL, FQR, FQM, FQO, FQK, FS1, FS2, FS3, FNTRACE };
 typedef struct fp_ctx {
@@ -215,9 +244,16 @@ typedef struct fp_ctx {
     fr_t* tc[FNTRACE];             /* canonical */
     fr_t* te[FNTRACE];             /* on the 4n coset (Qk: trace only, public rows zero) */
     fr_t* l0e;                     /* L_0 on the coset */
-    fr_t* lpub_e[8];               /* L_i on the coset for the public rows i < nb_public (<= 8; more: Qk is re-transformed per proof) */
+    /* rows of Qk a proof writes: the public inputs 0 .. nb_public-1, then nb_public + cci_k for the BSB22 commitments; their
+     * Lagrange polynomials on the coset (row 0 = l0e) complete Qk inside the quotient loop */
+    int n_inj; uint32_t inj_row[FP_MAX_INJ]; fr_t* inj_e[FP_MAX_INJ];
     fr_t zhinv[4];
     uint8_t vk_pt[FNTRACE][96], vkb[FNTRACE][96];
+    /* BSB22 (bsb22_test.go:18-39; templateLogicSigBN254.go:386-397): Qcp_k canonical / on the coset / committed, the Lagrange SRS */
+    uint32_t nb_commit, cci[2];
+    void* srs_lag;
+    fr_t *qcp_c[2], *qcp_e[2];
+    uint8_t qcp_pt[2][96], qcp_b[2][96];
 } fp_ctx;
 
 static fr_t* fp_alloc(size_t n) { return (fr_t*)calloc(n, sizeof(fr_t)); }
@@ -236,13 +272,22 @@ static void fp_ifft_n(const fp_ctx* X, fr_t* a, fp_pool* pool, int threads) {
 
 void orc_fast_free(fp_ctx* X) {
     if (!X) return;
-    free(X->srs); free(X->w0); free(X->w0i); free(X->w1); free(X->w1i); free(X->upow); free(X->uinv_pow); free(X->omega_pow); free(X->l0e);
+    free(X->srs); free(X->w0); free(X->w0i); free(X->w1); free(X->w1i); free(X->upow); free(X->uinv_pow); free(X->omega_pow);
     for (int i = 0; i < FNTRACE; i++) { free(X->tl[i]); free(X->tc[i]); free(X->te[i]); }
-    for (int i = 0; i < 8; i++) free(X->lpub_e[i]);
+    for (int i = 0; i < X->n_inj; i++) if (X->inj_e[i] != X->l0e) free(X->inj_e[i]);
+    free(X->l0e); free(X->srs_lag);
+    for (int k = 0; k < 2; k++) { free(X->qcp_c[k]); free(X->qcp_e[k]); }
     free(X);
 }
 
+int orc_fast_setup_ex(const orc_circuit_ex* E, int threads, fp_ctx** out);
 int orc_fast_setup(const orc_circuit* C, int threads, fp_ctx** out) {
+    orc_circuit_ex E; memset(&E, 0, sizeof E); E.base = *C;
+    return orc_fast_setup_ex(&E, threads, out);
+}
+int orc_fast_setup_ex(const orc_circuit_ex* E, int threads, fp_ctx** out) {
+    const orc_circuit* C = &E->base;
+    if (E->nb_commit > 2 || (E->nb_commit && !E->srs_lagrange) || C->nb_public + E->nb_commit > FP_MAX_INJ) return 2;
     orc_init();
     {   /* many threads of ONE process allocate and free multi-megabyte buffers per proof: keep them inside malloc's arenas instead
          * of an mmap / munmap pair each (the address-space lock serialises those across all threads) */
@@ -287,16 +332,34 @@ int orc_fast_setup(const orc_circuit* C, int threads, fp_ctx** out) {
         fp_commit(cv, X->srs, X->tc[i], n, pool, threads, X->vk_pt[i]);
         g1_raw(cv, X->vk_pt[i], X->vkb[i]);
     }
-    /* L_0 and the Lagrange polynomials of the public rows on the coset: L_r(X) = (1/n) sum_i omega^(-r i) X^i */
+    /* BSB22: Qcp_k canonical, on the coset, committed; the Lagrange SRS */
+    X->nb_commit = E->nb_commit;
+    if (E->nb_commit) { X->srs_lag = malloc(n * PT); memcpy(X->srs_lag, E->srs_lagrange, n * PT); }
+    for (uint32_t k = 0; k < E->nb_commit; k++) {
+        X->cci[k] = E->cci[k];
+        X->qcp_c[k] = fp_alloc(n); X->qcp_e[k] = fp_alloc(n4);
+        memcpy(X->qcp_c[k], E->qcp[k], n * sizeof(fr_t));
+        fp_ifft_n(X, X->qcp_c[k], pool, threads);
+        fp_coset_eval(X, X->qcp_c[k], n, X->qcp_e[k], pool, threads);
+        fp_commit(cv, X->srs, X->qcp_c[k], n, pool, threads, X->qcp_pt[k]);
+        g1_raw(cv, X->qcp_pt[k], X->qcp_b[k]);
+    }
+    /* L_0 and the Lagrange polynomials of the written rows on the coset: L_r(X) = (1/n) sum_i omega^(-r i) X^i */
     fr_t* tmp = fp_alloc(n);
     X->l0e = fp_alloc(n4);
     for (size_t i = 0; i < n; i++) tmp[i] = X->ninv;
     fp_coset_eval(X, tmp, n, X->l0e, pool, threads);
-    for (uint32_t r = 1; r < C->nb_public && r < 8; r++) {
+    X->n_inj = 0;
+    for (uint32_t r = 0; r < C->nb_public; r++) X->inj_row[X->n_inj++] = r;
+    for (uint32_t k = 0; k < E->nb_commit; k++) X->inj_row[X->n_inj++] = C->nb_public + E->cci[k];
+    for (int j = 0; j < X->n_inj; j++) {
+        const uint32_t r = X->inj_row[j];
+        if (r >= n) { free(tmp); fp_pool_destroy(pool); orc_fast_free(X); return 2; }
+        if (r == 0) { X->inj_e[j] = X->l0e; continue; }
         fr_t wr, cur = X->ninv; f4_inv(F, &wr, &X->omega_pow[r]);
         for (size_t i = 0; i < n; i++) { tmp[i] = cur; f4_mul(F, &cur, &cur, &wr); }
-        X->lpub_e[r] = fp_alloc(n4);
-        fp_coset_eval(X, tmp, n, X->lpub_e[r], pool, threads);
+        X->inj_e[j] = fp_alloc(n4);
+        fp_coset_eval(X, tmp, n, X->inj_e[j], pool, threads);
     }
     free(tmp);
     {
@@ -332,7 +395,7 @@ static void fp_gp_terms_task(void* arg, int t) {
 }
 
 typedef struct {
-    const fp_ctx* X; fr_t *el, *er, *eo, *ez, *h; fr_t alpha, a2, beta, gamma, bu, bu2; fr_t delta[8]; size_t per;
+    const fp_ctx* X; fr_t *el, *er, *eo, *ez, *h; fr_t alpha, a2, beta, gamma, bu, bu2; fr_t delta[FP_MAX_INJ]; fr_t* epi2[2]; size_t per;
 } fp_quot_job;
 static void fp_quot_task(void* arg, int t) {
     fp_quot_job* Q = (fp_quot_job*)arg;
@@ -344,12 +407,13 @@ static void fp_quot_task(void* arg, int t) {
         const fr_t l = Q->el[i], r = Q->er[i], o = Q->eo[i], z = Q->ez[i], zs = Q->ez[(i + 4) % n4];
         fr_t gate, tt, lg, rg, og, pa, pb, a, b, c, loc, num, qk = X->te[FQK][i];
         /* completed Qk = trace Qk + sum_r (pub_r - trace Qk[r]) L_r */
-        for (uint32_t rr = 0; rr < X->nb_public; rr++) { f4_mul(F, &tt, &Q->delta[rr], rr == 0 ? &X->l0e[i] : &X->lpub_e[rr][i]); f4_add(F, &qk, &qk, &tt); }
+        for (int rr = 0; rr < X->n_inj; rr++) { f4_mul(F, &tt, &Q->delta[rr], &X->inj_e[rr][i]); f4_add(F, &qk, &qk, &tt); }
         f4_mul(F, &gate, &X->te[FQL][i], &l);
         f4_mul(F, &tt, &X->te[FQR][i], &r); f4_add(F, &gate, &gate, &tt);
         f4_mul(F, &tt, &l, &r); f4_mul(F, &tt, &tt, &X->te[FQM][i]); f4_add(F, &gate, &gate, &tt);
         f4_mul(F, &tt, &X->te[FQO][i], &o); f4_add(F, &gate, &gate, &tt);
         f4_add(F, &gate, &gate, &qk);
+        for (uint32_t k = 0; k < X->nb_commit; k++) { f4_mul(F, &tt, &X->qcp_e[k][i], &Q->epi2[k][i]); f4_add(F, &gate, &gate, &tt); }
         f4_add(F, &lg, &l, &Q->gamma); f4_add(F, &rg, &r, &Q->gamma); f4_add(F, &og, &o, &Q->gamma);
         f4_mul(F, &tt, &Q->beta, &X->te[FS1][i]); f4_add(F, &a, &lg, &tt);
         f4_mul(F, &tt, &Q->beta, &X->te[FS2][i]); f4_add(F, &b, &rg, &tt);
@@ -391,7 +455,7 @@ static void fp_poly_eval(int curve, fr_t* r, const fr_t* c, size_t len, const fr
 }
 
 /* sum_i k_i P_i for a handful of points (the [lin] combination): plain double-and-add, Jacobian */
-static void fp_small_msm(int cv, const uint8_t (*pts)[96], const fr_t* ks, int count, void* out_aff) {
+static void fp_small_msm(int cv, uint8_t (*pts)[96], const fr_t* ks, int count, void* out_aff) {
     const fr_field* F = &FR[cv];
     if (cv == 0) {
         bn_jac acc; bn_jac_set_inf(&FP_BN, &acc);
@@ -425,19 +489,39 @@ static void fp_lc_task(void* arg, int t) {       /* out[i] = sum_k ks[k] ps[k][i
     }
 }
 
-/* plonk.Prove (algoplonk.go:89) on a prepared context; the bytes of orc_prove */
+/* plonk.Prove (algoplonk.go:89) on a prepared context; the bytes of orc_prove (and, with commitments, of oracle/plonk.py).
+ * pi2[k] = the BSB22 committed columns (Lagrange, n Fr each, hiding entries placed) */
+int orc_fast_prove_ex(const fp_ctx* X, const void* Lp, const void* Rp, const void* Op, const void* pubp, const void* blindp,
+                      const void* const* pi2p, int threads, uint8_t* blob, uint64_t* blob_len, uint8_t* challenges_out);
 int orc_fast_prove(const fp_ctx* X, const void* Lp, const void* Rp, const void* Op, const void* pubp, const void* blindp, int threads,
                    uint8_t* blob, uint64_t* blob_len, uint8_t* challenges_out) {
+    return orc_fast_prove_ex(X, Lp, Rp, Op, pubp, blindp, NULL, threads, blob, blob_len, challenges_out);
+}
+int orc_fast_prove_ex(const fp_ctx* X, const void* Lp, const void* Rp, const void* Op, const void* pubp, const void* blindp,
+                      const void* const* pi2p, int threads, uint8_t* blob, uint64_t* blob_len, uint8_t* challenges_out) {
     const int cv = X->curve;
     const fr_field* F = &FR[cv];
     if (threads < 1) threads = 1;
-    if (X->nb_public > 8) return 2;          /* the fast path completes Qk through the public rows' Lagrange polynomials (<= 8 of them) */
+    const uint32_t nbc = X->nb_commit;
+    if (nbc && !pi2p) return 2;
     const size_t n = X->n, n4 = 4 * n, PT = g1_size(cv);
     const fr_t *L = (const fr_t*)Lp, *R = (const fr_t*)Rp, *O = (const fr_t*)Op, *pub = (const fr_t*)pubp, *bl = (const fr_t*)blindp;
     fp_pool* pool = fp_pool_create(threads);
     const fr_t u = X->u; fr_t u2; f4_sqr(F, &u2, &u);
 
-    /* ---- round 1 ---- */
+    /* ---- round 1: BSB22 commitments (kzg.Commit over the Lagrange SRS, hash to a field element), wires ---- */
+    uint8_t bsb_pt[2][96], bsb_b[2][96];
+    fr_t cval[2];
+    fr_t *pi2c[2] = {NULL, NULL}, *epi2[2] = {NULL, NULL};
+    for (uint32_t k = 0; k < nbc; k++) {
+        fp_commit(cv, X->srs_lag, (const fr_t*)pi2p[k], n, pool, threads, bsb_pt[k]);
+        g1_raw(cv, bsb_pt[k], bsb_b[k]);
+        fp_hash_fr(F, &cval[k], bsb_b[k], PT);
+        pi2c[k] = fp_alloc(n); epi2[k] = fp_alloc(n4);
+        memcpy(pi2c[k], pi2p[k], n * sizeof(fr_t));
+        fp_ifft_n(X, pi2c[k], pool, threads);
+        fp_coset_eval(X, pi2c[k], n, epi2[k], pool, threads);
+    }
     fr_t* wc[4];
     for (int j = 0; j < 4; j++) wc[j] = fp_alloc(n + 3);
     memcpy(wc[0], L, n * sizeof(fr_t)); memcpy(wc[1], R, n * sizeof(fr_t)); memcpy(wc[2], O, n * sizeof(fr_t));
@@ -450,9 +534,13 @@ int orc_fast_prove(const fp_ctx* X, const void* Lp, const void* Rp, const void* 
     for (uint32_t i = 0; i < X->nb_public; i++) fr_to_be(F, &pub[i], pub_b + 32 * i);
     uint8_t gamma_raw[32], beta_raw[32], alpha_raw[32], zeta_raw[32];
     {
-        const uint8_t* parts[12] = {X->vkb[FS1], X->vkb[FS2], X->vkb[FS3], X->vkb[FQL], X->vkb[FQR], X->vkb[FQM], X->vkb[FQO], X->vkb[FQK], pub_b, lro_b[0], lro_b[1], lro_b[2]};
-        size_t lens[12] = {PT, PT, PT, PT, PT, PT, PT, PT, (size_t)X->nb_public * 32, PT, PT, PT};
-        challenge("gamma", NULL, parts, lens, 12, gamma_raw);
+        const uint8_t* parts[14]; size_t lens[14]; int np = 0;
+        const uint8_t* head[8] = {X->vkb[FS1], X->vkb[FS2], X->vkb[FS3], X->vkb[FQL], X->vkb[FQR], X->vkb[FQM], X->vkb[FQO], X->vkb[FQK]};
+        for (int i = 0; i < 8; i++) { parts[np] = head[i]; lens[np++] = PT; }
+        for (uint32_t k = 0; k < nbc; k++) { parts[np] = X->qcp_b[k]; lens[np++] = PT; }
+        parts[np] = pub_b; lens[np++] = (size_t)X->nb_public * 32;
+        for (int j = 0; j < 3; j++) { parts[np] = lro_b[j]; lens[np++] = PT; }
+        challenge("gamma", NULL, parts, lens, np, gamma_raw);
         challenge("beta", gamma_raw, NULL, NULL, 0, beta_raw);
     }
     fr_t gamma, beta; fr_from_be_reduce(F, &gamma, gamma_raw); fr_from_be_reduce(F, &beta, beta_raw);
@@ -476,7 +564,12 @@ int orc_fast_prove(const fp_ctx* X, const void* Lp, const void* Rp, const void* 
     for (int k = 0; k < 3; k++) { f4_sub(F, &wc[3][k], &wc[3][k], &bl[6 + k]); f4_add(F, &wc[3][n + k], &wc[3][n + k], &bl[6 + k]); }
     uint8_t z_pt[96], z_b[96];
     fp_commit(cv, X->srs, wc[3], n + 3, pool, threads, z_pt); g1_raw(cv, z_pt, z_b);
-    { const uint8_t* parts[1] = {z_b}; size_t lens[1] = {PT}; challenge("alpha", beta_raw, parts, lens, 1, alpha_raw); }
+    {
+        const uint8_t* parts[3]; size_t lens[3]; int np = 0;
+        for (uint32_t k = 0; k < nbc; k++) { parts[np] = bsb_b[k]; lens[np++] = PT; }
+        parts[np] = z_b; lens[np++] = PT;
+        challenge("alpha", beta_raw, parts, lens, np, alpha_raw);
+    }
     fr_t alpha; fr_from_be_reduce(F, &alpha, alpha_raw);
 
     /* ---- round 3: quotient on the coset (only l, r, o, Z are transformed: the trace sits there already) ---- */
@@ -486,13 +579,18 @@ int orc_fast_prove(const fp_ctx* X, const void* Lp, const void* Rp, const void* 
     {
         fp_quot_job Q; Q.X = X; Q.el = ew[0]; Q.er = ew[1]; Q.eo = ew[2]; Q.ez = ew[3]; Q.h = h;
         Q.alpha = alpha; f4_sqr(F, &Q.a2, &alpha); Q.beta = beta; Q.gamma = gamma; Q.bu = bu; Q.bu2 = bu2;
-        for (uint32_t r = 0; r < X->nb_public; r++) f4_sub(F, &Q.delta[r], &pub[r], &X->tl[FQK][r]);
+        for (int j = 0; j < X->n_inj; j++) {
+            const fr_t* written = (uint32_t)j < X->nb_public ? &pub[j] : &cval[j - X->nb_public];
+            f4_sub(F, &Q.delta[j], written, &X->tl[FQK][X->inj_row[j]]);
+        }
+        Q.epi2[0] = epi2[0]; Q.epi2[1] = epi2[1];
         Q.per = (n4 + (size_t)threads * 4 - 1) / ((size_t)threads * 4); if (Q.per < 256) Q.per = 256;
         fp_pool_run(pool, fp_quot_task, &Q, (int)((n4 + Q.per - 1) / Q.per));
         fp_fft(cv, h, n4, X->w1i, pool, threads);
         fp_scale(cv, h, n4, X->uinv_pow, NULL, pool, threads);
     }
     for (int j = 0; j < 4; j++) free(ew[j]);
+    for (uint32_t k = 0; k < nbc; k++) free(epi2[k]);
     int rc = 0;
     for (size_t i = 3 * (n + 2); i < n4; i++) if (!f4_is_zero(&h[i])) { rc = 4; break; }
     uint8_t h_pt[3][96], h_b[3][96];
@@ -507,6 +605,8 @@ int orc_fast_prove(const fp_ctx* X, const void* Lp, const void* Rp, const void* 
     fp_poly_eval(cv, &lz, wc[0], n + 2, &zeta, pool, threads); fp_poly_eval(cv, &rz, wc[1], n + 2, &zeta, pool, threads);
     fp_poly_eval(cv, &oz, wc[2], n + 2, &zeta, pool, threads);
     fp_poly_eval(cv, &s1z, X->tc[FS1], n, &zeta, pool, threads); fp_poly_eval(cv, &s2z, X->tc[FS2], n, &zeta, pool, threads);
+    fr_t qcpz[2];
+    for (uint32_t k = 0; k < nbc; k++) fp_poly_eval(cv, &qcpz[k], X->qcp_c[k], n, &zeta, pool, threads);
     fr_t* q2 = fp_alloc(n + 3);
     poly_div_linear(F, q2, wc[3], n + 3, &zw);
     fr_t a2, zn, lag0, c_s3, c_z, zn2, zn2sq, t, a, b, c;
@@ -520,10 +620,12 @@ int orc_fast_prove(const fp_ctx* X, const void* Lp, const void* Rp, const void* 
     fr_t linz;
     {
         fr_t piz; memset(&piz, 0, sizeof piz);
-        for (uint32_t r = 0; r < X->nb_public; r++) {   /* L_r(zeta) = omega^r (zeta^n - 1) / (n (zeta - omega^r)) */
+        for (int j = 0; j < X->n_inj; j++) {   /* L_r(zeta) = omega^r (zeta^n - 1) / (n (zeta - omega^r)) over the rows a proof writes */
+            const uint32_t r = X->inj_row[j];
+            const fr_t* written = (uint32_t)j < X->nb_public ? &pub[j] : &cval[j - X->nb_public];
             fr_t d, lr; f4_sub(F, &d, &zeta, &X->omega_pow[r]); f4_inv(F, &d, &d);
             f4_mul(F, &lr, &zn, &X->ninv); f4_mul(F, &lr, &lr, &X->omega_pow[r]); f4_mul(F, &lr, &lr, &d);
-            f4_mul(F, &lr, &lr, &pub[r]); f4_add(F, &piz, &piz, &lr);
+            f4_mul(F, &lr, &lr, written); f4_add(F, &piz, &piz, &lr);
         }
         fr_t og, prod; f4_add(F, &og, &oz, &gamma);
         f4_mul(F, &prod, &alpha, &zshift); f4_mul(F, &prod, &prod, &a); f4_mul(F, &prod, &prod, &b); f4_mul(F, &prod, &prod, &og);
@@ -542,24 +644,32 @@ int orc_fast_prove(const fp_ctx* X, const void* Lp, const void* Rp, const void* 
     f4_mul(F, &lr, &lz, &rz); f4_neg(F, &mz, &zn); f4_mul(F, &mz2, &mz, &zn2); f4_mul(F, &mz3, &mz, &zn2sq);
     uint8_t lin_pt[96], lin_b[96];
     {
-        uint8_t pts[10][96];
+        uint8_t pts[12][96];
         memcpy(pts[0], X->vk_pt[FQL], 96); memcpy(pts[1], X->vk_pt[FQR], 96); memcpy(pts[2], X->vk_pt[FQM], 96); memcpy(pts[3], X->vk_pt[FQO], 96);
         memcpy(pts[4], X->vk_pt[FQK], 96); memcpy(pts[5], X->vk_pt[FS3], 96); memcpy(pts[6], z_pt, 96); memcpy(pts[7], h_pt[0], 96);
         memcpy(pts[8], h_pt[1], 96); memcpy(pts[9], h_pt[2], 96);
-        const fr_t ks[10] = {lz, rz, lr, oz, one, c_s3, c_z, mz, mz2, mz3};
-        fp_small_msm(cv, (const uint8_t (*)[96])pts, ks, 10, lin_pt);
+        fr_t ks[12] = {lz, rz, lr, oz, one, c_s3, c_z, mz, mz2, mz3};
+        for (uint32_t k = 0; k < nbc; k++) { memcpy(pts[10 + k], bsb_pt[k], 96); ks[10 + k] = qcpz[k]; }
+        fp_small_msm(cv, pts, ks, 10 + (int)nbc, lin_pt);
         g1_raw(cv, lin_pt, lin_b);
     }
     uint8_t gk_raw[32];
-    fr_t claimed[6] = {linz, lz, rz, oz, s1z, s2z};
+    fr_t claimed[8] = {linz, lz, rz, oz, s1z, s2z};
+    for (uint32_t k = 0; k < nbc; k++) claimed[6 + k] = qcpz[k];
     {
-        uint8_t zeta_be[32], cvb[6][32], zsb[32];
+        uint8_t zeta_be[32], cvb[8][32], zsb[32];
         fr_to_be(F, &zeta, zeta_be);
-        for (int i = 0; i < 6; i++) fr_to_be(F, &claimed[i], cvb[i]);
+        for (uint32_t i = 0; i < 6 + nbc; i++) fr_to_be(F, &claimed[i], cvb[i]);
         fr_to_be(F, &zshift, zsb);
-        const uint8_t* parts[14] = {zeta_be, lin_b, lro_b[0], lro_b[1], lro_b[2], X->vkb[FS1], X->vkb[FS2], cvb[0], cvb[1], cvb[2], cvb[3], cvb[4], cvb[5], zsb};
-        size_t lens[14] = {32, PT, PT, PT, PT, PT, PT, 32, 32, 32, 32, 32, 32, 32};
-        challenge("gamma", NULL, parts, lens, 14, gk_raw);
+        const uint8_t* parts[20]; size_t lens[20]; int np = 0;
+        parts[np] = zeta_be; lens[np++] = 32;
+        parts[np] = lin_b; lens[np++] = PT;
+        for (int j = 0; j < 3; j++) { parts[np] = lro_b[j]; lens[np++] = PT; }
+        parts[np] = X->vkb[FS1]; lens[np++] = PT; parts[np] = X->vkb[FS2]; lens[np++] = PT;
+        for (uint32_t k = 0; k < nbc; k++) { parts[np] = X->qcp_b[k]; lens[np++] = PT; }
+        for (uint32_t i = 0; i < 6 + nbc; i++) { parts[np] = cvb[i]; lens[np++] = 32; }
+        parts[np] = zsb; lens[np++] = 32;
+        challenge("gamma", NULL, parts, lens, np, gk_raw);
     }
     fr_t gk; fr_from_be_reduce(F, &gk, gk_raw);
     /* folded = lin + gk l + gk^2 r + gk^3 o + gk^4 S1 + gk^5 S2 in one pass over lin's constituents */
@@ -568,11 +678,18 @@ int orc_fast_prove(const fp_ctx* X, const void* Lp, const void* Rp, const void* 
         fr_t g1 = gk, g2, g3, g4, g5;
         f4_mul(F, &g2, &g1, &gk); f4_mul(F, &g3, &g2, &gk); f4_mul(F, &g4, &g3, &gk); f4_mul(F, &g5, &g4, &gk);
         /* (lin takes the TRACE's Qk, the polynomial behind the verifying key's [Qk]; the public inputs enter through PI(zeta)) */
-        const fr_t* ps[15] = {X->tc[FQL], X->tc[FQR], X->tc[FQM], X->tc[FQO], X->tc[FQK], X->tc[FS3], wc[3], h, h + (n + 2), h + 2 * (n + 2),
+        const fr_t* ps[19] = {X->tc[FQL], X->tc[FQR], X->tc[FQM], X->tc[FQO], X->tc[FQK], X->tc[FS3], wc[3], h, h + (n + 2), h + 2 * (n + 2),
                               wc[0], wc[1], wc[2], X->tc[FS1], X->tc[FS2]};
-        const size_t ls[15] = {n, n, n, n, n, n, n + 3, n + 2, n + 2, n + 2, n + 2, n + 2, n + 2, n, n};
-        const fr_t ks[15] = {lz, rz, lr, oz, one, c_s3, c_z, mz, mz2, mz3, g1, g2, g3, g4, g5};
-        fp_lc_job J; J.F = F; J.out = folded; J.ps = ps; J.ls = ls; J.ks = ks; J.count = 15; J.n = n + 3;
+        size_t ls[19] = {n, n, n, n, n, n, n + 3, n + 2, n + 2, n + 2, n + 2, n + 2, n + 2, n, n};
+        fr_t ks[19] = {lz, rz, lr, oz, one, c_s3, c_z, mz, mz2, mz3, g1, g2, g3, g4, g5};
+        int cnt = 15;
+        fr_t gpow = g5;
+        for (uint32_t k = 0; k < nbc; k++) {        /* lin takes qcp_k(zeta) pi2_k; the fold takes gk^(6+k) Qcp_k */
+            ps[cnt] = pi2c[k]; ls[cnt] = n; ks[cnt++] = qcpz[k];
+            f4_mul(F, &gpow, &gpow, &gk);
+            ps[cnt] = X->qcp_c[k]; ls[cnt] = n; ks[cnt++] = gpow;
+        }
+        fp_lc_job J; J.F = F; J.out = folded; J.ps = ps; J.ls = ls; J.ks = ks; J.count = cnt; J.n = n + 3;
         J.per = (n + 3 + (size_t)threads * 4 - 1) / ((size_t)threads * 4); if (J.per < 256) J.per = 256;
         fp_pool_run(pool, fp_lc_task, &J, (int)((n + 3 + J.per - 1) / J.per));
     }
@@ -590,12 +707,15 @@ int orc_fast_prove(const fp_ctx* X, const void* Lp, const void* Rp, const void* 
     fr_to_be(F, &zshift, wp); wp += 32;
     memcpy(wp, bh_b, PT); wp += PT;
     memcpy(wp, zs_b, PT); wp += PT;
+    for (uint32_t k = 0; k < nbc; k++) { fr_to_be(F, &claimed[6 + k], wp); wp += 32; }      /* helper.go:74-85 */
+    for (uint32_t k = 0; k < nbc; k++) { memcpy(wp, bsb_b[k], PT); wp += PT; }
     *blob_len = (uint64_t)(wp - blob);
     if (challenges_out) {
         fr_to_be(F, &gamma, challenges_out); fr_to_be(F, &beta, challenges_out + 32); fr_to_be(F, &alpha, challenges_out + 64);
         fr_to_be(F, &zeta, challenges_out + 96); fr_to_be(F, &gk, challenges_out + 128);
     }
     for (int j = 0; j < 4; j++) free(wc[j]);
+    for (uint32_t k = 0; k < nbc; k++) free(pi2c[k]);
     free(pub_b); free(h); free(q1); free(q2); free(folded);
     fp_pool_destroy(pool);
     return rc;

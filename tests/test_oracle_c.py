@@ -117,3 +117,37 @@ def test_fast_prover_gives_the_bytes_of_the_plain_one(clib, cname, log_n):
     bad[5] = (bad[5] + 1) % cv.r
     assert fp.prove(cv.fr_vector(L), cv.fr_vector(R), cv.fr_vector(bad), cv.fr_vector(w.public), cv.fr_vector(blinding(cv, 1)), threads=2)[0] == 4
     fp.close()
+
+
+@pytest.mark.parametrize("cname,nb", [("bn254", 1), ("bn254", 2), ("bls12-381", 1), ("bls12-381", 2)])
+def test_fast_prover_bsb22_matches_the_python_oracle(clib, cname, nb):
+    """The BSB22 path of oracle/fast_prover.c (commitment over the Lagrange SRS, hash_fr into Qk, Qcp * pi2 in the quotient, the
+    extra terms of lin / the fold / the transcripts, the blob tail of helper.go:74-85) against oracle/plonk.py on the reference's
+    own commitment circuit (bsb22_test.go:18-39) - the C oracle proper has no BSB22 path, so this is what lets bench.py compare
+    the GPU's BASELINE configs[4] proofs with a host prover at full size."""
+    from oracle import circuits as ocircuits
+    cv, ov = CURVES[cname]
+    c, sol0, plan = ocircuits.bsb22_square(ov, nb)
+    n = c.domain_size()
+    tau = tau_from_seed(23, cv.r)
+    osrs = oplonk.synthetic_srs(ov, n, tau, materialize=True)
+    opk = oplonk.setup(c, osrs)
+    g = SplitMix64(5)
+    hiding = [(g.fr(cv.r), g.fr(cv.r)) for _ in range(nb)]
+    wn = ov.omega(n)
+    sol, pi2 = ocircuits.solve_bsb22(c, sol0, plan, lambda col: osrs.commit(oplonk.intt(col, wn, cv.r)), hiding)
+    L, R, O = oplonk.solve_lro(c, sol)
+    public = sol[: c.nb_public]
+    bl = blinding(cv, 3)
+    want = oplonk.marshal_proof(ov, oplonk.prove(opk, L, R, O, public, bl, pi2=pi2))
+    # Lagrange SRS: [L_i(tau)]G1
+    lag_scalars = [oplonk.poly_eval(oplonk.intt([1 if j == i else 0 for j in range(n)], wn, cv.r), tau, cv.r) for i in range(n)]
+    lag = cv.g1_vector([ov.mul(ov.g1, s) for s in lag_scalars])
+    tr = opk.trace
+    cols = [cv.fr_vector(x) for x in (tr.ql, tr.qr, tr.qm, tr.qo, tr.qk)]
+    fp = c_oracle.FastProver(clib, cv.abi, n, c.nb_public, cv.g1_vector(osrs.g1), cols, list(tr.S), threads=3,
+                             qcp=[cv.fr_vector(q) for q in tr.qcp], cci=list(opk.vk.commitment_constraint_indexes), srs_lagrange=lag)
+    rc, got, _ = fp.prove(cv.fr_vector(L), cv.fr_vector(R), cv.fr_vector(O), cv.fr_vector(public), cv.fr_vector(bl), threads=3,
+                          pi2=[cv.fr_vector(p) for p in pi2])
+    assert rc == 0 and got == want
+    fp.close()
