@@ -484,6 +484,19 @@ def test_bsb22_at_scale_is_accepted_by_the_transcribed_verifier(gpu, cname, log_
     assert not oplonk.verify(ovk, bytes(bad), pib)
     bad = bytearray(blob); bad[base_words * 32 + 5] ^= 1   # tamper with qcp(zeta)
     assert not oplonk.verify(ovk, bytes(bad), pib)
+    # byte for byte against the host prover's BSB22 path (oracle/fast_prover.c, itself held to oracle/plonk.py on the reference's
+    # commitment circuit by tests/test_oracle_c.py): the same solved wires, committed column, blinding
+    from oracle import c_oracle
+    solution, pi2 = ap_plonk.solve_with_commitments(ccs, pk, w, hiding=[(12345, 67890)])
+    tr = frontend.build_trace(ccs)
+    L, R, O = frontend.wire_columns(ccs, solution)
+    fp = c_oracle.FastProver(c_oracle.load(), cv.abi, n, ccs.GetNbPublicVariables(), srs.g1,
+                             [cv.fr_vector(x) for x in (tr.ql, tr.qr, tr.qm, tr.qo, tr.qk)], tr.perm, threads=oracle_threads(),
+                             qcp=[cv.fr_vector(q) for q in tr.qcp], cci=[cidx for _, cidx in ccs.commitments], srs_lagrange=srs.g1_lagrange)
+    rc, want, _ = fp.prove(cv.fr_vector(L), cv.fr_vector(R), cv.fr_vector(O), cv.fr_vector(w.public), cv.fr_vector(bl),
+                           threads=oracle_threads(), pi2=[cv.fr_vector(p) for p in pi2])
+    fp.close()
+    assert rc == 0 and blob == want
     pk.close()
 
 
