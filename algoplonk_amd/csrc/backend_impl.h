@@ -1037,6 +1037,12 @@ class CurveBackend : public Backend {
             // 16 -> 825; BN254 2^15: 13 -> 1 274, 14 -> 1 224, 15 -> 1 274 (and the lower latency)
             else if (slots > 2 && log_size == 14) c_ = 13;
             else if (slots > 2 && (log_size == 15 || log_size == 16)) c_ = 15;
+            // 2^18 and 2^19: 17 bits (15 windows; the histogram's packed 16-bit counters hold up to 786 432 bases).  Round 5, same
+            // box, two interleaved rounds: 2^18 251 / 253 -> 260 / 261 proofs/s, 2^19 125.1 / 125.3 -> 130.0 / 130.5 (bit-heavy
+            // witness +2.6 % / +3 %), a lone proof 5.24 -> 5.12 and 9.59 -> 9.24 ms; at 2^17 the two widths tie (528.8 against
+            // 528.7 over three rounds) and 16 stays.
+            // BLS12-381 (14-limb field: its reduction tail costs 2.3 x as much per bucket) loses 2 % with 17 bits at 2^18 and ties at 2^19.
+            if ((log_size == 18 || log_size == 19) && FPP::N <= 8) c_ = 17;
         }
         if (c_ < 7 || c_ > 20) { set_error("msm_window %d out of [7,20]", c_); return APK_ERR_ARG; }
         // c = 17 counts in packed 16-bit halves: a sort slice (at most msm_G_max_ of them) must stay below 2^16 entries
