@@ -6,9 +6,10 @@
 // structure follows SURVEY.md §3.3; what every round must produce is pinned by the verifier template
 // (/root/reference/verifier/templateLogicSigBN254.go, lines cited at each step).  GPU-natural schedule,
 // not gnark's: everything between two Fiat-Shamir challenges is a chain of launches on one HIP stream with
-// all polynomials resident; the wire/Z commitments are taken over the CANONICAL SRS after the iNTT (same group
-// element as gnark's Lagrange-SRS commit + blinding commit); the quotient is evaluated on ONE 4n coset
-// (5 coset NTTs per proof, the 7 trace polynomials' coset evaluations are precomputed per circuit).
+// all polynomials resident; [Z], [H1..3] and the openings are committed over the CANONICAL SRS, [L][R][O] over the canonical SRS
+// after the iNTT or - round 5, when the witness makes it cheaper - over the Lagrange SRS the way gnark does (same group
+// elements either way); the quotient is evaluated on ONE 4n coset (4 coset NTTs per proof, the 7 trace polynomials' coset
+// evaluations are precomputed per circuit).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <atomic>
