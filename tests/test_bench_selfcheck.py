@@ -61,3 +61,24 @@ def test_pmc_accumulate_summary_is_reproducible_from_the_raw_passes(tmp_path):
         done += 1
     if not done:
         pytest.skip("no round >= 4 PMC summary committed yet")
+
+
+def test_cpu_baseline_counts_the_cores_it_is_granted(tmp_path, monkeypatch):
+    """bench_cpu.effective_cores: visible CPUs, affinity mask and the cgroup quota, whichever is smallest (the GPU boxes show 256
+    CPUs behind `cpu.max` = 1600000 100000; rounds 1-4 reported the 256)."""
+    import builtins
+    import bench_cpu
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            p = tmp_path / "cpu.max"
+            p.write_text("1600000 100000\n")
+            return real_open(p, *a, **k)
+        return real_open(path, *a, **k)
+
+    monkeypatch.setattr(builtins, "open", fake_open)
+    monkeypatch.setattr(bench_cpu.os, "cpu_count", lambda: 256)
+    monkeypatch.setattr(bench_cpu.os, "sched_getaffinity", lambda pid: set(range(256)))
+    n, info = bench_cpu.effective_cores()
+    assert n == 16 and info["visible_cpus"] == 256 and info["cgroup_cpu_max"] == "1600000 100000"

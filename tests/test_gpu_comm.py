@@ -140,7 +140,15 @@ def test_bench_py_runs_its_multi_rank_modes_under_the_contract_launcher(gpu, mod
     if mode in ("prove-split", "prove-spmd"):
         assert line["matches_single_gpu_proof"] is True and line["scaling"] == "strong"
     if mode == "prove":
-        assert line["scaling"] == "weak" and line["value"] > 0
+        assert line["scaling"] == "weak" and line["value"] > 0 and line["proofs_under_load_ok_on_all_ranks"] is True
+    # round 5: every multi-rank line says what its data plane really was and measures it (two ranks on ONE GPU cannot be RCCL:
+    # the line must say so, with the reason, instead of passing for an xGMI measurement)
+    plane = line["config"]["data_plane"]
+    assert plane["rccl_ranks"] == 0 and plane["transport"].startswith("fallback:ipc:") and "share device 0" in plane["transport"], plane
+    assert plane["link_gbps"]["allgather_gbps_received"] > 0 and plane["link_gbps"]["ring_send_recv_gbps"] == 0.0, plane
+    if mode == "prove-spmd":
+        ph = line["phase_ms_per_proof_rank0"]
+        assert ph["msm_ms"] > 0 and ph["sums_exchange_ms"] > 0 and ph["commit_rounds_per_proof"] == 4.0 and ph["non_msm_ms"] > 0, ph
 
 
 @pytest.mark.gpu
