@@ -1018,11 +1018,14 @@ class CurveBackend : public Backend {
         }
         if (c_ == 0 && log_size >= 20) {
             // Round 5, from 2^20 bases: the widest window the two-level sort's packed entry has room for - 19 bits (14 windows
-            // instead of 16) up to 2^21 bases, 18 (15 windows) at 2^22 - else 16.  Same box, one MSM at a time / config 5 with four
+            // instead of 16) up to 2^21 bases, 18 (15 windows) at 2^22 and 2^23 - else 16.  Same box, one MSM at a time / config 5 with four
             // proofs in flight (profiles/r05_msm_size_sweep.json): BN254 2^20 1.73 -> 1.63 ms, 2^21 3.16 -> 2.97, 2^22 6.15 -> 6.01;
             // BLS12-381 2^20 3.32 -> 3.18, 2^21 6.26 -> 5.73 ms and 17.2 -> 18.6 proofs/s (c = 18: 17.8); c = 20 loses again at
             // 2^20 (1.79 / 3.41 ms: 2^19 buckets per MSM in the reduction) and does not fit the entry at 2^21.
+            // (with up to 8 192 partitions 19 bits also fit 2^22 and 18 bits 2^23: measured 6.03 against 5.86 ms at 2^22 - 18 stays
+            // there - and 12.74 against 13.03 ms for 18 against 16 bits at 2^23)
             for (int cand : {19, 18}) {
+                if (cand == 19 && log_size >= 22) continue;
                 if (choose_window(cand, log_size, slots) == APK_OK) return APK_OK;
             }
             c_ = 16;

@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256) msm_colscan_kernel(uint32_t* __restrict__
 // bit 31 the sign.  Round 3 fixed idx_bits = 22 and pb_log = 8 (2^17 bases at 16 windows); round 4 picks them per context
 // (MsmPartCfg): the index takes the bits it needs (26 for BLS12-381 2^21 x 16 windows - BASELINE configs[4]) and the partition
 // count grows until a partition's entries fit the second level's LDS tile (2 048 partitions of 16 buckets there).
-constexpr uint32_t MSM_PART_MAX = 4096;     // partitions per MSM (round 5: 2 048 -> 4 096 for the windows above 17 bits: 2^18 buckets in partitions of 64)
+constexpr uint32_t MSM_PART_MAX = 8192;     // partitions per MSM (round 5: 2 048 -> 8 192 for the windows above 17 bits and for 2^24 bases: 2^19 buckets in partitions of 64)
 constexpr uint32_t MSM_PART_GMAX = 16384;   // slices per MSM in the first level (2^24 bases in slices of ~2 044 scalars)
 constexpr uint32_t MSM_LDS_WORDS = 40960;   // 160 KiB of LDS per workgroup
 constexpr uint32_t MSM_PART_TILE = 36864;   // most entries of a partition sorted in LDS (144 KiB); larger (skewed) partitions scatter in HBM

@@ -517,7 +517,7 @@ def window_bits(args) -> int:
         return args.window_used
     throughput = args.mode == "prove" and args.inflight > 2
     if args.log_n >= 20:
-        return 19 if args.log_n <= 21 else 18 if args.log_n == 22 else 16
+        return 19 if args.log_n <= 21 else 18 if args.log_n <= 23 else 16
     if args.log_n in (18, 19) and args.curve == "bn254":
         return 17
     return 16 if (args.log_n >= 17 and throughput) else min(15, max(8, args.log_n - 2))
