@@ -989,6 +989,7 @@ const char* apk_comm_transport_reason(const apk_comm* c) { return c ? c->why_not
 
 int apk_comm_phase_ms(apk_comm* c, double* out, int reset) {
     if (!c || !out) { set_error("comm: phase_ms: null argument"); return APK_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(c->step_mu);      // the commitment rounds add to these under the same lock
     out[0] = c->ms_msm; out[1] = c->ms_sums; out[2] = c->ms_gather; out[3] = (double)c->n_commit_rounds; out[4] = (double)c->n_gathers;
     if (reset) { c->ms_msm = c->ms_sums = c->ms_gather = 0; c->n_commit_rounds = c->n_gathers = 0; }
     return APK_OK;
