@@ -699,7 +699,7 @@ def bench_prove(args, cv, rk) -> None:
         if not args.no_pmc:
             # (the PMC passes profile the MSMs of a circuit of the same size and curve WITHOUT the commitment: the accumulate
             # kernel's traffic and instruction count per pair do not depend on the circuit)
-            pmc = pmc_traffic(args.curve, args.log_n, window_bits(args), timeout_s=420.0 if args.log_n < 20 else 1500.0)
+            pmc = pmc_traffic(args.curve, args.log_n, window_bits(args), timeout_s=150.0 if args.log_n < 20 else 1500.0)   # a pass takes ~10 s at 2^17; a hung profiler must not hold the line up
         if not args.no_cpu_baseline:
             probe = go_probe()
             cpu_baseline = gnark_cpu_baseline(probe, args.curve, args.log_n, args.cpu_baseline_seconds)
