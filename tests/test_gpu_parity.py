@@ -895,3 +895,23 @@ def test_lagrange_basis_wire_commitments_are_the_same_group_elements(gpu, cname,
             blind = sum(b * (pow(wl.tau, n + k, cv.r) - pow(wl.tau, k, cv.r)) for k, b in enumerate(sc[n:])) % cv.r
             assert pk.msm(sc, basis=1) == ov.mul(ov.g1, (f_at_tau + blind) % cv.r)
         pk.close()
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12-381"])
+@pytest.mark.parametrize("log_n", [3, 5])
+def test_lagrange_route_at_the_smallest_sizes(gpu, cname, log_n, monkeypatch):
+    """The extended Lagrange table at n = 8 and n = 32 (n + 3 = 11 / 35 bases, the blinding points right behind a handful of Lagrange
+    points), forced: the proofs are the oracle's byte for byte, with and without public inputs in the witness rows."""
+    cv, ov = CURVES[cname]
+    monkeypatch.setenv("APK_WIRES_LAGRANGE", "1")
+    for nb_public in (1, 2):
+        ccs, w, sol = random_chain_ccs(cv, log_n, 90 + log_n, nb_public=nb_public)
+        pk, vk, opk, srs = _setup_pair(cv, ov, ccs, 6, gpu)
+        bl = blinding(cv, 15)
+        oc = oracle_circuit_from_ccs(ov, ccs)
+        L, R, O = oplonk.solve_lro(oc, sol)
+        want = oplonk.marshal_proof(ov, oplonk.prove(opk, L, R, O, w.public, bl))
+        for _ in range(2):
+            assert MarshalProof(ap_plonk.Prove(ccs, pk, w, bl)) == want
+        assert pk.paths()["msm_lagrange_wires"] == 2
+        pk.close()
