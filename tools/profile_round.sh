@@ -43,5 +43,10 @@ python tools/pmc_accumulate.py $O $TAG $O/${TAG}_pmc_msm_accumulate.json > $O/${
 timeout 900 python tools/msm_size_sweep.py 11 24 bn254 $O/${TAG}_msm_size_sweep.json > $O/${TAG}_msm_size_sweep.log 2>&1
 timeout 600 python tools/msm_size_sweep.py 19 22 bn254 $O/${TAG}_msm_window_sweep_bn254.json 16,18,19,20 > $O/${TAG}_msm_window_sweep_bn254.log 2>&1
 timeout 600 python tools/msm_size_sweep.py 19 21 bls12_381 $O/${TAG}_msm_window_sweep_bls12381.json 16,18,19,20 > $O/${TAG}_msm_window_sweep_bls12381.log 2>&1
+# kernel timeline of one lone proof (start, duration, idle gap per launch)
+timeout 300 rocprofv3 --kernel-trace -d /tmp/${TAG}_tl17 -o r -- python tools/prof_msm.py 17 0 4 > /dev/null 2>&1
+python tools/timeline.py $(find /tmp/${TAG}_tl17 -name r_results.db | head -1) 3.35 > $O/${TAG}_timeline_bn254_2p17.txt
+timeout 300 rocprofv3 --kernel-trace -d /tmp/${TAG}_tl14 -o r -- python tools/prof_msm.py 14 0 4 bls12_381 > /dev/null 2>&1
+python tools/timeline.py $(find /tmp/${TAG}_tl14 -name r_results.db | head -1) 2.85 > $O/${TAG}_timeline_bls12381_2p14.txt
 rm -rf $O/${TAG}_kt1 $O/${TAG}_kt24 $O/${TAG}_ktbls $O/${TAG}_facts_*.json
 ls -la $O | grep ${TAG} | tail -40
