@@ -260,3 +260,36 @@ def test_subcoset_split_of_round_3_is_byte_identical(gpu, cname, G, log_n, bsb):
     assert MarshalProof(ap_plonk.Prove(ccs, pks[1], w, bl, **kw)) == plain
     for pk in pks:
         pk.close()
+
+
+@pytest.mark.gpu
+def test_a_communicator_takes_its_hooks_off_the_context_when_it_goes(gpu):
+    """apk_comm_spmd_begin installs hooks on the context whose user pointer is the communicator.  A communicator that is
+    destroyed or rebound WITHOUT spmd_end (an exception between the two calls is enough) must take them off again - the next
+    apk_prove on that context would otherwise call into freed memory.  World 1 here: the lifecycle, not the exchange."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from algoplonk_amd import parallel, plonk as ap_plonk, setup as ap_setup, MarshalProof
+    from helpers import CURVES, blinding, random_chain_ccs
+    from oracle.prng import tau_from_seed
+    cv, ov = CURVES["bn254"]
+    ccs, w, sol = random_chain_ccs(cv, 8, 3)
+    srs = ap_setup.unsafe_srs(cv, ccs.domain_size(), tau_from_seed(4, cv.r), device=gpu)
+    pk, vk = ap_plonk.Setup(ccs, srs, device=gpu)
+    bl = blinding(cv, 2)
+    want = MarshalProof(ap_plonk.Prove(ccs, pk, w, bl))
+    for how in ("destroy", "rebind", "unbind"):
+        comm = parallel.Comm(0, 1)
+        comm.bind(pk.ctx)
+        comm.spmd_begin()
+        assert MarshalProof(ap_plonk.Prove(ccs, pk, w, bl)) == want          # through the hook (world 1: this rank commits everything)
+        if how == "destroy":
+            comm.close()                                                       # no spmd_end
+        elif how == "rebind":
+            comm.bind(pk.ctx)                                                  # binding again ends what the old binding installed
+        else:
+            comm.bind(None)
+        assert MarshalProof(ap_plonk.Prove(ccs, pk, w, bl)) == want          # no hook left behind: the context proves on its own
+        if how != "destroy":
+            comm.close()
+        assert MarshalProof(ap_plonk.Prove(ccs, pk, w, bl)) == want
+    pk.close()
