@@ -140,3 +140,34 @@ def test_serialize_deserialize_compiled_circuit_then_prove(gpu, cname, tmp_path)
     with pytest.raises(ValueError):
         ser.DeserializeCompiledCircuit(path, device=gpu)
     cc.Pk.close(); cc2.Pk.close()
+
+
+def test_plonk_vk_inside_a_proving_key_picks_its_layout_from_what_follows():
+    """inside a proving key the verifying key is followed by the kzg proving key, whose point count must be Size + 3 -
+    that, not four zero bytes, decides between the layout with and without Kzg.Lines (a key without commitments has nq = 0, and
+    any four zero bytes used to pass for its empty index list)."""
+    import struct
+    from oracle import circuits as ocircuits, plonk as oplonk
+    from oracle.prng import tau_from_seed
+    cv, ov = CURVES["bn254"]
+    c, sol = ocircuits.pythagorean(ov) if hasattr(ocircuits, "pythagorean") else (None, None)
+    if c is None:
+        c, sol, _ = ocircuits.bsb22_square(ov, 0)
+    tau = tau_from_seed(3, cv.r)
+    ovk = oplonk.setup(c, oplonk.synthetic_srs(ov, c.domain_size(), tau, materialize=False)).vk
+    vk = ap_plonk.VerifyingKey(curve=cv, Size=ovk.size, SizeInv=ovk.size_inv, Generator=ovk.generator, CosetShift=ovk.coset_shift,
+                               NbPublicVariables=ovk.nb_public, Ql=ovk.ql, Qr=ovk.qr, Qm=ovk.qm, Qo=ovk.qo, Qk=ovk.qk, S=list(ovk.s), Qcp=[],
+                               CommitmentConstraintIndexes=[], KzgG1=ovk.g1, tau=None, KzgG2=ap_setup.g2_from_tau(cv, tau))
+    b = ser.write_plonk_vk(vk)
+    follow = struct.pack(">I", vk.Size + 3) + bytes(40)            # the head of a kzg proving key: its G1 count
+    assert ser.read_plonk_vk(cv, io.BytesIO(b + follow), embedded=True).kzg_lines_bytes == 0
+    nlines = ser.KZG_LINES_BYTES[cv.name]
+    lines = bytes(4) + bytes(range(1, 256)) * (nlines // 255 + 1)  # a Lines block that BEGINS with four zero bytes (the old trap)
+    with_lines = b[:-4] + lines[:nlines] + b[-4:] + follow
+    back = ser.read_plonk_vk(cv, io.BytesIO(with_lines), embedded=True)
+    assert back.kzg_lines_bytes == nlines and back == vk
+    with pytest.raises(ValueError, match="unpinned"):
+        ser.read_plonk_vk(cv, io.BytesIO(b + struct.pack(">I", vk.Size + 4) + bytes(40)), embedded=True)
+    # a vk FILE: the layout follows from the remaining length alone
+    with pytest.raises(ValueError, match="unpinned"):
+        ser.read_plonk_vk(cv, io.BytesIO(b + bytes(4)))
