@@ -210,6 +210,7 @@ class CurveBackend : public Backend {
     std::atomic<uint32_t> wire_density_pm_{0xffffffffu}; // non-zero digits of the last measured proof's wires, per mille of uniform
     std::atomic<uint32_t> proof_seq_{0};
     Aff vk_pts_[8 + APK_MAX_COMMITMENTS];
+    HostFixedBase<FPP> vk_fixed_;   // host tables of [Ql][Qr][Qm][Qo][S3] for the [lin] combination (host_msm.h)
     std::vector<Slot*> slots_;
     SlotGate gate_;            // who proves on which slot; its busy count picks the load-dependent kernel forms (slot_gate.h)
     std::mutex mu_;
@@ -1588,6 +1589,10 @@ int CurveBackend<FRP, FPP, CURVE_ID>::setup_trace(const apk_circuit_desc* d) {
         CHK(sync_results(s));
         memcpy(&vk_pts_[base], s.h_pinned, a.batch * sizeof(Aff));
     }
+    {   // the five of them that enter every proof's [lin] with a fresh coefficient: fixed-base tables on the host (a few ms)
+        const Aff fixed[5] = {vk_pts_[0], vk_pts_[1], vk_pts_[2], vk_pts_[3], vk_pts_[7]};
+        vk_fixed_.build(fixed, 5);
+    }
     return APK_OK;
 }
 
@@ -1901,6 +1906,23 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     const Fr zeta = fr_from_be(zeta_raw);
 
     // ---------------- round 4: evaluations, linearised polynomial, openings ----------------------------------
+    Fr zn_m1, zn2, mz;   // zeta^n - 1, zeta^(n+2), 1 - zeta^n: worked out below while the GPU evaluates
+    // The context's parked host threads for the [lin] combination while this proof has the context (nearly) to itself - then the
+    // GPU idles through it; with many proofs in flight the callers' own threads already keep the host busy.  Since the combination
+    // takes GLV halves and fixed-base tables (host_msm.h) one thread does BN254's in 0.10 ms (0.15 before) and waking three more
+    // costs what they save; BLS12-381's (0.23 ms) still gains a little from three (same box: tools/ab_lone.sh).
+    static const int lc_threads = env_int("APK_HOST_LINCOMB_THREADS", FPP::N <= 8 ? 1 : 3, 1, 8);
+    static const bool host_glv = env_int("APK_HOST_GLV", 1, 0, 1) != 0;   // 0: full-length scalars (measurement aid; same bytes)
+    HostPool* pool = nullptr;
+    const bool host_idle = gate_.busy() <= 2;     // no other proofs' threads competing for the host while the GPU works on this one
+    if (lc_threads > 1 && host_idle) {
+        std::lock_guard<std::mutex> lk2(mu_);
+        if (!lc_pool_) lc_pool_.reset(new HostPool(lc_threads - 1));
+        pool = lc_pool_.get();
+        path(P_LINCOMB_POOL);
+    }
+    XYZZ<FPP, Fe64<FPP>> lin_h = XYZZ<FPP, Fe64<FPP>>::inf();
+    bool lin_h_done = false;
     const Fr zw = zeta * omega_;
     const bool z0 = zeta.is_zero();
     const Fr zeta_inv = Fr::inv(zeta), zw_inv = Fr::inv(zw);
@@ -1936,6 +1958,21 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         CHK(eval_many(s, ea, ptr<Fr>(s.pw_z), hfr));
         // the opening quotient of Z at omega*zeta does not wait for anything the host derives from the evaluations
         CHK(kzg_quotient(s, ptr<Fr>(s.cz), n + 3, ptr<Fr>(s.pw_zw), ptr<Fr>(s.pw_zwi), z0, ptr<Fr>(s.q2)));
+        // [lin] (below) is a combination of commitments the host holds; the coefficients of [H1..3] depend on zeta alone, so a
+        // lone proof's host thread works that part out while the GPU evaluates (the rest needs the evaluations).  With other
+        // proofs in flight it stays one pass: a second pass repeats the doublings, and the host is what those proofs share.
+        zn_m1 = Fr::pow_u64(zeta, n) - Fr::one();
+        zn2 = Fr::pow_u64(zeta, n + 2);
+        mz = Fr::neg(zn_m1);
+        static const int early_h = env_int("APK_LIN_EARLY_H", 1, 0, 1);
+        if (host_idle && early_h && (pool || FPP::N <= 8)) {   // (one thread takes longer over BLS12-381's three than the GPU over the evaluations)
+            const auto t_lc = std::chrono::steady_clock::now();
+            const Aff hpts[3] = {hcom[0], hcom[1], hcom[2]};
+            const Fr hks[3] = {mz, mz * zn2, mz * zn2 * zn2};
+            lin_h = host_lincomb_sum<FRP, FPP>(hpts, hks, 3, pool, host_glv);
+            lin_h_done = true;
+            if (stats_on_) lincomb_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lc).count();
+        }
         CHK(sync_results(s));
         const Fr c32 = fr_u64(32);        // eval_partial_kernel multiplies value x value on the product's radix: f(z) / 32 comes back
         for (int i = 0; i < ea.count; i++) ev[i] = hfr[i] * c32;
@@ -1943,7 +1980,6 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     const Fr lz = ev[0], rz = ev[1], oz = ev[2], s1z = ev[3], s2z = ev[4];
     const Fr zshift = ev[5 + nb_commit_];
     // coefficients of the linearised polynomial (templateLogicSigBN254.go:195-201,231-254)
-    const Fr zn_m1 = Fr::pow_u64(zeta, n) - Fr::one();
     const Fr alpha2 = alpha * alpha;
     // L_i(zeta) = omega^i (zeta^n - 1) / (n (zeta - omega^i)) for the rows the prover wrote into Qk (public inputs, commitment
     // hashes) and for row 0: one shared inversion
@@ -1979,8 +2015,6 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     const Fr lin_z = Fr::neg(pi_z + alpha * zshift * (lz + beta * s1z + gamma) * (rz + beta * s2z + gamma) * (oz + gamma) - alpha2 * lag0);
     const Fr c_s3 = alpha * beta * zshift * (lz + beta * s1z + gamma) * (rz + beta * s2z + gamma);
     const Fr c_z = alpha2 * lag0 - alpha * (lz + beta * zeta + gamma) * (rz + beta_u * zeta + gamma) * (oz + beta_u2 * zeta + gamma);
-    const Fr zn2 = Fr::pow_u64(zeta, n + 2);
-    const Fr mz = Fr::neg(zn_m1);
     // terms of the linearised polynomial: the polynomial (device), its commitment (host), its coefficient
     struct LinTerm { const Fr* poly; uint32_t len; Aff com; Fr coef; };
     std::vector<LinTerm> lin_terms = {
@@ -1993,22 +2027,29 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     // (host_msm.h) instead of a tenth size-n MSM
     Aff lin_com;
     {
+        // terms 7..9 are the [H] part (taken above when the pool was there), term 4 is [Qk] with coefficient one: a plain addition
         Aff lp[HOST_MSM_MAX];
         Fr lk[HOST_MSM_MAX];
-        for (size_t i = 0; i < lin_terms.size(); i++) { lp[i] = lin_terms[i].com; lk[i] = lin_terms[i].coef; }
-        const auto t_lc = std::chrono::steady_clock::now();
-        // the context's parked host threads while this proof has it (nearly) to itself - then the GPU idles through the
-        // combination; with many proofs in flight the callers' own threads already keep the host busy
-        static const int lc_threads = env_int("APK_HOST_LINCOMB_THREADS", 4, 1, 8);
-        HostPool* pool = nullptr;
-        if (lc_threads > 1 && gate_.busy() <= 2) {
-            std::lock_guard<std::mutex> lk2(mu_);
-            if (!lc_pool_) lc_pool_.reset(new HostPool(lc_threads - 1));
-            pool = lc_pool_.get();
-            path(P_LINCOMB_POOL);
+        // terms 0..3 and 5 ([Ql][Qr][Qm][Qo][S3]) come out of the context's fixed-base tables: 33 additions each
+        static const bool host_fixed = env_int("APK_HOST_FIXED", 1, 0, 1) != 0;   // 0: through the Straus pass (measurement aid; same bytes)
+        int cnt = 0;
+        for (size_t i = 0; i < lin_terms.size(); i++) {
+            if (i == 4 || (lin_h_done && i >= 7 && i <= 9) || (host_fixed && (i <= 3 || i == 5))) continue;
+            lp[cnt] = lin_terms[i].com; lk[cnt] = lin_terms[i].coef; cnt++;
         }
-        lin_com = host_lincomb<FRP, FPP>(lp, lk, (int)lin_terms.size(), pool);
-        if (stats_on_) lincomb_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lc).count();
+        const auto t_lc = std::chrono::steady_clock::now();
+        XYZZ<FPP, Fe64<FPP>> sum = host_lincomb_sum<FRP, FPP>(lp, lk, cnt, pool, host_glv);
+        if (host_fixed) {
+            const Fr fk[5] = {lin_terms[0].coef, lin_terms[1].coef, lin_terms[2].coef, lin_terms[3].coef, lin_terms[5].coef};
+            vk_fixed_.template accumulate<FRP>(sum, fk);
+        }
+        if (lin_h_done) sum.add(lin_h);
+        {
+            using F64 = Fe64<FPP>;
+            sum.madd(Affine<FPP, F64>{F64::from(vk_pts_[4].x), F64::from(vk_pts_[4].y)});
+        }
+        lin_com = host_xyzz_to_affine<FPP>(sum);
+        if (stats_on_) lincomb_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lc).count();
     }
     memcpy(out->zshift_value, &zshift, sizeof(Fr));
     Fr claimed[6 + APK_MAX_COMMITMENTS] = {lin_z, lz, rz, oz, s1z, s2z};

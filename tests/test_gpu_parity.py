@@ -26,11 +26,11 @@ def test_g1_mul_batch(gpu, cname):
         assert P == ov.mul(ov.g1, s)
 
 
-def _setup_pair(cv, ov, ccs, seed, gpu, lagrange=False, msm_window=0):
+def _setup_pair(cv, ov, ccs, seed, gpu, lagrange=False, msm_window=0, slots=1):
     n = ccs.domain_size()
     tau = tau_from_seed(seed, cv.r)
     srs = ap_setup.unsafe_srs(cv, n, tau, device=gpu, lagrange=lagrange)
-    pk, vk = ap_plonk.Setup(ccs, srs, device=gpu, msm_window=msm_window)
+    pk, vk = ap_plonk.Setup(ccs, srs, device=gpu, msm_window=msm_window, slots=slots)
     osrs = oplonk.synthetic_srs(ov, n, tau, materialize=False)
     opk = oplonk.setup(oracle_circuit_from_ccs(ov, ccs), osrs)
     return pk, vk, opk, srs
@@ -71,6 +71,27 @@ def test_srs_vk_msm_ntt(gpu, cname, log_n):
     assert pk.ntt(v4, which=1, coset=True) == oplonk.ntt(shifted, w4, cv.r)
     back = pk.ntt(pk.ntt(v4, which=1, coset=True), which=1, inverse=True, coset=True)
     assert back == v4
+    pk.close()
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12-381"])
+def test_a_lone_proof_on_a_serving_context_matches_the_oracle(gpu, cname):
+    """A proof that has a context of several slots to itself: the commitment of the linearised polynomial is put together on the
+    host from GLV halves and the context's fixed-base tables of the VK points (host_msm.h, glv_params.h), the [H] part before the
+    evaluations are back (backend_impl.h round 4), on BLS12-381 with the context's parked host threads (the path counter says so).
+    Same bytes as the oracle prover's."""
+    cv, ov = CURVES[cname]
+    ccs, w, sol = random_chain_ccs(cv, 10, 0xA5A5)
+    pk, vk, opk, srs = _setup_pair(cv, ov, ccs, 33, gpu, slots=4)
+    bl = blinding(cv, 7)
+    pk.paths(reset=True)
+    blobs = [MarshalProof(ap_plonk.Prove(ccs, pk, w, bl)) for _ in range(3)]
+    paths = pk.paths()
+    if "APK_HOST_LINCOMB_THREADS" not in os.environ:
+        assert paths["proofs"] == 3 and paths["host_lincomb_pooled"] == (0 if cname == "bn254" else 3), paths
+    L, R, O = oplonk.solve_lro(oracle_circuit_from_ccs(ov, ccs), sol)
+    want = oplonk.marshal_proof(ov, oplonk.prove(opk, L, R, O, w.public, bl))
+    assert blobs[0] == want and blobs[1] == want and blobs[2] == want
     pk.close()
 
 
@@ -696,10 +717,16 @@ print("SHA", hashlib.sha256(MarshalProof(plonk.Prove(ccs, pk, w, blinding(cv, 3)
                        # the four-launch form of the two-level sort (count - scan - scatter - sort) behind the two-launch default
                        {"APK_MSM_SORT2": "1", "APK_MSM_SORT_FUSED": "0"}, {"APK_MSM_SORT2": "1", "APK_MSM_SORT_FUSED": "0", "APK_MSM_PART_PBLOG": "4"},
                        {"APK_MSM_SCAN_FUSED": "1"}, {"APK_MSM_GRAPH": "1", "APK_MSM_SORT2": "1"},
-                       {"APK_MSM_COMBINE_QUAD": "1", "APK_MSM_LEAN_TAIL": "0"}, {"APK_MSM_COMBINE_QUAD": "0", "APK_MSM_LEAN_TAIL": "0"}]),
+                       {"APK_MSM_COMBINE_QUAD": "1", "APK_MSM_LEAN_TAIL": "0"}, {"APK_MSM_COMBINE_QUAD": "0", "APK_MSM_LEAN_TAIL": "0"},
+                       # round 5: the host's [lin] combination - GLV halves, fixed-base tables of the VK points, the [H] part ahead of
+                       # the evaluations, parked threads - against the full-length one-pass Straus form it replaced
+                       {"APK_HOST_LINCOMB_THREADS": "3"}, {"APK_HOST_GLV": "0", "APK_HOST_FIXED": "0", "APK_LIN_EARLY_H": "0"},
+                       {"APK_HOST_GLV": "0"}, {"APK_HOST_FIXED": "0", "APK_LIN_EARLY_H": "0", "APK_HOST_LINCOMB_THREADS": "4"}]),
     ("bls12-381", 10, 12, [{"APK_MSM_LEAN_TAIL": "1", "APK_NTT_RADIX4": "1"}, {"APK_MSM_SORT2": "1"},
                            {"APK_MSM_SORT2": "1", "APK_MSM_PART_PBLOG": "3", "APK_MSM_PART_SMALL_SCAN": "0"},
-                           {"APK_MSM_COMBINE_QUAD": "1", "APK_MSM_LEAN_TAIL": "0"}, {"APK_MSM_COMBINE_QUAD": "0", "APK_MSM_LEAN_TAIL": "0"}]),
+                           {"APK_MSM_COMBINE_QUAD": "1", "APK_MSM_LEAN_TAIL": "0"}, {"APK_MSM_COMBINE_QUAD": "0", "APK_MSM_LEAN_TAIL": "0"},
+                           {"APK_HOST_LINCOMB_THREADS": "1"}, {"APK_HOST_GLV": "0", "APK_HOST_FIXED": "0", "APK_LIN_EARLY_H": "0"},
+                           {"APK_HOST_FIXED": "0"}]),
 ])
 def test_run_time_variants_give_the_same_bytes(gpu, cname, log_n, window, variants):
     """The forms the library picks at run time - lean tail kernels when other proofs are in flight (sixteen-lane row/column

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Small driver for profiler runs: one context at BN254 2^log_n, then a few single MSMs and proofs.
 usage: python tools/prof_msm.py [log_n] [msms] [proofs] [bn254|bls12_381]
-APK_PROF_FACTS=file: what the run did (sizes, MSMs, pairs, window, table bytes) as JSON, for tools/pmc_summary.py --json."""
+APK_PROF_SLOTS=k: proving slots of the context (1).  APK_PROF_FACTS=file: what the run did (sizes, MSMs, pairs, window, table bytes) as JSON, for tools/pmc_summary.py --json."""
 import ctypes as C
 import json
 import os
@@ -18,7 +18,7 @@ cv = ecc.BLS12_381 if len(sys.argv) > 4 and sys.argv[4] == "bls12_381" else ecc.
 wl = workloads.random_circuit(cv, log_n, 0xA190 if cv is ecc.BN254 else 0xA191)
 n = wl.ccs.domain_size()
 srs = setup.unsafe_srs(cv, n, wl.tau)
-pk, vk = plonk.Setup(wl.ccs, srs)
+pk, vk = plonk.Setup(wl.ccs, srs, slots=int(os.environ.get("APK_PROF_SLOTS", "1")))
 L, R, O = frontend.wire_columns(wl.ccs, wl.solution)
 d = []
 for v in (L, R, O):

@@ -40,6 +40,41 @@ static int hammer_lincomb(const char* name, const uint32_t* gx, const uint32_t* 
         ks[i] = Fr::to_mont(k);
     }
     const Aff want = host_lincomb<FRP, FPP>(pts, ks, COUNT, nullptr);
+    // the GLV pass (two half-length columns per point) against the plain full-length one, scalars at the edges included
+    int glv_bad = 0;
+    {
+        Fr edge[COUNT];
+        for (int i = 0; i < COUNT; i++) edge[i] = ks[i];
+        edge[0] = Fr::zero(); edge[1] = Fr::one(); edge[2] = Fr::neg(Fr::one());
+        Fr lam = Fr::zero();
+        for (int w = 0; w < 4; w++) { lam.l[2 * w] = (uint32_t)GlvParams<FPP>::lambda[w]; lam.l[2 * w + 1] = (uint32_t)(GlvParams<FPP>::lambda[w] >> 32); }
+        edge[3] = Fr::to_mont(lam); edge[4] = Fr::neg(edge[3]);
+        Fr p128 = Fr::zero(); p128.l[4] = 1; edge[5] = Fr::to_mont(p128);
+        Aff ep[COUNT];
+        for (int i = 0; i < COUNT; i++) ep[i] = pts[i];
+        ep[6] = Aff::inf(); ep[8] = ep[7];
+        for (int c = 1; c <= COUNT; c++) {
+            const Aff a = host_xyzz_to_affine<FPP>(host_lincomb_xyzz<FRP, FPP>(ep, edge, c, true));
+            const Aff b = host_xyzz_to_affine<FPP>(host_lincomb_xyzz<FRP, FPP>(ep, edge, c, false));
+            if (memcmp(&a, &b, sizeof a) != 0) glv_bad++;
+        }
+        // phi(P) = (beta x, y) = lambda P
+        Fp bp;
+        for (int w = 0; w < Fp::N; w++) bp.l[w] = GlvParams<FPP>::beta[w];
+        const Aff lp = host_lincomb<FRP, FPP>(&pts[2], &edge[3], 1, nullptr);
+        if (!(lp.x == Fp::to_mont(bp) * pts[2].x) || !(lp.y == pts[2].y)) glv_bad++;
+        // the fixed-base tables (a context's [Ql][Qr][Qm][Qo][S3]) against the Straus pass: an infinity point, a repeated one,
+        // the scalars 0 and r - 1 among them
+        HostFixedBase<FPP> fb;
+        const Aff fp5[5] = {ep[0], ep[1], Aff::inf(), ep[7], ep[7]};
+        const Fr fk5[5] = {edge[7], edge[8], edge[9], edge[2], edge[0]};
+        fb.build(fp5, 5);
+        XYZZ<FPP, Fe64<FPP>> facc = XYZZ<FPP, Fe64<FPP>>::inf();
+        fb.template accumulate<FRP>(facc, fk5);
+        const Aff fa = host_xyzz_to_affine<FPP>(facc), fw = host_lincomb<FRP, FPP>(fp5, fk5, 5, nullptr);
+        if (memcmp(&fa, &fw, sizeof fa) != 0) glv_bad++;
+        printf("%s: GLV pass against the plain pass (11 prefixes), the endomorphism, fixed-base tables: %d mismatches\n", name, glv_bad);
+    }
     HostPool pool(3);
     std::atomic<int> bad{0}, pooled{0};
     std::vector<std::thread> th;
@@ -53,7 +88,7 @@ static int hammer_lincomb(const char* name, const uint32_t* gx, const uint32_t* 
         });
     for (auto& t : th) t.join();
     printf("%s: %d combinations from 32 threads on a 3-worker pool, %d mismatches\n", name, pooled.load(), bad.load());
-    return bad.load();
+    return bad.load() + glv_bad;
 }
 
 static int hammer_gate(int slots) {
