@@ -96,6 +96,36 @@ def test_a_lone_proof_on_a_serving_context_matches_the_oracle(gpu, cname):
 
 
 @pytest.mark.parametrize("cname", ["bn254", "bls12-381"])
+def test_selector_commitments_at_infinity(gpu, cname):
+    """A circuit of additions only: Qm = 0 and Qk = 0, so [Qm] and [Qk] in the verifying key are the point at infinity.  They
+    still enter every proof's [lin] (coefficients l(zeta) r(zeta) and 1): the host's fixed-base table of an infinity point and the
+    plain addition of one must add nothing.  Bytes = the oracle prover's; the transcribed verifier accepts."""
+    cv, ov = CURVES[cname]
+    r = cv.r
+    g = SplitMix64(0x1F)
+    nb_public, n = 2, 1 << 6
+    sol = [g.fr(r) for _ in range(nb_public + 2)]
+    cons = []
+    for _ in range(n - nb_public):
+        nv = len(sol)
+        xa, xb = g.below(nv), g.below(nv)
+        ql, qr = g.fr(r), g.fr(r)
+        cons.append((ql, qr, 0, r - 1, 0, xa, xb, nv))
+        sol.append((ql * sol[xa] + qr * sol[xb]) % r)
+    ccs = frontend.ConstraintSystem(r, ["p0", "p1"], ["s0", "s1"], cons, "gates", len(sol))
+    w = frontend.Witness(r, sol[:nb_public], sol[nb_public:nb_public + 2])
+    pk, vk, opk, srs = _setup_pair(cv, ov, ccs, 5, gpu, slots=3)
+    ovk = oracle_vk_from_product(ov, vk)
+    assert ovk.qm is None and ovk.qk is None, "the verifying key holds [Qm] = [Qk] = infinity"
+    bl = blinding(cv, 12)
+    blob = MarshalProof(ap_plonk.Prove(ccs, pk, w, bl))
+    L, R, O = oplonk.solve_lro(oracle_circuit_from_ccs(ov, ccs), sol)
+    assert blob == oplonk.marshal_proof(ov, oplonk.prove(opk, L, R, O, w.public, bl))
+    assert oplonk.verify(ovk, blob, MarshalPublicInputs(w))
+    pk.close()
+
+
+@pytest.mark.parametrize("cname", ["bn254", "bls12-381"])
 @pytest.mark.parametrize("log_n", [3, 5, 8, 11])
 def test_prove_matches_oracle(gpu, cname, log_n):
     cv, ov = CURVES[cname]
