@@ -234,7 +234,7 @@ class CurveBackend : public Backend {
     } sc_;
     // which forms the load-dependent choices took (apk_paths_read): always counted, relaxed atomics
     enum PathIdx { P_PROOFS, P_MSM_BATCHES, P_SORT2, P_SORT2_LOAD, P_SORT_FUSED, P_LEAN_TAIL, P_ROWCOL_SERIAL, P_COMBINE_QUAD, P_SMALL_UNITS,
-                   P_ONE_LAUNCH, P_LAGRANGE_WIRES, P_NTT_SEQ, P_NTT_R4, P_NTT_R4_LOAD, P_TAIL_FILL, P_LINCOMB_POOL, P_COUNT };
+                   P_ONE_LAUNCH, P_LAGRANGE_WIRES, P_NTT_SEQ, P_NTT_R4, P_NTT_R4_LOAD, P_TAIL_FILL, P_LINCOMB_POOL, P_UNIT_LOADED, P_COUNT };
     std::atomic<uint64_t> paths_[P_COUNT] = {};
     void path(PathIdx i) { paths_[i].fetch_add(1, std::memory_order_relaxed); }
     int paths_read(apk_path_counts* out, int reset) override {
@@ -471,6 +471,14 @@ class CurveBackend : public Backend {
         if (slots_.size() > 2) others_busy = gate_.busy() > 1;
         static const int graphs_on = env_int("APK_MSM_GRAPH", 0, 0, 1);   // a captured batch must not depend on the moment of capture:
         if (graphs_on) others_busy = false;                               // neither its unit nor its kernel forms
+        // Under load the units grow: a bucket of 64 entries is then merged from 2 partial sums instead of 4 (the merge's general
+        // additions cost 14 products against the accumulate loop's 10), and the other proofs' kernels fill the SIMDs the fewer,
+        // longer waves leave.  Same box, BN254, two rounds (tools/sweep_unit_window.sh): 2^16 941.6 / 947.9 -> 952.3 / 962.4
+        // proofs/s at 40 entries, 2^17 with 17-bit windows 514.4 / 515.5 -> 530.7 / 530.8 at 40 and 533.2 / 532.1 at 64, 2^18 and
+        // 2^19 +0.5 %; a lone proof pays for long units (3.25 -> 3.43 ms at 32), so only with others in flight.
+        // (2^15 bases and BLS12-381 2^14 lose 1-2 % with them - too few waves left even for a busy GPU - so from 2^16 bases.)
+        static const uint32_t unit_loaded = (uint32_t)env_int("APK_MSM_UNIT_LOADED", 48, 0, MSM_UNIT_MAX);
+        if (!unit_env && others_busy && unit < unit_loaded && msm_bases_ >= 65536u) { unit = unit_loaded; path(P_UNIT_LOADED); }
         // Small batches (a lone 2^14 MSM: 360 k entries) do not even give every SIMD one wave at 16 entries per lane, and a lone
         // wave issues a dependent instruction every ~6.5 cycles: the accumulate launch is then 16 additions long whatever the
         // size (BLS12-381 2^14: 229 of the MSM's 580 us).  Below one wave per SIMD the unit shrinks - down to
@@ -1048,6 +1056,11 @@ class CurveBackend : public Backend {
             // 528.7 over three rounds) and 16 stays.
             // BLS12-381 (14-limb field: its reduction tail costs 2.3 x as much per bucket) loses 2 % with 17 bits at 2^18 and ties at 2^19.
             if ((log_size == 18 || log_size == 19) && FPP::N <= 8) c_ = 17;
+            // 2^17 on a throughput context: the tie broke when the accumulate units under load went to 48 entries (run_msm_body:
+            // a bucket of 30 entries is then ONE partial sum and the merge of 65 536 buckets costs next to nothing).  Same box,
+            // two rounds, two boxes: 16 bits 516.8 / 516.1 and 529.4 / 528.4, 17 bits with long units 533.2 / 532.1 and
+            // 544.5 / 548.7 proofs/s (+3 %); a lone proof 3.21 -> 3.24 ms.  (18 bits: 497; 2^16 with 17 bits: -1.5 %.)
+            if (log_size == 17 && slots > 2 && FPP::N <= 8) c_ = 17;
         }
         if (c_ < 7 || c_ > 20) { set_error("msm_window %d out of [7,20]", c_); return APK_ERR_ARG; }
         // c = 17 counts in packed 16-bit halves: a sort slice (at most msm_G_max_ of them) must stay below 2^16 entries

@@ -421,7 +421,8 @@ typedef struct {
     uint64_t ntt_radix4_by_load;        /* ... radix-4 only BECAUSE other proofs were in flight (2^17..2^19) */
     uint64_t tail_fill_proofs;          /* lone proofs whose coset transforms ran beside the MSM tails (side stream) */
     uint64_t host_lincomb_pooled;       /* [lin] combinations dealt to the context's parked host threads */
-    uint64_t reserved[8];
+    uint64_t msm_units_by_load;         /* MSM batches whose accumulate units were lengthened BECAUSE other proofs were in flight */
+    uint64_t reserved[7];
 } apk_path_counts;
 int apk_paths_read(apk_ctx* ctx, apk_path_counts* out, int reset);
 

@@ -892,6 +892,8 @@ def test_proofs_under_load_match_the_c_oracle(gpu, cname, log_n):
     # the loaded forms ran (nearly every batch has other proofs beside it; the first and last few may not)
     assert loaded["msm_lean_tail"] >= loaded["msm_batches"] // 2, loaded
     assert loaded["msm_rowcol_serial"] >= loaded["msm_batches"] // 2, loaded
+    if log_n >= 16:
+        assert loaded["msm_units_by_load"] >= loaded["msm_batches"] // 2, loaded        # 48-entry accumulate units (from 2^16 bases)
     assert loaded["msm_sort_two_level"] >= loaded["msm_batches"] // 2, loaded
     if log_n >= 17:
         assert loaded["ntt_radix4_by_load"] >= 1, loaded
@@ -901,7 +903,7 @@ def test_proofs_under_load_match_the_c_oracle(gpu, cname, log_n):
     lone = MarshalProof(ap_plonk.Proof(cv, _prove_resident(pk, dptr, pub, bl)))
     alone = pk.paths(reset=True)
     assert lone == want
-    assert alone["proofs"] == 1 and alone["msm_lean_tail"] == 0 and alone["msm_rowcol_serial"] == 0 and alone["tail_fill_proofs"] == 1, alone
+    assert alone["proofs"] == 1 and alone["msm_lean_tail"] == 0 and alone["msm_rowcol_serial"] == 0 and alone["tail_fill_proofs"] == 1 and alone["msm_units_by_load"] == 0, alone
     for p in dptr:
         check(lib.apk_device_free(pk.ctx, p))
     pk.close()
