@@ -478,7 +478,11 @@ class CurveBackend : public Backend {
         // 2^19 +0.5 %; a lone proof pays for long units (3.25 -> 3.43 ms at 32), so only with others in flight.
         // (2^15 bases and BLS12-381 2^14 lose 1-2 % with them - too few waves left even for a busy GPU - so from 2^16 bases.)
         static const uint32_t unit_loaded = (uint32_t)env_int("APK_MSM_UNIT_LOADED", 48, 0, MSM_UNIT_MAX);
-        if (!unit_env && others_busy && unit < unit_loaded && msm_bases_ >= 65536u) { unit = unit_loaded; path(P_UNIT_LOADED); }
+        static const uint32_t unit_loaded_bases = (uint32_t)env_int("APK_MSM_UNIT_LOADED_BASES", 65536, 0, 1 << 30);
+        // Where it pays is where one unit holds a whole bucket (the merge then has nothing to add): 2^16 bases with 16-bit
+        // windows 967 / 963 -> 985 / 977, with 15-bit windows (68 entries per bucket) 976 / 972 -> 951 / 950 - so only up to 64
+        // entries per bucket on average.
+        if (!unit_env && others_busy && unit < unit_loaded && msm_bases_ >= unit_loaded_bases && entries <= 64ull * total_buckets) { unit = unit_loaded; path(P_UNIT_LOADED); }
         // Small batches (a lone 2^14 MSM: 360 k entries) do not even give every SIMD one wave at 16 entries per lane, and a lone
         // wave issues a dependent instruction every ~6.5 cycles: the accumulate launch is then 16 additions long whatever the
         // size (BLS12-381 2^14: 229 of the MSM's 580 us).  Below one wave per SIMD the unit shrinks - down to
@@ -1050,6 +1054,8 @@ class CurveBackend : public Backend {
             // 16 -> 825; BN254 2^15: 13 -> 1 274, 14 -> 1 224, 15 -> 1 274 (and the lower latency)
             else if (slots > 2 && log_size == 14) c_ = 13;
             else if (slots > 2 && (log_size == 15 || log_size == 16)) c_ = 15;
+            // (2^16 went to 16 bits with the long accumulate units under load, below: 976 / 972 -> 985 / 977 proofs/s, same box)
+            if (slots > 2 && log_size == 16 && FPP::N <= 8) c_ = 16;
             // 2^18 and 2^19: 17 bits (15 windows; the histogram's packed 16-bit counters hold up to 786 432 bases).  Round 5, same
             // box, two interleaved rounds: 2^18 251 / 253 -> 260 / 261 proofs/s, 2^19 125.1 / 125.3 -> 130.0 / 130.5 (bit-heavy
             // witness +2.6 % / +3 %), a lone proof 5.24 -> 5.12 and 9.59 -> 9.24 ms; at 2^17 the two widths tie (528.8 against
