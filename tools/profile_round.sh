@@ -6,7 +6,7 @@ O=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout 400 python bench.py > $O/${TAG}_bench_bn254_2p17.log 2>&1; tail -1 $O/${TAG}_bench_bn254_2p17.log > $O/${TAG}_bench_bn254_2p17.json
 timeout 300 python bench.py --curve bls12_381 --log-n 14 > $O/${TAG}_bench_bls12381_2p14.log 2>&1; tail -1 $O/${TAG}_bench_bls12381_2p14.log > $O/${TAG}_bench_bls12381_2p14.json
-timeout 1500 python bench.py --curve bls12_381 --log-n 21 --bsb22 1 --inflight 4 --steps 4 --warmup 1 $BLS21_FLAGS > $O/${TAG}_bench_bls12381_2p21_bsb22.log 2>&1; tail -1 $O/${TAG}_bench_bls12381_2p21_bsb22.log > $O/${TAG}_bench_bls12381_2p21_bsb22.json
+timeout 1500 python bench.py --curve bls12_381 --log-n 21 --bsb22 1 --inflight 8 --steps 4 --warmup 1 $BLS21_FLAGS > $O/${TAG}_bench_bls12381_2p21_bsb22.log 2>&1; tail -1 $O/${TAG}_bench_bls12381_2p21_bsb22.log > $O/${TAG}_bench_bls12381_2p21_bsb22.json
 timeout 200 python bench.py --mode msm-sharded --steps 50 > $O/${TAG}_bench_msm_sharded.log 2>&1; tail -1 $O/${TAG}_bench_msm_sharded.log > $O/${TAG}_bench_msm_sharded.json
 timeout 200 python bench.py --mode prove-split --curve bls12_381 --log-n 21 --steps 5 --warmup 1 > $O/${TAG}_bench_prove_split_2p21.log 2>&1; tail -1 $O/${TAG}_bench_prove_split_2p21.log > $O/${TAG}_bench_prove_split_2p21.json
 # kernel traces: one proof at a time (sequential) and the bench's 32 callers (saturated)
