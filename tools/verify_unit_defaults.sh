@@ -1,3 +1,6 @@
+#!/bin/bash
+# The defaults that came out of tools/sweep_unit_window.sh against the forms they replaced, two interleaved rounds of bench.py lines
+# per setting (2^16 / 2^17 / 2^18 BN254, 2^14 / 2^17 BLS12-381).  usage: bash tools/verify_unit_defaults.sh   -> gpurun_out/verify_unit/summary.txt
 O=gpurun_out/verify_unit; mkdir -p $O; rm -f $O/*.jsonl
 b() { tag=$1; shift; env "$@" 2>/dev/null | tail -1 >> $O/$tag.jsonl; }
 for r in 1 2; do
