@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Soak: T threads prove the same BN254 2^log_n instance over and over on one context; every proof must have the same
 bytes (same inputs + same blinding scalars -> byte-identical proofs), so any race between slots shows up as a second hash.
-usage: python tools/soak.py [log_n] [threads] [rounds]"""
+usage: python tools/soak.py [log_n] [threads] [rounds] [bn254|bls12_381] [slots]
+(slots defaults to the thread count; fewer slots than threads also exercises the wait at the slot gate, two or three threads the
+host-side paths of a nearly idle context: parked threads, the early [H] part)"""
 import ctypes as C
 import hashlib
 import os
@@ -16,11 +18,12 @@ from algoplonk_amd._lib import lib, check
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 17
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-cv = ecc.BN254
-wl = workloads.random_circuit(cv, log_n, 0xA190)
+cv = ecc.BLS12_381 if len(sys.argv) > 4 and sys.argv[4] == "bls12_381" else ecc.BN254
+slots = int(sys.argv[5]) if len(sys.argv) > 5 else T
+wl = workloads.random_circuit(cv, log_n, 0xA190 if cv is ecc.BN254 else 0xA191)
 n = wl.ccs.domain_size()
 srs = setup.unsafe_srs(cv, n, wl.tau)
-pk, vk = plonk.Setup(wl.ccs, srs, slots=T)
+pk, vk = plonk.Setup(wl.ccs, srs, slots=slots)
 L, R, O = frontend.wire_columns(wl.ccs, wl.solution)
 dptr = []
 for b in (cv.fr_vector(v) for v in (L, R, O)):
