@@ -156,6 +156,7 @@ class CurveBackend : public Backend {
         DevBuf sort_tmp, counts, hist, offsets, unit_off, full_off, rem_rank, rem_list, merge_rank, merge_list, scan_blk, sorted, partial, bucket_sum, rowcol, bit_partial, result, result_xyzz, done_count;
         void* h_pinned = nullptr;  // small pinned staging for results: [0,1024) affine, [1024,2048) XYZZ, [2048,4096) scalars
         uint32_t pending_pts = 0;  // MSM sums waiting in h_pinned for their affine conversion (sync_results)
+        uint8_t* d_pinned = nullptr;   // the device's view of h_pinned (zero-copy results: the last kernel of a batch writes them there), or null
         std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;   // APK_MSM_GRAPH
         bool hook_pending = false; // a commitment batch handed to the context's commit hook at the next sync_results()
         int hook_basis = 0;
@@ -750,6 +751,7 @@ class CurveBackend : public Backend {
         else
             msm_rowcol_kernel<FPP><<<dim3(rows + cols, a.batch), 256, 0, st>>>(ptr<PtU>(s.bucket_sum), NB_, rows, cols, ptr<PtU>(s.rowcol));
         KCHK();
+        Pt* const res_out = s.d_pinned ? reinterpret_cast<Pt*>(s.d_pinned + 1024) : ptr<Pt>(s.result_xyzz);
         // the sums leave the device in XYZZ form: the one field inversion of the affine conversion takes a lone GPU lane
         // ~100 us and the host a few; sync_results() finishes them into h_out (= the slot's pinned buffer)
         if (!APK_PHASE(16)) {
@@ -758,7 +760,7 @@ class CurveBackend : public Backend {
             const uint32_t threads = 4 * lt > 256 ? 4 * lt : 256;
             const size_t lds = (size_t)(lt > 64 ? lt : 64) * sizeof(PtU);
             msm_bitsum_final_quad_kernel<FPP><<<dim3(nbits, 2, a.batch), threads, lds, st>>>(
-                ptr<PtU>(s.rowcol), rows, cols, lt, ptr<PtU>(s.bit_partial), ptr<uint32_t>(s.done_count), cols_log, ptr<Pt>(s.result_xyzz));
+                ptr<PtU>(s.rowcol), rows, cols, lt, ptr<PtU>(s.bit_partial), ptr<uint32_t>(s.done_count), cols_log, res_out);
             KCHK();
         } else {
             if (quad & 2)
@@ -767,14 +769,14 @@ class CurveBackend : public Backend {
                 msm_bitsum_kernel<FPP><<<dim3(nbits, 2, a.batch), 256, 0, st>>>(ptr<PtU>(s.rowcol), rows, cols, ptr<PtU>(s.bit_partial));
             KCHK();
             if (quad & 4)
-                msm_final_quad_kernel<FPP><<<a.batch, 256, 0, st>>>(ptr<PtU>(s.bit_partial), nbits, cols_log, nullptr, ptr<Pt>(s.result_xyzz));
+                msm_final_quad_kernel<FPP><<<a.batch, 256, 0, st>>>(ptr<PtU>(s.bit_partial), nbits, cols_log, nullptr, res_out);
             else
-                msm_final_kernel<FPP><<<a.batch, 64, 0, st>>>(ptr<PtU>(s.bit_partial), nbits, cols_log, nullptr, ptr<Pt>(s.result_xyzz));
+                msm_final_kernel<FPP><<<a.batch, 64, 0, st>>>(ptr<PtU>(s.bit_partial), nbits, cols_log, nullptr, res_out);
             KCHK();
         }
         if (stats_on_) HIPCHK(hipEventRecord(s.ev1, st));
         (void)h_out;
-        HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(s.h_pinned) + 1024, s.result_xyzz.p, a.batch * sizeof(Pt), hipMemcpyDeviceToHost, st));
+        if (!s.d_pinned) HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(s.h_pinned) + 1024, s.result_xyzz.p, a.batch * sizeof(Pt), hipMemcpyDeviceToHost, st));
         s.pending_pts = a.batch;
         if (stats_on_) {
             HIPCHK(hipEventSynchronize(s.ev1));
@@ -896,6 +898,15 @@ class CurveBackend : public Backend {
         HIPCHK(hipEventCreate(&s.ev3));
         if (hipEventCreateWithFlags(&s.ev_sync, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); s.ev_sync = nullptr; }
         HIPCHK(hipHostMalloc(&s.h_pinned, 4096, hipHostMallocDefault));
+        // MSM sums and evaluations are a few hundred bytes behind a chain of kernels: the kernel that produces them writes them
+        // straight into this (coherent, device-visible) host buffer instead of a device buffer + a copy launch - one launch less
+        // per batch, and under load every launch of a proof's chain waits ~0.1 ms for its turn.  APK_ZERO_COPY=0: device buffer + copy.
+        static const int zero_copy = env_int("APK_ZERO_COPY", 1, 0, 1);
+        if (zero_copy) {
+            void* dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, s.h_pinned, 0) == hipSuccess) s.d_pinned = static_cast<uint8_t*>(dp);
+            else (void)hipGetLastError();
+        }
         const size_t fn = (size_t)n_ * sizeof(Fr), fn3 = (size_t)(n_ + 4) * sizeof(Fr), f4 = (size_t)n4_ * sizeof(Fr);
         if (msm_only_) {
             CHK(s.scratch_in.alloc((size_t)msm_bases_ * sizeof(Fr)));
@@ -1470,8 +1481,12 @@ class CurveBackend : public Backend {
         for (int i = 0; i < ea.count; i++) if (ea.len[i] > maxlen) maxlen = ea.len[i];
         const uint32_t nblocks = cdiv(maxlen, EVAL_BLOCK);
         eval_partial_kernel<FRP><<<dim3(nblocks, ea.count), POLY_THREADS, 0, st>>>(ea, pw, nblocks, ptr<Fr>(s.eval_partial)); KCHK();
-        eval_final_kernel<FRP><<<ea.count, POLY_THREADS, 0, st>>>(ptr<Fr>(s.eval_partial), nblocks, ptr<Fr>(s.eval_result)); KCHK();
-        HIPCHK(hipMemcpyAsync(h_out, s.eval_result.p, ea.count * sizeof(Fr), hipMemcpyDeviceToHost, st));
+        // (h_out lies in the slot's pinned buffer: with the zero-copy view the kernel writes the values there itself)
+        const bool direct = s.d_pinned && reinterpret_cast<uint8_t*>(h_out) >= reinterpret_cast<uint8_t*>(s.h_pinned) &&
+                            reinterpret_cast<uint8_t*>(h_out) + ea.count * sizeof(Fr) <= reinterpret_cast<uint8_t*>(s.h_pinned) + 4096;
+        Fr* const ev_out = direct ? reinterpret_cast<Fr*>(s.d_pinned + (reinterpret_cast<uint8_t*>(h_out) - reinterpret_cast<uint8_t*>(s.h_pinned))) : ptr<Fr>(s.eval_result);
+        eval_final_kernel<FRP><<<ea.count, POLY_THREADS, 0, st>>>(ptr<Fr>(s.eval_partial), nblocks, ev_out); KCHK();
+        if (!direct) HIPCHK(hipMemcpyAsync(h_out, s.eval_result.p, ea.count * sizeof(Fr), hipMemcpyDeviceToHost, st));
         return APK_OK;
     }
 
