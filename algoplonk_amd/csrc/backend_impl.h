@@ -898,6 +898,7 @@ class CurveBackend : public Backend {
         HIPCHK(hipEventCreate(&s.ev3));
         if (hipEventCreateWithFlags(&s.ev_sync, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); s.ev_sync = nullptr; }
         HIPCHK(hipHostMalloc(&s.h_pinned, 4096, hipHostMallocDefault));
+        memset(s.h_pinned, 0, 4096);   // (the tail-flag word is only ever written by a failing proof)
         // MSM sums and evaluations are a few hundred bytes behind a chain of kernels: the kernel that produces them writes them
         // straight into this (coherent, device-visible) host buffer instead of a device buffer + a copy launch - one launch less
         // per batch, and under load every launch of a proof's chain waits ~0.1 ms for its turn.  APK_ZERO_COPY=0: device buffer + copy.
@@ -1823,8 +1824,9 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
             g.data[0], g.data[1]);
         KCHK();
         gp_scan_block_kernel<FRP><<<dim3(nb, 2), POLY_THREADS, 0, st>>>(g, n); KCHK();
-        gp_scan_totals_kernel<FRP><<<2, POLY_THREADS, 0, st>>>(g, nb); KCHK();
-        HIPCHK(hipMemcpyAsync(hfr, g.tot[1] + nb, sizeof(Fr), hipMemcpyDeviceToHost, st));
+        Fr* const tot_out = s.d_pinned ? reinterpret_cast<Fr*>(s.d_pinned + 2048) : g.tot[1] + nb;     // hfr[0], from the device
+        gp_scan_totals_kernel<FRP><<<2, POLY_THREADS, 0, st>>>(g, nb, tot_out); KCHK();
+        if (!s.d_pinned) HIPCHK(hipMemcpyAsync(hfr, g.tot[1] + nb, sizeof(Fr), hipMemcpyDeviceToHost, st));
         CHK(sync_results(s));
         const Fr den_total_inv = Fr::inv(hfr[0]);
         gp_finish_kernel<FRP><<<cdiv(n, POLY_THREADS), POLY_THREADS, 0, st>>>(g, n, den_total_inv, ptr<Fr>(s.zlag)); KCHK();
@@ -1924,8 +1926,9 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         s.epoch++;
         const uint32_t tail4 = (n4_ - 3 * (n + 2)) * (uint32_t)(sizeof(Fr) / 16);
         tail_nonzero_kernel<0><<<cdiv(tail4, 256 * 8) < 512 ? cdiv(tail4, 256 * 8) : 512, 256, 0, st>>>(
-            reinterpret_cast<const uint4*>(ptr<Fr>(s.hcan) + 3 * (size_t)(n + 2)), tail4, s.epoch, ptr<uint32_t>(s.tail_flag)); KCHK();
-        HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(s.h_pinned) + 3072, s.tail_flag.p, 4, hipMemcpyDeviceToHost, st));
+            reinterpret_cast<const uint4*>(ptr<Fr>(s.hcan) + 3 * (size_t)(n + 2)), tail4, s.epoch,
+            s.d_pinned ? reinterpret_cast<uint32_t*>(s.d_pinned + 3072) : ptr<uint32_t>(s.tail_flag)); KCHK();
+        if (!s.d_pinned) HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(s.h_pinned) + 3072, s.tail_flag.p, 4, hipMemcpyDeviceToHost, st));
     }
     CHK(sync_results(s));
     if (*reinterpret_cast<const volatile uint32_t*>(reinterpret_cast<const uint8_t*>(s.h_pinned) + 3072) == s.epoch) {

@@ -201,11 +201,12 @@ __global__ void __launch_bounds__(POLY_THREADS) gp_scan_block_kernel(GpScan<FR> 
     scan_block_body<FR, OpMul>(g.data[blockIdx.y], count, blockIdx.y != 0, g.tot[blockIdx.y]);
 }
 template <class FR>
-__global__ void __launch_bounds__(POLY_THREADS) gp_scan_totals_kernel(GpScan<FR> g, uint32_t nblocks) {
+__global__ void __launch_bounds__(POLY_THREADS) gp_scan_totals_kernel(GpScan<FR> g, uint32_t nblocks, Fe<FR>* __restrict__ total_out) {
     wave_priority<APK_PRIO_FR>();
     Fe<FR> total = scan_totals_body<FR, OpMul>(g.tot[blockIdx.x], nblocks);
-    // the product of all denominators: inverted on the HOST (a lone GPU lane needs ~100 us for one Kaliski inversion)
-    if (blockIdx.x == 1 && threadIdx.x == POLY_THREADS - 1) g.tot[1][nblocks] = total;
+    // the product of all denominators: inverted on the HOST (a lone GPU lane needs ~100 us for one Kaliski inversion); total_out
+    // is the slot's pinned host buffer seen from the device, or a device word the host copies back
+    if (blockIdx.x == 1 && threadIdx.x == POLY_THREADS - 1) *total_out = total;
 }
 // Z[0] = 1; Z[k] = num_prefix_incl[k-1] * den_suffix_incl[k] / den_total
 template <class FR>
@@ -494,7 +495,9 @@ __global__ void __launch_bounds__(256) tail_nonzero_kernel(const uint4* __restri
         const uint4 v = words[i];
         acc |= v.x | v.y | v.z | v.w;
     }
-    if (__ballot(acc != 0) != 0 && (threadIdx.x & 63) == 0) atomicMax(flag, epoch);
+    // every writer stores the same word (the slot's epochs only grow and its proofs run one after the other), so a plain store
+    // does: `flag` may be host memory, where a device atomic is not a given
+    if (__ballot(acc != 0) != 0 && (threadIdx.x & 63) == 0) *reinterpret_cast<volatile uint32_t*>(flag) = epoch;
 }
 
 // z == 0 fallback: q[j] = f[j+1]
