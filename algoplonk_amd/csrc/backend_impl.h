@@ -1962,7 +1962,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     bool lin_h_done = false;
     const Fr zw = zeta * omega_;
     const bool z0 = zeta.is_zero();
-    const Fr zeta_inv = Fr::inv(zeta), zw_inv = Fr::inv(zw);
+    const Fr zeta_inv = Fr::inv(zeta), zw_inv = zeta_inv * omega_inv_;   // (one host inversion, ~10 us, before the launches below)
     {
         Fr* outs[4] = {ptr<Fr>(s.pw_z), ptr<Fr>(s.pw_zw), ptr<Fr>(s.pw_zi), ptr<Fr>(s.pw_zwi)};
         const Fr ws[4] = {zeta, zw, zeta_inv, zw_inv};
@@ -1981,6 +1981,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
             derive_powers_kernel<FRP><<<dim3(cdiv(n + 3, POLY_THREADS), 2), POLY_THREADS, 0, st>>>(dp, ptr<Fr>(twu_n_), n, n + 3); KCHK();
         }
     }
+    std::vector<Fr> lag_w, lag_den;
     Fr ev[EVAL_MAX];
     {
         EvalArgs<FRP> ea{};
@@ -2001,6 +2002,31 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         zn_m1 = Fr::pow_u64(zeta, n) - Fr::one();
         zn2 = Fr::pow_u64(zeta, n + 2);
         mz = Fr::neg(zn_m1);
+        // (so do the Lagrange terms: worked out here, while the GPU evaluates)
+        // L_i(zeta) = omega^i (zeta^n - 1) / (n (zeta - omega^i)) for the rows the prover wrote into Qk (public inputs, commitment
+        // hashes) and for row 0: one shared inversion
+        {
+            std::vector<uint32_t> rows = {0};
+            for (uint32_t i = 1; i < nb_public_; i++) rows.push_back(i);
+            for (uint32_t k = 0; k < nb_commit_; k++) rows.push_back(nb_public_ + cci_[k]);
+            Fr wi = Fr::one();
+            uint32_t at = 0;
+            for (uint32_t row : rows) {
+                if (row == at + 1) wi = wi * omega_; else if (row != at) wi = Fr::pow_u64(omega_, row);
+                at = row;
+                lag_w.push_back(wi);
+                lag_den.push_back(zeta - wi);
+            }
+            std::vector<Fr> pref(lag_den.size() + 1, Fr::one());
+            for (size_t i = 0; i < lag_den.size(); i++) pref[i + 1] = pref[i] * lag_den[i];
+            Fr inv = Fr::inv(pref.back());
+            const Fr scale = zn_m1 * n_inv_;
+            for (size_t i = lag_den.size(); i-- > 0;) {
+                const Fr di = inv * pref[i];
+                inv = inv * lag_den[i];
+                lag_w[i] = lag_w[i] * scale * di;        // = L_row(zeta)
+            }
+        }
         static const int early_h = env_int("APK_LIN_EARLY_H", 1, 0, 1);
         if (host_idle && early_h && (pool || FPP::N <= 8)) {   // (one thread takes longer over BLS12-381's three than the GPU over the evaluations)
             const auto t_lc = std::chrono::steady_clock::now();
@@ -2018,31 +2044,6 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     const Fr zshift = ev[5 + nb_commit_];
     // coefficients of the linearised polynomial (templateLogicSigBN254.go:195-201,231-254)
     const Fr alpha2 = alpha * alpha;
-    // L_i(zeta) = omega^i (zeta^n - 1) / (n (zeta - omega^i)) for the rows the prover wrote into Qk (public inputs, commitment
-    // hashes) and for row 0: one shared inversion
-    std::vector<Fr> lag_w, lag_den;
-    {
-        std::vector<uint32_t> rows = {0};
-        for (uint32_t i = 1; i < nb_public_; i++) rows.push_back(i);
-        for (uint32_t k = 0; k < nb_commit_; k++) rows.push_back(nb_public_ + cci_[k]);
-        Fr wi = Fr::one();
-        uint32_t at = 0;
-        for (uint32_t row : rows) {
-            if (row == at + 1) wi = wi * omega_; else if (row != at) wi = Fr::pow_u64(omega_, row);
-            at = row;
-            lag_w.push_back(wi);
-            lag_den.push_back(zeta - wi);
-        }
-        std::vector<Fr> pref(lag_den.size() + 1, Fr::one());
-        for (size_t i = 0; i < lag_den.size(); i++) pref[i + 1] = pref[i] * lag_den[i];
-        Fr inv = Fr::inv(pref.back());
-        const Fr scale = zn_m1 * n_inv_;
-        for (size_t i = lag_den.size(); i-- > 0;) {
-            const Fr di = inv * pref[i];
-            inv = inv * lag_den[i];
-            lag_w[i] = lag_w[i] * scale * di;        // = L_row(zeta)
-        }
-    }
     const Fr lag0 = lag_w[0];
     // lin(zeta) as the verifier derives it from the quotient identity (templateLogicSigBN254.go:203-218) - the
     // identity holds exactly (the tail check above), so this IS the evaluation of the linearised polynomial
