@@ -420,7 +420,7 @@ typedef struct {
     uint64_t ntt_radix4;                /* ... with radix-4 steps */
     uint64_t ntt_radix4_by_load;        /* ... radix-4 only BECAUSE other proofs were in flight (2^17..2^19) */
     uint64_t tail_fill_proofs;          /* lone proofs whose coset transforms ran beside the MSM tails (side stream) */
-    uint64_t host_lincomb_pooled;       /* [lin] combinations dealt to the context's parked host threads */
+    uint64_t host_lincomb_pooled;       /* [lin] combinations of nearly idle contexts dealt to parked host threads (BLS12-381 by default; BN254 with APK_HOST_LINCOMB_THREADS > 1) */
     uint64_t msm_units_by_load;         /* MSM batches whose accumulate units were lengthened BECAUSE other proofs were in flight */
     uint64_t reserved[7];
 } apk_path_counts;
