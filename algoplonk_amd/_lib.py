@@ -16,7 +16,7 @@ APK_BN254 = 0
 APK_BLS12_381 = 1
 APK_OK = 0
 APK_ERR_ARG, APK_ERR_HIP, APK_ERR_STATE, APK_ERR_WITNESS, APK_ERR_VERIFY = 1, 2, 3, 4, 5
-ABI_VERSION = 4
+ABI_VERSION = 5
 G1_MAX = 96
 G2_MAX = 192
 MAX_COMMITMENTS = 2
@@ -29,6 +29,7 @@ SYMBOLS = [
     "apk_prove", "apk_prove_device", "apk_verify", "apk_verify_ex", "apk_g2_decompress", "apk_g2_mul_generator", "apk_g1_mul_batch", "apk_g1_decompress", "apk_g1_to_lagrange", "apk_marshal_proof", "apk_marshal_public_inputs",
     "apk_fe_from_be", "apk_fe_to_be", "apk_hash_fr", "apk_host_fe_op", "apk_host_g1_op", "apk_g1_sum",
     "apk_device_alloc", "apk_device_free", "apk_device_upload", "apk_device_download",
+    "apk_host_alloc", "apk_host_free", "apk_host_register", "apk_host_unregister",
     "apk_stats_enable", "apk_stats_read", "apk_paths_read",
     "apk_ctx_set_wire_hook", "apk_coset_ntt_device",
     "apk_comm_create", "apk_comm_destroy", "apk_comm_rank", "apk_comm_world", "apk_comm_barrier", "apk_comm_max_f64", "apk_comm_bind",
@@ -98,6 +99,7 @@ class Stats(C.Structure):
         ("msm_accumulate_ms", C.c_double), ("msm_accumulate_launches", C.c_uint64), ("msm_pairs", C.c_uint64),
         ("msm_total_ms", C.c_double), ("msm_batches", C.c_uint64), ("ntt_ms", C.c_double), ("ntt_elements", C.c_uint64),
         ("prove_ms", C.c_double), ("proofs", C.c_uint64), ("round_ms", C.c_double * 4), ("host_lincomb_ms", C.c_double),
+        ("msm_sort_ms", C.c_double), ("msm_tail_ms", C.c_double),
     ]
 
 
@@ -105,8 +107,8 @@ class PathCounts(C.Structure):
     """apk_path_counts: which forms of the load-dependent kernels ran (include/apk.h)."""
     _names = ["proofs", "msm_batches", "msm_sort_two_level", "msm_sort_two_level_by_load", "msm_sort_fused", "msm_lean_tail",
               "msm_rowcol_serial", "msm_combine_quad", "msm_small_units", "msm_one_launch", "msm_lagrange_wires", "ntt_sequences",
-              "ntt_radix4", "ntt_radix4_by_load", "tail_fill_proofs", "host_lincomb_pooled", "msm_units_by_load"]
-    _fields_ = [(n, C.c_uint64) for n in _names] + [("reserved", C.c_uint64 * 7)]
+              "ntt_radix4", "ntt_radix4_by_load", "tail_fill_proofs", "host_lincomb_pooled", "msm_units_by_load", "host_inputs"]
+    _fields_ = [(n, C.c_uint64) for n in _names] + [("reserved", C.c_uint64 * 6)]
 
     def as_dict(self) -> dict:
         return {n: int(getattr(self, n)) for n in self._names}
@@ -175,6 +177,10 @@ def _load() -> C.CDLL:
     lib.apk_device_free.argtypes = [vp, vp]
     lib.apk_device_upload.argtypes = [vp, vp, vp, sz]
     lib.apk_device_download.argtypes = [vp, vp, vp, sz]
+    lib.apk_host_alloc.argtypes = [i32, sz, C.POINTER(vp)]
+    lib.apk_host_free.argtypes = [vp]
+    lib.apk_host_register.argtypes = [vp, sz]
+    lib.apk_host_unregister.argtypes = [vp]
     lib.apk_stats_enable.argtypes = [vp, i32]
     lib.apk_stats_read.argtypes = [vp, C.POINTER(Stats), i32]
     lib.apk_paths_read.argtypes = [vp, C.POINTER(PathCounts), i32]

@@ -277,6 +277,19 @@ struct apk_ctx {
     int curve;
 };
 
+// Live contexts: a communicator keeps a pointer to the context it was bound to, and host languages with finalizers (the Python
+// mirror; a Go host with runtime.SetFinalizer) may destroy the context FIRST.  apk_comm_destroy / apk_comm_bind ask here before they
+// take their hooks off a context (comm.cpp clear_ctx_hooks): a destroyed one is simply forgotten.
+#include <mutex>
+#include <set>
+namespace apk {
+static std::mutex g_live_mu;
+static std::set<const void*>& live_set() { static std::set<const void*> s; return s; }
+static void ctx_register(const void* c) { std::lock_guard<std::mutex> g(g_live_mu); live_set().insert(c); }
+static void ctx_forget(const void* c) { std::lock_guard<std::mutex> g(g_live_mu); live_set().erase(c); }
+bool ctx_alive(const void* c) { std::lock_guard<std::mutex> g(g_live_mu); return live_set().count(c) != 0; }
+}
+
 extern "C" {
 
 const char* apk_last_error(void) { return g_err.c_str(); }
@@ -304,6 +317,7 @@ int apk_ctx_create(const apk_circuit_desc* d, apk_ctx** out) {
     int r = be->init(d);
     if (r != APK_OK) { delete be; return r; }
     *out = new apk_ctx{be, d->curve};
+    ctx_register(*out);
     return APK_OK;
 }
 
@@ -317,11 +331,13 @@ int apk_msm_ctx_create(int curve, int device, const void* bases, uint64_t count,
     int r = be->init_msm_only(device, bases, count, msm_window);
     if (r != APK_OK) { delete be; return r; }
     *out = new apk_ctx{be, curve};
+    ctx_register(*out);
     return APK_OK;
 }
 
 void apk_ctx_destroy(apk_ctx* ctx) {
     if (!ctx) return;
+    ctx_forget(ctx);
     delete ctx->be;
     delete ctx;
 }
@@ -363,6 +379,46 @@ int apk_prove_device(apk_ctx* ctx, const void* L, const void* R, const void* O, 
     NEED_CTX();
     return ctx->be->prove(L, R, O, true, pub, bl, pi2, out);
 }
+// page-locked host memory for apk_prove's inputs (include/apk.h)
+static int host_mem_device(int device) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) { (void)hipGetLastError(); set_error("no HIP device available (%s); libapk has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e)); return APK_ERR_HIP; }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (%d devices)", device, ndev); return APK_ERR_ARG; }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) { set_error("hipSetDevice: %s", hipGetErrorString(e)); return APK_ERR_HIP; }
+    return APK_OK;
+}
+int apk_host_alloc(int device, size_t bytes, void** p) {
+    if (!p || bytes == 0) { set_error("null argument"); return APK_ERR_ARG; }
+    *p = nullptr;
+    int rc = host_mem_device(device);
+    if (rc != APK_OK) return rc;
+    hipError_t e = hipHostMalloc(p, bytes, hipHostMallocPortable);
+    if (e != hipSuccess) { (void)hipGetLastError(); *p = nullptr; set_error("hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); return APK_ERR_HIP; }
+    return APK_OK;
+}
+int apk_host_free(void* p) {
+    if (!p) return APK_OK;
+    hipError_t e = hipHostFree(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipHostFree: %s", hipGetErrorString(e)); return APK_ERR_HIP; }
+    return APK_OK;
+}
+int apk_host_register(void* p, size_t bytes) {
+    if (!p || bytes == 0) { set_error("null argument"); return APK_ERR_ARG; }
+    int rc = host_mem_device(0);
+    if (rc != APK_OK) return rc;
+    hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipHostRegister(%zu): %s", bytes, hipGetErrorString(e)); return APK_ERR_HIP; }
+    return APK_OK;
+}
+int apk_host_unregister(void* p) {
+    if (!p) return APK_OK;
+    hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipHostUnregister: %s", hipGetErrorString(e)); return APK_ERR_HIP; }
+    return APK_OK;
+}
+
 int apk_device_alloc(apk_ctx* ctx, size_t bytes, void** p) { NEED_CTX(); return ctx->be->dev_alloc(bytes, p); }
 int apk_device_free(apk_ctx* ctx, void* p) { NEED_CTX(); return ctx->be->dev_free(p); }
 int apk_device_upload(apk_ctx* ctx, void* d, const void* s, size_t b) { NEED_CTX(); return ctx->be->dev_upload(d, s, b); }

@@ -15,6 +15,9 @@ void set_error(const char* fmt, ...);
 // or an allocation size: nothing may abort across the C-ABI); `dflt` when the variable is unset or not a number.
 int env_int(const char* name, int dflt, int lo, int hi);
 
+// is this apk_ctx* still a live context (created and not yet destroyed)?  apk_api.cpp keeps the registry.
+bool ctx_alive(const void* ctx);
+
 struct Backend {
     virtual ~Backend() {}
     virtual int init(const apk_circuit_desc* d) = 0;

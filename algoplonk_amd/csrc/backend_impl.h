@@ -69,7 +69,7 @@ static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b -
 
 // kzg.ToLagrangeG1 on device buffers (defined at the end of this file): out[i] = [L_i(tau)]G1 from in[j] = [tau^j]G1
 template <class FRP, class FPP>
-int g1_to_lagrange_dev(const Affine<FPP>* d_in, uint64_t n, Affine<FPP>* d_out);
+int g1_to_lagrange_dev(const Affine<FPP>* d_in, uint64_t n, Affine<FPP>* d_out, hipStream_t st = nullptr);
 
 template <class FRP, class FPP, int CURVE_ID>
 class CurveBackend : public Backend {
@@ -147,7 +147,7 @@ class CurveBackend : public Backend {
         DevBuf pw_z, pw_zi, pw_zw, pw_zwi;  // powers of zeta, 1/zeta, omega*zeta, 1/(omega*zeta)   (n+3)
         DevBuf lin, folded, tmp, q1, q2;    // n+3
         DevBuf eval_partial, eval_result;
-        DevBuf pi2_lag[APK_MAX_COMMITMENTS], pi2_can[APK_MAX_COMMITMENTS], epi2[APK_MAX_COMMITMENTS];
+        DevBuf pi2_can[APK_MAX_COMMITMENTS], epi2[APK_MAX_COMMITMENTS];
         DevBuf scratch_in;  // upload staging for primitives
         DevBuf ntt_wide;    // NTT_MAX_BATCH transforms of 4n unsaturated-limb elements: the NTT's inter-pass form
         // MSM workspace
@@ -208,12 +208,41 @@ class CurveBackend : public Backend {
     // a witness value 0 / 1 / small then has 0 / 1 / few non-zero digits, where R^-1 tables see a uniform a * R mod r.
     MsmTables tab_can_, tab_lag_;
     int wires_lag_mode_ = -1;                            // APK_WIRES_LAGRANGE at context creation: -1 auto, 0 never, 1 always
+    // The extended Lagrange table is REQUIRED only by BSB22 commitments and by a forced Lagrange route (it is then built when the
+    // context is created and a failure fails the creation).  In the automatic mode without a caller's Lagrange SRS it is an
+    // optimisation some witnesses never use (uniform wires measure >= 90 % density; contexts with hooks commit canonically): the
+    // context keeps the canonical SRS on the device (8 / 12 MB at 2^17; the table itself would be 134 / 280 MB and a device iFFT in
+    // the exponent) and DERIVES the table the first time a proof's density - or the basis-1 primitive - asks for it, best effort:
+    // a failure (out of memory ...) clears the error and leaves the canonical route in place.
+    DevBuf srs_keep_;                                    // canonical SRS (n + 3 points) for the lazy derive; released after it
+    Aff lag_dk_[3];                                      // D_k = [tau^(n+k)]G1 - [tau^k]G1 (host, at creation)
+    std::mutex lag_mu_;
+    std::atomic<bool> lag_ready_{false};                 // tab_lag_ is built (release / acquire around the build)
+    std::atomic<bool> lag_failed_{false};                // a lazy derive failed: never tried again
     std::atomic<uint32_t> wire_density_pm_{0xffffffffu}; // non-zero digits of the last measured proof's wires, per mille of uniform
     std::atomic<uint32_t> proof_seq_{0};
     Aff vk_pts_[8 + APK_MAX_COMMITMENTS];
     HostFixedBase<FPP> vk_fixed_;   // host tables of [Ql][Qr][Qm][Qo][S3] for the [lin] combination (host_msm.h)
     std::vector<Slot*> slots_;
     SlotGate gate_;            // who proves on which slot; its busy count picks the load-dependent kernel forms (slot_gate.h)
+    // Host inputs (apk_prove: the call the cgo shim makes): a caller takes one of `in_sets_` BEFORE it takes a
+    // proving slot and sends L, R, O on the context's copy stream - so the upload of a proof that still waits for a slot (32 callers
+    // on 16 slots) runs beside the rounds of the proofs in flight, and a proof in flight never has a PCIe transfer in its chain.
+    // Pinned sources (apk_host_alloc / apk_host_register) are true asynchronous DMA; pageable ones are pinned on the fly by the
+    // runtime inside hipMemcpyAsync on the calling thread, which is waiting for a slot anyway (both 46 GB/s for 3 x 4 MiB on the
+    // boxes of this build: tools/ubench/h2d_probe.hip).  ONE copy stream for all sets: PCIe serialises the transfers anyway, and
+    // every further stream is a further hardware queue - a stream per set (32 of them beside the 16 proving streams, on 24
+    // hardware queues) cost 8 % proofs/s and 2.4 ms of a lone proof's latency (profiles/r06_host_inputs_ab.txt).
+    // Created on the first host-input proof.
+    struct InputSet {
+        DevBuf w[3], pi2[APK_MAX_COMMITMENTS];
+        hipStream_t copy = nullptr;     // the context's copy stream (not owned)
+        hipEvent_t ready = nullptr;
+        size_t index = 0;
+    };
+    std::vector<InputSet*> in_sets_;
+    SlotGate in_gate_;
+    hipStream_t copy_stream_ = nullptr;
     std::mutex mu_;
     // intra-proof multi-GPU (apk_ctx_set_commit_hook): the prover's commitments go through the host's hook instead of this GPU
     apk_commit_hook hook_ = nullptr;
@@ -235,7 +264,7 @@ class CurveBackend : public Backend {
     } sc_;
     // which forms the load-dependent choices took (apk_paths_read): always counted, relaxed atomics
     enum PathIdx { P_PROOFS, P_MSM_BATCHES, P_SORT2, P_SORT2_LOAD, P_SORT_FUSED, P_LEAN_TAIL, P_ROWCOL_SERIAL, P_COMBINE_QUAD, P_SMALL_UNITS,
-                   P_ONE_LAUNCH, P_LAGRANGE_WIRES, P_NTT_SEQ, P_NTT_R4, P_NTT_R4_LOAD, P_TAIL_FILL, P_LINCOMB_POOL, P_UNIT_LOADED, P_COUNT };
+                   P_ONE_LAUNCH, P_LAGRANGE_WIRES, P_NTT_SEQ, P_NTT_R4, P_NTT_R4_LOAD, P_TAIL_FILL, P_LINCOMB_POOL, P_UNIT_LOADED, P_HOST_INPUTS, P_COUNT };
     std::atomic<uint64_t> paths_[P_COUNT] = {};
     void path(PathIdx i) { paths_[i].fetch_add(1, std::memory_order_relaxed); }
     int paths_read(apk_path_counts* out, int reset) override {
@@ -253,6 +282,12 @@ class CurveBackend : public Backend {
 
     ~CurveBackend() override {
         (void)hipSetDevice(device_);
+        if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
+        for (InputSet* is : in_sets_) {
+            if (is->ready) (void)hipEventDestroy(is->ready);
+            delete is;
+        }
+        if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
         for (Slot* s : slots_) {
             if (s->stream) (void)hipStreamSynchronize(s->stream);
             for (auto& e : s->graphs) (void)hipGraphExecDestroy(e.second);
@@ -382,7 +417,46 @@ class CurveBackend : public Backend {
         return APK_OK;
     }
 
-    int run_msm(Slot& s, const MsmTables& T, const MsmBatchArgs& a, Aff* h_out) {
+    // tab_lag_ = plain multiples of the n Lagrange-SRS points (given on the host, or derived from d_srs on the device) + D_0..D_2
+    int build_lagrange_table(hipStream_t st, const Aff* d_srs, const void* h_lagrange) {
+        DevBuf lag;
+        CHK(lag.alloc((size_t)(n_ + 3) * sizeof(Aff)));
+        if (h_lagrange) HIPCHK(hipMemcpyAsync(lag.p, h_lagrange, (size_t)n_ * sizeof(Aff), hipMemcpyHostToDevice, st));
+        else CHK((g1_to_lagrange_dev<FRP, FPP>(d_srs, n_, ptr<Aff>(lag), st)));
+        HIPCHK(hipMemcpyAsync(ptr<Aff>(lag) + n_, lag_dk_, sizeof lag_dk_, hipMemcpyHostToDevice, st));
+        CHK(build_tables(st, ptr<Aff>(lag), n_ + 3, tab_lag_, /*plain=*/true));
+        HIPCHK(hipStreamSynchronize(st));     // `lag` is released on return
+        lag_ready_.store(true, std::memory_order_release);
+        return APK_OK;
+    }
+    bool lagrange_ready() const { return lag_ready_.load(std::memory_order_acquire); }
+    // can this context commit over the Lagrange SRS at all (now, or after a lazy derive)?
+    bool lagrange_possible() const { return lagrange_ready() || (srs_keep_.p && !lag_failed_.load(std::memory_order_relaxed)); }
+    // Best effort: true when the table is there on return.  A failed derive clears the HIP error state and is not retried.
+    bool ensure_lagrange_table(hipStream_t st) {
+        if (lagrange_ready()) return true;
+        std::lock_guard<std::mutex> lk(lag_mu_);
+        if (lagrange_ready()) return true;
+        if (!srs_keep_.p || lag_failed_.load(std::memory_order_relaxed)) return false;
+        const int rc = build_lagrange_table(st, ptr<Aff>(srs_keep_), nullptr);
+        if (rc != APK_OK) {
+            (void)hipGetLastError();
+            tab_lag_.table.release();
+            tab_lag_.built = false;
+            lag_failed_.store(true, std::memory_order_relaxed);
+            (void)hipStreamSynchronize(st);
+            srs_keep_.release();
+            return false;
+        }
+        srs_keep_.release();
+        return true;
+    }
+
+    int run_msm(Slot& s, const MsmTables& T, const MsmBatchArgs& a_in, Aff* h_out) {
+        // whether the scalars leave the Montgomery form in the sort is a property of the TABLE (R^-1 * P or P): derived here, so
+        // that no call site can pair a table with the wrong scalar form
+        MsmBatchArgs a = a_in;
+        a.plain = T.plain ? 1u : 0u;
         static const int graphs = env_int("APK_MSM_GRAPH", 0, 0, 1);
         if (!graphs || stats_on_) return run_msm_body(s, T, a, h_out);
         GraphKey key{};
@@ -780,10 +854,14 @@ class CurveBackend : public Backend {
         s.pending_pts = a.batch;
         if (stats_on_) {
             HIPCHK(hipEventSynchronize(s.ev1));
-            float tot = 0, acc = 0;
+            float tot = 0, acc = 0, srt = 0, tail = 0;
             HIPCHK(hipEventElapsedTime(&tot, s.ev0, s.ev1));
             HIPCHK(hipEventElapsedTime(&acc, s.ev2, s.ev3));
+            HIPCHK(hipEventElapsedTime(&srt, s.ev0, s.ev2));
+            HIPCHK(hipEventElapsedTime(&tail, s.ev3, s.ev1));
             std::lock_guard<std::mutex> g(stats_mu_);
+            stats_.msm_sort_ms += srt;
+            stats_.msm_tail_ms += tail;
             stats_.msm_total_ms += tot;
             stats_.msm_batches += 1;
             stats_.msm_accumulate_ms += acc;
@@ -804,6 +882,7 @@ class CurveBackend : public Backend {
         for (uint32_t b = 0; b < a.batch; b++)
             if (a.len[b] > T.n_bases || a.offset[b] > T.n_bases - a.len[b]) { set_error("msm: %u scalars exceed the %u bases", a.len[b], T.n_bases); return APK_ERR_ARG; }
         s.hook_pending = true; s.hook_basis = basis; s.hook_args = a;
+        s.hook_args.plain = T.plain ? 1u : 0u;
         return APK_OK;
     }
 
@@ -925,7 +1004,7 @@ class CurveBackend : public Backend {
         CHK(s.lin.alloc(fn3)); CHK(s.folded.alloc(fn3)); CHK(s.tmp.alloc(fn3)); CHK(s.q1.alloc(fn3)); CHK(s.q2.alloc(fn3));
         CHK(s.eval_partial.alloc((size_t)EVAL_MAX * cdiv(n_ + 4, EVAL_BLOCK) * sizeof(Fr)));
         CHK(s.eval_result.alloc(EVAL_MAX * sizeof(Fr)));
-        for (uint32_t k = 0; k < nb_commit_; k++) { CHK(s.pi2_lag[k].alloc(fn)); CHK(s.pi2_can[k].alloc(fn)); CHK(s.epi2[k].alloc(f4)); }
+        for (uint32_t k = 0; k < nb_commit_; k++) { CHK(s.pi2_can[k].alloc(fn)); CHK(s.epi2[k].alloc(f4)); }
         CHK(s.scratch_in.alloc(f4));
         CHK(s.tail_flag.alloc(16));
         HIPCHK(hipMemset(s.tail_flag.p, 0, 16));
@@ -979,6 +1058,61 @@ class CurveBackend : public Backend {
         HIPCHK(hipMemset(s.done_count.p, 0, (MSM_MAX_BATCH + 1) * sizeof(uint32_t)));
         return APK_OK;
     }
+
+    // ---- host-input staging sets (see InputSet) ---------------------------------------------------------------------------------
+    int ensure_input_sets() {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (!in_sets_.empty()) return APK_OK;
+        // as many sets again as proving slots (callers waiting for a slot have their upload in flight), at most 32
+        static const int sets_env = env_int("APK_INPUT_SETS", 0, 0, 64);
+        size_t count = sets_env ? (size_t)sets_env : 2 * slots_.size();
+        if (count > 32 && !sets_env) count = 32;
+        if (count < 1) count = 1;
+        if (!copy_stream_) HIPCHK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+        std::vector<InputSet*> made;
+        int rc = APK_OK;
+        for (size_t i = 0; i < count && rc == APK_OK; i++) {
+            InputSet* is = new InputSet();
+            is->index = i;
+            made.push_back(is);
+            rc = alloc_input_set(*is);
+        }
+        if (rc != APK_OK && made.size() > 1) {       // out of memory half way: keep the sets that were completed
+            InputSet* last = made.back();
+            made.pop_back();
+            if (last->ready) (void)hipEventDestroy(last->ready);
+            delete last;
+            (void)hipGetLastError();
+            rc = APK_OK;
+        }
+        if (rc != APK_OK) { for (InputSet* is : made) delete is; return rc; }
+        in_sets_ = made;
+        in_gate_.resize(in_sets_.size());
+        return APK_OK;
+    }
+    int alloc_input_set(InputSet& is) {
+        const size_t fn3 = (size_t)(n_ + 4) * sizeof(Fr);
+        for (int j = 0; j < 3; j++) CHK(is.w[j].alloc(fn3));
+        for (uint32_t k = 0; k < nb_commit_; k++) CHK(is.pi2[k].alloc(fn3));
+        is.copy = copy_stream_;
+        HIPCHK(hipEventCreateWithFlags(&is.ready, hipEventDisableTiming));
+        return APK_OK;
+    }
+    struct InputGuard {
+        CurveBackend* b; InputSet* set = nullptr; bool ok = false;
+        explicit InputGuard(CurveBackend* b_) : b(b_) {}
+        int take() {
+            CHK(b->ensure_input_sets());
+            set = b->in_sets_[b->in_gate_.acquire()];
+            return APK_OK;
+        }
+        ~InputGuard() {
+            if (!set) return;
+            // an error return may leave copies or kernels in flight that still read the caller's buffers / this set
+            if (!ok) (void)hipDeviceSynchronize();
+            b->in_gate_.release(set->index);
+        }
+    };
 
     Slot* acquire() { return slots_[gate_.acquire()]; }
     void release(Slot* s) {
@@ -1232,23 +1366,22 @@ class CurveBackend : public Backend {
         HIPCHK(hipMemcpy(srs.p, d->srs_g1, (size_t)(n_ + 3) * sizeof(Aff), hipMemcpyHostToDevice));
         CHK(build_tables(st, ptr<Aff>(srs), n_ + 3, tab_can_));
         wires_lag_mode_ = env_int("APK_WIRES_LAGRANGE", -1, -1, 1);
-        if (d->srs_g1_lagrange || wires_lag_mode_ != 0) {
-            // the extended Lagrange table: the caller's Lagrange SRS (gnark's ProvingKey.KzgLagrange), or - not given - derived
-            // here from the canonical one (kzg.ToLagrangeG1 as an inverse FFT in the exponent, kernels_setup.h), then D_0..D_2
-            DevBuf lag;
-            CHK(lag.alloc((size_t)(n_ + 3) * sizeof(Aff)));
-            if (d->srs_g1_lagrange) HIPCHK(hipMemcpy(lag.p, d->srs_g1_lagrange, (size_t)n_ * sizeof(Aff), hipMemcpyHostToDevice));
-            else CHK((g1_to_lagrange_dev<FRP, FPP>(ptr<Aff>(srs), n_, ptr<Aff>(lag))));
+        {
             const Aff* g = reinterpret_cast<const Aff*>(d->srs_g1);
-            Aff dk[3];
             for (int k = 0; k < 3; k++) {
                 Pt p = Pt::from_affine(g[n_ + k]);
                 p.madd(g[k], /*negate=*/true);
-                dk[k] = p.to_affine();
+                lag_dk_[k] = p.to_affine();
             }
-            HIPCHK(hipMemcpy(ptr<Aff>(lag) + n_, dk, sizeof dk, hipMemcpyHostToDevice));
-            CHK(build_tables(st, ptr<Aff>(lag), n_ + 3, tab_lag_, /*plain=*/true));
-            HIPCHK(hipDeviceSynchronize());
+        }
+        if (d->srs_g1_lagrange || wires_lag_mode_ == 1) {
+            // the extended Lagrange table NOW: the caller's Lagrange SRS (gnark's ProvingKey.KzgLagrange; BSB22 needs it) or a forced
+            // Lagrange route - derived from the canonical SRS when not given (kzg.ToLagrangeG1 as an inverse FFT in the exponent)
+            CHK(build_lagrange_table(st, ptr<Aff>(srs), d->srs_g1_lagrange));
+        } else if (wires_lag_mode_ != 0) {
+            // automatic route, nothing given: derived on first use (ensure_lagrange_table), from the SRS kept here
+            CHK(srs_keep_.alloc((size_t)(n_ + 3) * sizeof(Aff)));
+            HIPCHK(hipMemcpyAsync(srs_keep_.p, srs.p, (size_t)(n_ + 3) * sizeof(Aff), hipMemcpyDeviceToDevice, st));
         }
         HIPCHK(hipDeviceSynchronize());
         srs.release();
@@ -1295,11 +1428,12 @@ class CurveBackend : public Backend {
     // ---------------------------------------------------------------------------------------------- primitives
     int msm(int basis, const void* scalars, uint64_t len, bool on_device, void* out) override {
         HIPCHK(hipSetDevice(device_));
-        MsmTables& T = basis ? tab_lag_ : tab_can_;
-        if (!T.built) { set_error("context has no %s SRS", basis ? "Lagrange" : "canonical"); return APK_ERR_STATE; }
-        if (len > T.n_bases) { set_error("msm length %llu exceeds SRS size %u", (unsigned long long)len, T.n_bases); return APK_ERR_ARG; }
         SlotGuard g(this);
         Slot& s = *g.s;
+        if (basis) (void)ensure_lagrange_table(s.stream);      // the automatic mode derives the table on first use
+        MsmTables& T = basis ? tab_lag_ : tab_can_;
+        if (basis ? !lagrange_ready() : !T.built) { set_error("context has no %s SRS", basis ? "Lagrange" : "canonical"); return APK_ERR_STATE; }
+        if (len > T.n_bases) { set_error("msm length %llu exceeds SRS size %u", (unsigned long long)len, T.n_bases); return APK_ERR_ARG; }
         const void* dsc = scalars;
         if (!on_device) {
             HIPCHK(hipMemcpyAsync(s.scratch_in.p, scalars, len * sizeof(Fr), hipMemcpyHostToDevice, s.stream));
@@ -1316,8 +1450,6 @@ class CurveBackend : public Backend {
     // `count` partial MSMs in one batch: sum over scalars[b][0 .. len) * SRS[offset + i]; scalars in device memory
     int msm_batch(int basis, uint32_t count, const void* const* d_scalars, const uint64_t* offsets, const uint64_t* lens, void* out) override {
         HIPCHK(hipSetDevice(device_));
-        MsmTables& T = basis ? tab_lag_ : tab_can_;
-        if (!T.built) { set_error("context has no %s SRS", basis ? "Lagrange" : "canonical"); return APK_ERR_STATE; }
         if (count == 0 || count > MSM_MAX_BATCH) { set_error("msm batch of %u (1..%d)", count, MSM_MAX_BATCH); return APK_ERR_ARG; }
         Slot* own = hook_slot();                       // called from inside this thread's commit hook: use the prover's slot
         bool mine = false;
@@ -1326,6 +1458,9 @@ class CurveBackend : public Backend {
         struct MaybeGuard { CurveBackend* b; Slot* s; bool owned; ~MaybeGuard() { if (owned) b->release(s); } };
         MaybeGuard g{this, own ? own : acquire(), own == nullptr};
         Slot& s = *g.s;
+        if (basis) (void)ensure_lagrange_table(s.stream);
+        MsmTables& T = basis ? tab_lag_ : tab_can_;
+        if (basis ? !lagrange_ready() : !T.built) { set_error("context has no %s SRS", basis ? "Lagrange" : "canonical"); return APK_ERR_STATE; }
         MsmBatchArgs a{};
         a.batch = count;
         a.plain = T.plain ? 1u : 0u;
@@ -1639,12 +1774,23 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     HIPCHK(hipSetDevice(device_));
     auto t_start = std::chrono::steady_clock::now();
     if (!L || !R || !O || !blinding || !out || (nb_public_ && !pub) || (nb_commit_ && !pi2)) { set_error("null argument to apk_prove"); return APK_ERR_ARG; }
+    const size_t fn = (size_t)n_ * sizeof(Fr);
+    // host inputs: on their way to the device on a copy stream BEFORE this caller queues for a proving slot (InputSet)
+    InputGuard in(this);
+    if (!on_device) {
+        CHK(in.take());
+        const void* src[3] = {L, R, O};
+        for (int j = 0; j < 3; j++) HIPCHK(hipMemcpyAsync(in.set->w[j].p, src[j], fn, hipMemcpyHostToDevice, in.set->copy));
+        for (uint32_t k = 0; k < nb_commit_; k++) {
+            if (!pi2[k]) { set_error("null BSB22 column"); return APK_ERR_ARG; }
+            HIPCHK(hipMemcpyAsync(in.set->pi2[k].p, pi2[k], fn, hipMemcpyHostToDevice, in.set->copy));
+        }
+        HIPCHK(hipEventRecord(in.set->ready, in.set->copy));
+    }
     SlotGuard guard(this);
     Slot& s = *guard.s;
     hipStream_t st = s.stream;
-    const size_t fn = (size_t)n_ * sizeof(Fr);
     const uint32_t n = n_;
-    const hipMemcpyKind kin = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     const Fr* bl = reinterpret_cast<const Fr*>(blinding);
     const Fr* pubv = reinterpret_cast<const Fr*>(pub);
     Aff* hp = reinterpret_cast<Aff*>(s.h_pinned);
@@ -1658,19 +1804,21 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     const Fr* dR = reinterpret_cast<const Fr*>(R);
     const Fr* dO = reinterpret_cast<const Fr*>(O);
     if (!on_device) {
-        HIPCHK(hipMemcpyAsync(s.wl.p, L, fn, kin, st)); HIPCHK(hipMemcpyAsync(s.wr.p, R, fn, kin, st)); HIPCHK(hipMemcpyAsync(s.wo.p, O, fn, kin, st));
-        dL = ptr<Fr>(s.wl); dR = ptr<Fr>(s.wr); dO = ptr<Fr>(s.wo);
+        HIPCHK(hipStreamWaitEvent(st, in.set->ready, 0));
+        dL = ptr<Fr>(in.set->w[0]); dR = ptr<Fr>(in.set->w[1]); dO = ptr<Fr>(in.set->w[2]);
+        path(P_HOST_INPUTS);
     }
     Aff bsb[APK_MAX_COMMITMENTS];
     Fr cval[APK_MAX_COMMITMENTS];
     uint8_t bsb_bytes[APK_MAX_COMMITMENTS][2 * FPB];
     for (uint32_t k = 0; k < nb_commit_; k++) {
         // kzg.Commit(pi2, Lagrange SRS) then hash_to_field (templateLogicSigBN254.go:386-397)
-        HIPCHK(hipMemcpyAsync(s.pi2_lag[k].p, pi2[k], fn, kin, st));
+        // (the committed column is only read: the caller's device buffer, or the input set's copy of the caller's host buffer)
+        const Fr* col = on_device ? reinterpret_cast<const Fr*>(pi2[k]) : ptr<Fr>(in.set->pi2[k]);
         MsmBatchArgs a{};
-        a.batch = 1; a.scalars[0] = s.pi2_lag[k].p; a.len[0] = n; a.offset[0] = 0; a.plain = tab_lag_.plain ? 1u : 0u;
+        a.batch = 1; a.scalars[0] = col; a.len[0] = n; a.offset[0] = 0;
         CHK(commit(s, tab_lag_, 1, a, hp));
-        CHK(inv_ntt_n(st, ptr<Fr>(s.pi2_lag[k]), ptr<Fr>(s.pi2_can[k])));
+        CHK(inv_ntt_n(st, col, ptr<Fr>(s.pi2_can[k])));
         {
             const Fr* cin = ptr<Fr>(s.pi2_can[k]); Fr* eout = ptr<Fr>(s.epi2[k]);
             CHK(coset_eval(st, 1, &cin, &n, &eout));
@@ -1692,7 +1840,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     constexpr uint32_t DENSITY_UNKNOWN = 0xffffffffu;
     volatile uint32_t* h_density = reinterpret_cast<volatile uint32_t*>(reinterpret_cast<uint8_t*>(s.h_pinned) + 3200);
     bool use_lag = false, measuring = false;
-    if (tab_lag_.built && tab_lag_.plain && !hook_ && wires_lag_mode_ != 0) {
+    if (lagrange_possible() && !hook_ && wires_lag_mode_ != 0) {
         const uint32_t seq = proof_seq_.fetch_add(1, std::memory_order_relaxed);
         uint32_t pm = wire_density_pm_.load(std::memory_order_relaxed);
         if (wires_lag_mode_ == 1) use_lag = true;
@@ -1716,9 +1864,11 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
             }
             use_lag = pm < 900u;
         }
+        // (automatic mode without a caller's Lagrange SRS: the table is derived now, once, on this proof's stream - or not at all)
+        if (use_lag && !lagrange_ready()) use_lag = ensure_lagrange_table(st);
     }
     Fr* lagv[3] = {ptr<Fr>(s.wl), ptr<Fr>(s.wr), ptr<Fr>(s.wo)};
-    if (use_lag && on_device)
+    if (use_lag)
         for (int j = 0; j < 3; j++) HIPCHK(hipMemcpyAsync(lagv[j], wires[j], fn, hipMemcpyDeviceToDevice, st));
     // (no zero-fill of the tails: blind_kernel assigns the coefficients n .. n+d-1 and nothing reads beyond them)
     {
@@ -1933,6 +2083,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     CHK(sync_results(s));
     if (*reinterpret_cast<const volatile uint32_t*>(reinterpret_cast<const uint8_t*>(s.h_pinned) + 3072) == s.epoch) {
         set_error("quotient is not a polynomial: the witness does not satisfy the circuit");
+        in.ok = true;      // (the stream was just drained: nothing of this proof is still reading its inputs)
         return APK_ERR_WITNESS;
     }
     Aff hcom[3] = {hp[0], hp[1], hp[2]};
@@ -2140,6 +2291,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     memcpy(out->gamma, &gamma, sizeof(Fr)); memcpy(out->beta, &beta, sizeof(Fr)); memcpy(out->alpha, &alpha, sizeof(Fr));
     memcpy(out->zeta, &zeta, sizeof(Fr)); memcpy(out->gamma_kzg, &gk, sizeof(Fr));
     mark(3);
+    in.ok = true;
     path(P_PROOFS);
     if (stats_on_) {
         double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
@@ -2206,7 +2358,7 @@ int g1_decompress_impl(int device, const uint8_t* in, uint64_t count, void* out)
 
 // kzg.ToLagrangeG1 on device buffers: an inverse FFT in the exponent (kernels_setup.h); complete when it returns
 template <class FRP, class FPP>
-int g1_to_lagrange_dev(const Affine<FPP>* d_in, uint64_t n, Affine<FPP>* d_out) {
+int g1_to_lagrange_dev(const Affine<FPP>* d_in, uint64_t n, Affine<FPP>* d_out, hipStream_t st) {
     using Fr = Fe<FRP>;
     using Aff = Affine<FPP>;
     using Pt = XYZZ<FPP>;
@@ -2227,17 +2379,17 @@ int g1_to_lagrange_dev(const Affine<FPP>* d_in, uint64_t n, Affine<FPP>* d_out) 
     CHK(twi.alloc((n / 2 + 1) * sizeof(Fr)));
     PowersBatch<FRP> pb{};
     pb.out[0] = ptr<Fr>(twi); pb.w[0] = winv; pb.scale[0] = Fr::one();
-    powers_kernel<FRP><<<dim3(cdiv(cdiv(n / 2, 8), 256), 1), 256>>>(pb, (uint32_t)(n / 2));
+    powers_kernel<FRP><<<dim3(cdiv(cdiv(n / 2, 8), 256), 1), 256, 0, st>>>(pb, (uint32_t)(n / 2));
     KCHK();
-    lagrange_load_kernel<FPP><<<cdiv(n, 256), 256>>>(d_in, (uint32_t)n, log_n, ptr<Pt>(work));
+    lagrange_load_kernel<FPP><<<cdiv(n, 256), 256, 0, st>>>(d_in, (uint32_t)n, log_n, ptr<Pt>(work));
     KCHK();
     for (int t = 0; t < log_n; t++) {
-        lagrange_stage_kernel<FRP, FPP><<<cdiv(n / 2, 128), 128>>>(ptr<Pt>(work), ptr<Fr>(twi), (uint32_t)n, log_n, t);
+        lagrange_stage_kernel<FRP, FPP><<<cdiv(n / 2, 128), 128, 0, st>>>(ptr<Pt>(work), ptr<Fr>(twi), (uint32_t)n, log_n, t);
         KCHK();
     }
-    lagrange_finish_kernel<FRP, FPP><<<cdiv(n, 128), 128>>>(ptr<Pt>(work), (uint32_t)n, ninv, d_out);
+    lagrange_finish_kernel<FRP, FPP><<<cdiv(n, 128), 128, 0, st>>>(ptr<Pt>(work), (uint32_t)n, ninv, d_out);
     KCHK();
-    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipStreamSynchronize(st));     // the work buffers are released on return
     return APK_OK;
 }
 

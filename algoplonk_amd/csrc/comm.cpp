@@ -119,6 +119,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;      // optional: used when a collective timed out
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -137,6 +138,7 @@ struct Rccl {
         SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(AllGather, "ncclAllGather") SYM(GroupStart, "ncclGroupStart")
         SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+        CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(h, "ncclCommAbort"));
         return true;
     }
 };
@@ -181,6 +183,8 @@ struct apk_comm {
     void* d_wire_out = nullptr; size_t wire_out_cap = 0; // workers: its 4n evaluations
     std::vector<uint8_t> h_stage;
     void* d_ag = nullptr; size_t ag_cap = 0;             // RCCL: device staging of the partial-sum all-gather (hipMalloc on `device`)
+    void* h_ag = nullptr;                                // ... and its page-locked host mirror (same capacity): no copy of the
+                                                         // communicator's stream ever targets caller-owned memory
     bool step_synced = false;       // the current step's status reached every rank of it (serve() keeps serving) - or the transport
                                     // broke mid-step and the stream to the leader is no longer aligned (serve() leaves)
     bool split_on = false;
@@ -204,7 +208,14 @@ static int bi_msm(void* u, int basis, uint32_t count, const void* const* sc, con
 }
 static int bi_coset(void* u, const void* in, uint64_t len, void* out) { return apk_coset_ntt_device(((apk_comm*)u)->ctx, in, len, out); }
 static int bi_alloc(void* u, size_t b, void** p) { return apk_device_alloc(((apk_comm*)u)->ctx, b, p); }
-static int bi_release(void* u, void* p) { return apk_device_free(((apk_comm*)u)->ctx, p); }
+static int bi_release(void* u, void* p) {
+    apk_comm* c = (apk_comm*)u;
+    if (c->ctx && !ctx_alive(c->ctx)) c->ctx = nullptr;
+    // (the context these buffers came through is gone - destroyed before its communicator: the allocation itself is plain device
+    // memory and is returned to the runtime directly)
+    if (!c->ctx) { const hipError_t e = hipFree(p); if (e != hipSuccess) (void)hipGetLastError(); return APK_OK; }
+    return apk_device_free(c->ctx, p);
+}
 static int bi_copy(void* u, void* d, const void* s, size_t b, int kind) {
     apk_ctx* c = ((apk_comm*)u)->ctx;
     return kind == 0 ? apk_device_copy(c, d, s, b) : kind == 1 ? apk_device_upload(c, d, s, b) : apk_device_download(c, d, s, b);
@@ -328,6 +339,8 @@ struct WallMs {
 // binding changes or the communicator dies: a hook left behind points at freed memory and the next apk_prove on that context
 // would call it (an exception between spmd_begin and spmd_end is enough to get there).
 static void clear_ctx_hooks(apk_comm* c) {
+    // (a host whose finalizers destroyed the context before the communicator: nothing left to take the hooks off)
+    if (c->ctx && !ctx_alive(c->ctx)) c->ctx = nullptr;
     if (c->ctx && (c->split_on || c->spmd_on)) {
         (void)apk_ctx_set_commit_hook(c->ctx, nullptr, nullptr);
         (void)apk_ctx_set_wire_hook(c->ctx, nullptr, nullptr);
@@ -349,7 +362,15 @@ static int stream_wait(apk_comm* c, const char* what) {
         if (e != hipErrorNotReady) { (void)hipGetLastError(); set_error("comm: %s: %s", what, hipGetErrorString(e)); return APK_ERR_HIP; }
         if (spins < 2000) continue;                      // the exchanges this guards take tens of microseconds
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > (double)c->timeout_s) {
+            // The stream still holds the unfinished collective and whatever was queued behind it.  The collective is aborted; the
+            // stream and the staging buffers it may still write to are ABANDONED (deliberately leaked, never reused or freed) and a
+            // fresh stream takes over, so a peer that joins late cannot make anything write into memory with a new owner.
             c->rccl = false;
+            if (c->nccl && g_rccl.CommAbort) (void)g_rccl.CommAbort(c->nccl);
+            c->nccl = nullptr;
+            c->d_ag = nullptr; c->h_ag = nullptr; c->ag_cap = 0;
+            c->stream = nullptr;
+            if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->stream = nullptr; }
             set_error("comm: %s did not complete within %d s (a peer never joined the collective); RCCL plane abandoned", what, c->timeout_s);
             return APK_ERR_STATE;
         }
@@ -370,14 +391,16 @@ static int sums_allgather(apk_comm* c, const void* mine, void* all, size_t n) {
         // can fail before the collective, so the ranks agree on it over the control plane first - nobody enters an all-gather
         // that a peer cannot join
         if (c->d_ag) (void)hipFree(c->d_ag);
-        c->d_ag = nullptr; c->ag_cap = 0;
-        int32_t ok = hipMalloc(&c->d_ag, need * 2 + 4096) == hipSuccess ? 1 : 0;
-        if (!ok) { (void)hipGetLastError(); c->d_ag = nullptr; }
+        if (c->h_ag) (void)hipHostFree(c->h_ag);
+        c->d_ag = nullptr; c->h_ag = nullptr; c->ag_cap = 0;
+        int32_t ok = hipMalloc(&c->d_ag, need * 2 + 4096) == hipSuccess && hipHostMalloc(&c->h_ag, need * 2 + 4096, hipHostMallocDefault) == hipSuccess ? 1 : 0;
+        if (!ok) { (void)hipGetLastError(); if (c->d_ag) (void)hipFree(c->d_ag); if (c->h_ag) (void)hipHostFree(c->h_ag); c->d_ag = nullptr; c->h_ag = nullptr; }
         std::vector<int32_t> oks(c->world);
         CHK(ctl_allgather(c, &ok, oks.data(), 4));
         for (int r = 0; r < c->world; r++)
             if (!oks[r]) {
                 if (c->d_ag) { (void)hipFree(c->d_ag); c->d_ag = nullptr; }
+                if (c->h_ag) { (void)hipHostFree(c->h_ag); c->h_ag = nullptr; }
                 set_error("comm: rank %d could not allocate the all-gather staging buffer (%zu bytes)", r, need * 2 + 4096);
                 return APK_ERR_HIP;
             }
@@ -385,10 +408,17 @@ static int sums_allgather(apk_comm* c, const void* mine, void* all, size_t n) {
     }
     uint8_t* d_all = (uint8_t*)c->d_ag;
     uint8_t* d_mine = d_all + n * (size_t)c->world;
-    HCHK(hipMemcpyAsync(d_mine, mine, n, hipMemcpyHostToDevice, c->stream));
+    // through the communicator's own page-locked mirror: should the wait below time out, the copy still queued on the (then
+    // abandoned) stream targets memory nobody else will own, not the caller's vector
+    uint8_t* h_all = (uint8_t*)c->h_ag;
+    uint8_t* h_mine = h_all + n * (size_t)c->world;
+    memcpy(h_mine, mine, n);
+    HCHK(hipMemcpyAsync(d_mine, h_mine, n, hipMemcpyHostToDevice, c->stream));
     NCHK(g_rccl.AllGather(d_mine, d_all, n, ncclUint8, c->nccl, c->stream));
-    HCHK(hipMemcpyAsync(all, d_all, n * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
-    return stream_wait(c, "the partial sums' ncclAllGather");
+    HCHK(hipMemcpyAsync(h_all, d_all, n * (size_t)c->world, hipMemcpyDeviceToHost, c->stream));
+    CHK(stream_wait(c, "the partial sums' ncclAllGather"));
+    memcpy(all, h_all, n * (size_t)c->world);
+    return APK_OK;
 }
 
 // ---- data-plane: scatter of per-rank chunks held by rank 0; peer copies between rank 0 and one worker -------------------------
@@ -651,6 +681,7 @@ void apk_comm_destroy(apk_comm* c) {
     clear_ctx_hooks(c);
     release_buffers(c);
     if (c->d_ag) { (void)hipSetDevice(c->device); (void)hipFree(c->d_ag); }
+    if (c->h_ag) (void)hipHostFree(c->h_ag);
     if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (int fd : c->peer) if (fd >= 0) close(fd);

@@ -59,6 +59,43 @@ class Workload:
     tau: int
 
 
+@dataclass
+class Variant:
+    """One assignment of a circuit: the inputs, the solved variables, the 9 blinding scalars (and BSB22 hiding pairs)."""
+    witness: frontend.Witness
+    blinding: List[int]
+    solution: List[int] = None
+    hiding: List[Tuple[int, int]] = None
+
+
+def variant_inputs(ccs: frontend.ConstraintSystem, count: int, seed: int) -> List[Variant]:
+    """`count` assignments of ONE circuit (same selectors, same permutation - one proving context), every one with its own
+    input vector, its own blinding and its own BSB22 hiding pairs, all from SplitMix64(seed + i): what concurrent callers of
+    (*CompiledCircuit).Verify hand the prover (/root/reference/algoplonk.go:79-98 - each call has its own assignment).  The
+    synthetic circuits take ANY inputs (every gate defines its output wire), so each variant is a satisfying witness; unsolved
+    here (BSB22 circuits need the context's commitment hint: plonk.solve_with_commitments)."""
+    r = ccs.field
+    nbp, nbs = ccs.GetNbPublicVariables(), len(ccs.secret_names)
+    out = []
+    for i in range(count):
+        g = SplitMix64((seed + 0x9E37 * (i + 1)) & MASK64)
+        vals = [g.fr(r) for _ in range(nbp + nbs)]
+        gb = SplitMix64(((seed + 0x9E37 * (i + 1)) ^ 0xB11D) & MASK64)
+        blinding = [gb.fr(r) for _ in range(9)]
+        hiding = [(gb.fr(r), gb.fr(r)) for _ in range(len(ccs.commitments))]
+        out.append(Variant(frontend.Witness(r, vals[:nbp], vals[nbp:]), blinding, None, hiding))
+    return out
+
+
+def variants(wl: "Workload", count: int, seed: int) -> List[Variant]:
+    """The workload's own assignment followed by count - 1 others of the same circuit (variant_inputs), solved."""
+    out = [Variant(wl.witness, wl.blinding, wl.solution, [])]
+    for v in variant_inputs(wl.ccs, count - 1, seed):
+        v.solution = frontend.solve(wl.ccs, v.witness)
+        out.append(v)
+    return out
+
+
 def random_circuit_bsb22(curve: ecc.ID, log_n: int, seed: int, nb_commitments: int = 1, committed: int = 16,
                          nb_public: int = 2):
     """BASELINE.json configs[4] shape: the random-gate circuit with `nb_commitments` BSB22 commitments, each over

@@ -72,6 +72,12 @@ def parse_args(argv=None):
     ap.add_argument("--witness", default="uniform", choices=["uniform", "bits"],
                     help="wire values of the synthetic circuit: uniform Fr (BASELINE.md section 2) or the bit-heavy circuit of "
                          "workloads.skewed_circuit; the default run reports the bit-heavy rate beside the headline (`witness_bits`)")
+    ap.add_argument("--witnesses", type=int, default=0,
+                    help="distinct assignments of the circuit the concurrent callers prove (every caller walks through all of them; "
+                         "default 16 up to 2^18, 8 at 2^19, 4 from 2^20; never more than --inflight)")
+    ap.add_argument("--no-oracle-check", action="store_true",
+                    help="skip the per-witness comparison of the timed region's proofs with the C oracle's (bench_cpu.oracle_blobs)")
+    ap.add_argument("--no-host-inputs", action="store_true", help="skip the apk_prove (host pointers) legs")
     ap.add_argument("--step-barrier", action="store_true",
                     help="join all callers after every step (rounds 1-2); default: persistent callers, barriers only around the K steps")
     ap.add_argument("--mode", default="prove", choices=["prove", "msm-sharded", "prove-split", "prove-spmd", "launcher-selftest"])
@@ -575,8 +581,53 @@ def roofline_from_stats(args, cv, st, pmc, issue=None):
     return roofline
 
 
+def proof_algorithmic_bytes(cv, log_n: int, nb_commit: int) -> dict:
+    """SURVEY.md section 8d's per-proof algorithmic bytes (the contract's HBM yardstick), per curve and size: 10 KZG commitments of n
+    (scalar, point) pairs; the GPU-natural transform schedule 12 iNTT_n + 12 coset-NTT_4n + 1 iNTT_4n at 64 B per element; one
+    quotient pass over 14 vectors of 4n elements; ~50 MB of other pointwise passes at 2^17, taken proportional to n.  Each BSB22
+    commitment adds one MSM, one iNTT_n + one coset-NTT_4n and two 4n vectors in the quotient pass."""
+    n = 1 << log_n
+    pair = 32 + 2 * cv.fp_bytes
+    msm = (10 + nb_commit) * n * pair
+    ntt = ((12 + nb_commit) * n + (13 + nb_commit) * 4 * n) * 64
+    quotient = (14 + 2 * nb_commit) * 4 * n * 32
+    misc = int(50e6 * n / (1 << 17))
+    return {"msm": msm, "ntt": ntt, "quotient": quotient, "misc": misc, "total": msm + ntt + quotient + misc}
+
+
+def extra_rooflines(args, cv, st, value_per_rank: float, lat_stats_ms: float) -> dict:
+    """The whole proof and the transforms on the contract's HBM yardstick, and where a lone instrumented proof's time goes - every
+    input measured by this run (apk_stats: HIP events on the kernels' own stream)."""
+    alg = proof_algorithmic_bytes(cv, args.log_n, args.bsb22)
+    proofs = max(st.proofs, 1)
+    out = {"proof": {"bound": "hbm", "algorithmic_bytes": alg["total"], "algorithmic_bytes_by_part": alg,
+                     "achieved": round(alg["total"] * value_per_rank / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(alg["total"] * value_per_rank / 1e9 / HBM_PEAK_GBS, 6),
+                     "basis": "SURVEY.md section 8d bytes per proof x proofs/s of one GPU under load"}}
+    if st.ntt_ms > 0:
+        gbs = st.ntt_elements * 64.0 / (st.ntt_ms * 1e-3) / 1e9
+        out["ntt"] = {"bound": "hbm", "kernel": "ntt_pass_kernel", "algorithmic_bytes_per_element": 64,
+                      "elements_per_proof": int(st.ntt_elements / proofs), "ms_per_proof": round(st.ntt_ms / proofs, 4),
+                      "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 6),
+                      "basis": "lone instrumented proofs: elements transformed x 64 B (one read + one write per transform) / HIP-event time of the passes"}
+    per = lambda ms: round(ms / proofs, 4)
+    total = st.prove_ms / proofs if st.prove_ms > 0 else lat_stats_ms
+    parts = {"msm_accumulate": per(st.msm_accumulate_ms), "msm_sort_and_scans": per(st.msm_sort_ms), "msm_tails": per(st.msm_tail_ms),
+             "ntt": per(st.ntt_ms), "host_lincomb": per(st.host_lincomb_ms)}
+    parts["rounds_2_to_4_pointwise_and_host"] = round(max(total - sum(parts.values()), 0.0), 4)
+    out["lone_proof_ms_by_part"] = {"total": round(total, 4), **parts,
+                                    "share": {k: round(v / total, 4) for k, v in parts.items()} if total > 0 else None,
+                                    "basis": "apk_stats over the instrumented lone proofs (the statistics synchronise the host with every batch, so the total is above proof_latency_ms)"}
+    return out
+
+
+def default_witnesses(args) -> int:
+    k = args.witnesses or (16 if args.log_n <= 18 else 8 if args.log_n == 19 else 4)
+    return max(1, min(k, args.inflight))
+
+
 def bench_prove(args, cv, rk) -> None:
-    from algoplonk_amd import _lib, frontend, plonk, setup, workloads
+    from algoplonk_amd import _lib, batch, frontend, plonk, setup, workloads
     from algoplonk_amd._lib import lib, check
 
     seed = {("bn254", 0): 0xA190, ("bls12_381", 0): 0xA191}.get((args.curve, args.bsb22), 0xA193)
@@ -597,35 +648,36 @@ def bench_prove(args, cv, rk) -> None:
     srs = setup.unsafe_srs(cv, n, tau, device=rk.local_rank, lagrange=bool(args.bsb22))
     pk, vk = plonk.Setup(ccs, srs, device=rk.local_rank, msm_window=args.msm_window, slots=args.inflight)
     args.window_used = pk.msm_window
-    if args.bsb22:
-        solution, pi2_host = plonk.solve_with_commitments(ccs, pk, witness, hiding=[(0xA193 + k, 0x3910A + k) for k in range(args.bsb22)])
-    else:
-        solution = wl.solution
-    L, R, O = frontend.wire_columns(ccs, solution)
-
-    def resident(vec):
-        b = cv.fr_vector(vec)
-        p = C.c_void_p()
-        check(lib.apk_device_alloc(pk.ctx, len(b), C.byref(p)))
-        check(lib.apk_device_upload(pk.ctx, p, b, len(b)))
-        return p
-
-    dptr = [resident(v) for v in (L, R, O)]
-    d_pi2 = None
-    if pi2_host:
-        ptrs = [resident(col) for col in pi2_host]
-        d_pi2 = (C.c_void_p * len(ptrs))(*ptrs)
-    pub = cv.fr_vector(witness.public)
-    bl = cv.fr_vector(blinding)
+    # ---- K distinct assignments of the circuit: the callers of the timed region walk through them, so that at
+    # any moment the proofs in flight have different wires, public inputs, blinding scalars (and BSB22 columns / hiding pairs) - as
+    # concurrent (*CompiledCircuit).Verify calls do (algoplonk.go:79-98).  Assignment 0 is the workload's own.
+    K = default_witnesses(args)
+    first = workloads.Variant(witness, blinding, None if args.bsb22 else wl.solution, [(0xA193 + k, 0x3910A + k) for k in range(args.bsb22)])
+    vs = [first] + workloads.variant_inputs(ccs, K - 1, seed)
+    ws = batch.WitnessSet(pk, ccs, vs).to_device()
+    if not args.no_host_inputs:
+        ws.to_pinned(rk.local_rank)
     setup_s = time.time() - t0
 
     proofs = [_lib.Proof() for _ in range(args.inflight)]
+    last_pick = [0] * args.inflight
+    counters = [0] * args.inflight
     errors = []
+    mode = {"where": "device"}
+    import math
+    stride = next((c for c in (3, 5, 7, 11, 13) if math.gcd(c, K) == 1), 1)
 
     def one(i):
-        rc = lib.apk_prove_device(pk.ctx, dptr[0], dptr[1], dptr[2], pub, bl, d_pi2, C.byref(proofs[i]))
+        a = (i + stride * counters[i]) % K    # caller i walks the set; its neighbours hold other assignments at any moment
+        counters[i] += 1
+        last_pick[i] = a
+        rc = ws.prove(a, proofs[i], mode["where"])
         if rc != 0:
             errors.append((rc, lib.apk_last_error()))
+
+    import hashlib
+    from algoplonk_amd import MarshalProof
+    sha = lambda p: hashlib.sha256(MarshalProof(plonk.Proof(cv, p))).hexdigest()[:16]
 
     pk.paths(reset=True)
     elapsed = rk.timed_callers(one, args.inflight, args.steps, args.warmup, args.step_barrier)
@@ -634,34 +686,57 @@ def bench_prove(args, cv, rk) -> None:
     total_proofs = args.steps * args.inflight * rk.world
     value = total_proofs / elapsed
     # ---- what the timed region PRODUCED: every caller's last proof (made with the other callers in flight, i.e. by the loaded
-    # forms of the kernels - `paths` says which ran) is marshalled and hashed before anything else touches the buffers; all of them
-    # must be the same bytes (same inputs, same blinding) and, below, the same bytes as the lone proof and as the CPU oracle's
-    import hashlib
-    from algoplonk_amd import MarshalProof
+    # forms of the kernels - `paths` says which ran) is marshalled and hashed before anything else touches the buffers; each is
+    # held to the lone proof and to the C oracle's proof of ITS OWN assignment below
     paths_loaded = pk.paths(reset=True)
-    load_hashes = [hashlib.sha256(MarshalProof(plonk.Proof(cv, p))).hexdigest()[:16] for p in proofs]
-    under_load_identical = len(set(load_hashes)) == 1
+    load_hashes = [(last_pick[i], sha(proofs[i])) for i in range(args.inflight)]
+
+    # ---- the call the cgo shim makes: apk_prove with HOST pointers, same callers, same walk through the
+    # assignments - from page-locked buffers (apk_host_alloc: the shim's witness pool) and from ordinary pageable memory
+    host_legs = {}
+    if not args.no_host_inputs:
+        for where in ("pinned", "pageable"):
+            mode["where"] = where
+            # (the same number of steps as the headline for the page-locked leg: with persistent callers the ramp-down of the last
+            # proofs is a fixed cost, and a shorter leg would read low for that reason alone)
+            steps_h = args.steps if where == "pinned" else max(6, args.steps // 2)
+            el = rk.timed_callers(one, args.inflight, steps_h, 2, args.step_barrier)
+            if errors:
+                raise SystemExit("apk_prove (%s host inputs) failed: %r" % (where, errors[0]))
+            host_legs[where] = {"value": steps_h * args.inflight * rk.world / el, "steps": steps_h,
+                                "hashes": [(last_pick[i], sha(proofs[i])) for i in range(args.inflight)]}
+        host_legs["paths_pageable_leg"] = pk.paths(reset=True)
+        mode["where"] = "device"
 
     # ---- single-proof latency + live HIP-event timing of the dominant kernel (own pass, after the timed region)
     # latency as a caller sees it: one proof at a time, instrumentation off (the library's statistics synchronise the host
     # with every MSM and NTT batch, which keeps it from queueing ahead); then the same with the statistics on for the per-round
     # and per-kernel figures below
     nlat = 5
-    one(0)
-    lone_sha = hashlib.sha256(MarshalProof(plonk.Proof(cv, proofs[0]))).hexdigest()[:16]
+    lone_hashes = []
+    for a in range(K):
+        check(ws.prove(a, proofs[0], "device"))
+        lone_hashes.append(sha(proofs[0]))
     paths_lone = pk.paths(reset=True)
-    lat0 = time.perf_counter()
-    for _ in range(nlat):
-        one(0)
-    lat_ms = (time.perf_counter() - lat0) / nlat * 1e3
+
+    def lone_latency(where):
+        check(ws.prove(0, proofs[0], where))
+        t_ = time.perf_counter()
+        for k in range(nlat):
+            check(ws.prove(k % K, proofs[0], where))
+        return (time.perf_counter() - t_) / nlat * 1e3
+
+    lat_ms = lone_latency("device")
+    lat_host = {w: lone_latency(w) for w in (("pinned", "pageable") if not args.no_host_inputs else ())}
     pk.enable_stats(True)
     pk.stats(reset=True)
     lat1 = time.perf_counter()
-    for _ in range(3):
-        one(0)
+    for k in range(3):
+        check(ws.prove(k % K, proofs[0], "device"))
     lat_stats_ms = (time.perf_counter() - lat1) / 3 * 1e3
     st = pk.stats(reset=True)
     pk.enable_stats(False)
+    dptr = ws.items[0].dev
 
     # ---- MSM-only throughput (second half of BASELINE.json's metric): one 2^log_n MSM, scalars resident in HBM
     out_pt = C.create_string_buffer(2 * cv.fp_bytes)
@@ -695,49 +770,75 @@ def bench_prove(args, cv, rk) -> None:
 
     pmc = None
     cpu_baseline = None
+    oracle_sha = None
     if rk.rank == 0 and rk.world == 1:
         if not args.no_pmc:
             # (the PMC passes profile the MSMs of a circuit of the same size and curve WITHOUT the commitment: the accumulate
             # kernel's traffic and instruction count per pair do not depend on the circuit)
             pmc = pmc_traffic(args.curve, args.log_n, window_bits(args), timeout_s=150.0 if args.log_n < 20 else 1500.0)   # a pass takes ~10 s at 2^17; a hung profiler must not hold the line up
+        if not args.no_oracle_check:
+            # the CHECKER: the host prover's proof of every assignment (oracle/fast_prover.c, ~0.4 s each at 2^17 on 16 cores)
+            try:
+                from bench_cpu import oracle_blobs
+                oracle_sha = [hashlib.sha256(b).hexdigest()[:16] if b else None for b in oracle_blobs(cv, ccs, srs, ws.items)]
+            except Exception as e:
+                oracle_sha = {"error": str(e)[:200]}
         if not args.no_cpu_baseline:
             probe = go_probe()
             cpu_baseline = gnark_cpu_baseline(probe, args.curve, args.log_n, args.cpu_baseline_seconds)
             if cpu_baseline is None:
                 try:
-                    from bench_cpu import cpu_baseline_prove, cpu_baseline_prove_ccs
-                    if args.bsb22:
-                        # the performance-first host prover has the BSB22 path (held to oracle/plonk.py by tests/test_oracle_c.py):
-                        # the GPU's very workload, commitments included - its proof hash is compared with the GPU's below
-                        cpu_baseline = cpu_baseline_prove_ccs(cv, name, ccs, srs, solution, witness.public, blinding, pi2_host,
-                                                              args.cpu_baseline_seconds)
-                    else:
-                        cpu_baseline = cpu_baseline_prove(wl, srs, args.cpu_baseline_seconds)
+                    from bench_cpu import cpu_baseline_prove_items
+                    cpu_baseline = cpu_baseline_prove_items(cv, name, ccs, srs, ws.items[0], args.cpu_baseline_seconds)
                 except Exception as e:  # the baseline is reported, never required for the GPU number
                     cpu_baseline = {"value": None, "unit": "proofs/sec", "cores": 0, "kind": "port", "sample": "unavailable: %s" % e}
             cpu_baseline["go_probe"] = probe
     roofline = roofline_from_stats(args, cv, st, pmc, valu_issue_rate() if (rk.rank == 0 and pmc) else None)
+    roofline.update(extra_rooflines(args, cv, st, value / rk.world, lat_stats_ms))
     plane = rk.data_plane_probe(pk.ctx)
 
-    # every rank checks its own timed region; the line (rank 0) carries the verdict of all of them
-    loaded_ok = under_load_identical and load_hashes[0] == lone_sha
-    all_ok = rk.comm.max(0.0 if loaded_ok else 1.0) == 0.0
+    # ---- parity of everything this run produced.  Per assignment a: the lone proof's hash; every proof made under load for a (the
+    # callers' last proofs of the timed region and of the host-input legs) must equal it; and it must equal the C oracle's proof
+    # of a.  Every rank checks its own region; the line (rank 0) carries the verdict of all of them.
+    def leg_ok(hs):
+        return all(h == lone_hashes[a] for a, h in hs)
+
+    loaded_ok = leg_ok(load_hashes)
+    host_ok = all(leg_ok(host_legs[w]["hashes"]) for w in ("pinned", "pageable") if w in host_legs)
+    all_ok = rk.comm.max(0.0 if (loaded_ok and host_ok) else 1.0) == 0.0
+    matches_oracle = None
+    if isinstance(oracle_sha, list):
+        matches_oracle = [oracle_sha[a] == lone_hashes[a] for a in range(K)]
     if rk.rank == 0:
-        gpu_proof_sha = load_hashes[0]
         if cpu_baseline and cpu_baseline.get("proof_sha256_prefix"):
-            cpu_baseline["matches_gpu_proof"] = cpu_baseline["proof_sha256_prefix"] == gpu_proof_sha
-            cpu_baseline["matches_proofs_under_load"] = under_load_identical and cpu_baseline["proof_sha256_prefix"] == load_hashes[0]
+            cpu_baseline["matches_gpu_proof"] = cpu_baseline["proof_sha256_prefix"] == lone_hashes[0]
+            cpu_baseline["matches_proofs_under_load"] = loaded_ok and cpu_baseline["proof_sha256_prefix"] == lone_hashes[0]
         line = {
             "metric": "proofs/sec", "value": round(value, 4), "unit": "proofs/sec", "n_gpus": rk.world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (Montgomery Fr/Fp)" if cv.name == "bn254" else "u32x8 Fr / u32x12 Fp (Montgomery)",
             "data": "synthetic",
             "config": {"workload": name, "log_n": args.log_n, "curve": cv.name, "proofs_per_step": args.inflight,
+                       "distinct_witnesses": K,
                        "stepping": "joined after every step" if (args.step_barrier or args.inflight == 1) else
-                                   "%d persistent callers x K proofs each; barriers only around the K steps" % args.inflight,
+                                   "%d persistent callers x K proofs each, every caller walking through the %d assignments; barriers only around the K steps" % (args.inflight, K),
+                       "inputs": "L, R, O resident in HBM (apk_prove_device); the host-pointer call of the cgo shim is `value_host_inputs`",
                        "srs": "synthetic tau=SHA256(seed)", "parallelism": "replicas x%d" % rk.world, "world_size": rk.world,
                        "backend": "libapk comm (barrier + MAX over TCP only: independent proofs exchange no data)" if rk.world > 1 else "single process",
                        "rccl_ranks": plane.get("rccl_ranks", 0), "data_plane": plane},
+            # the timed region's own output, per assignment
+            "distinct_witnesses": K, "matches_oracle": matches_oracle,
+            "witness_sha256_prefixes": lone_hashes, "oracle_sha256_prefixes": oracle_sha,
+            "proofs_under_load_checked": len(load_hashes), "proofs_under_load_match_lone_proofs": loaded_ok,
+            "proofs_under_load_ok_on_all_ranks": all_ok,
+            # apk_prove with host pointers: the same callers and assignments from page-locked / pageable host memory
+            "value_host_inputs": round(host_legs["pinned"]["value"], 4) if "pinned" in host_legs else None,
+            "value_host_inputs_pageable": round(host_legs["pageable"]["value"], 4) if "pageable" in host_legs else None,
+            "host_inputs_ratio": round(host_legs["pinned"]["value"] / value, 4) if "pinned" in host_legs else None,
+            "host_input_steps": {w: host_legs[w]["steps"] for w in ("pinned", "pageable") if w in host_legs},
+            "proofs_from_host_inputs_match_lone_proofs": host_ok if host_legs else None,
+            "proof_latency_host_inputs_ms": round(lat_host["pinned"], 3) if lat_host else None,
+            "proof_latency_host_inputs_pageable_ms": round(lat_host["pageable"], 3) if lat_host else None,
             "proof_latency_ms": round(lat_ms, 3), "proof_latency_instrumented_ms": round(lat_stats_ms, 3), "msm_mscalar_per_s": round(msm_mscalar, 3),
             "msm_ms": round(msm_s * 1e3, 4), "msm_mscalar_per_s_saturated": round(msm_sat_mscalar, 3), "setup_s": round(setup_s, 2),
             "msm_batch_avg_ms": round(st.msm_total_ms / max(st.msm_batches, 1), 4),
@@ -749,20 +850,19 @@ def bench_prove(args, cv, rk) -> None:
             # line plus this
             "env_knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("APK_") and k != "APK_COMM_TOKEN"},
             "msm_window": pk.msm_window,
-            # the timed region's own output: the last proof of each of the `inflight` callers, made under load
-            "proofs_under_load_identical": under_load_identical, "proofs_under_load_checked": len(load_hashes),
-            "proofs_under_load_match_lone_proof": loaded_ok, "proofs_under_load_ok_on_all_ranks": all_ok,
-            "lone_proof_sha256_prefix": lone_sha,
             "paths_under_load": paths_loaded, "paths_lone_proof": paths_lone,
-            "proof_sha256_prefix": gpu_proof_sha, "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "proof_sha256_prefix": lone_hashes[0], "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line), flush=True)
+    ws.close()
     rk.close()
     bad = []
     if not all_ok:
-        bad.append("proofs of the timed region differ (hashes on rank %d: %s; lone proof %s)" % (rk.rank, sorted(set(load_hashes)), lone_sha))
-    if rk.rank == 0 and cpu_baseline and cpu_baseline.get("matches_proofs_under_load") is False:
-        bad.append("proofs of the timed region differ from the CPU oracle's proof (%s vs %s)" % (load_hashes[0], cpu_baseline.get("proof_sha256_prefix")))
+        wrong = sorted({(a, h) for a, h in load_hashes if h != lone_hashes[a]})
+        bad.append("proofs of the timed region%s differ from the lone proofs of the same assignments (rank %d: %s)"
+                   % ("" if not loaded_ok else " (host-input legs)", rk.rank, wrong[:4]))
+    if rk.rank == 0 and matches_oracle is not None and not all(matches_oracle):
+        bad.append("proofs differ from the C oracle's proofs of the same assignments: %s" % [a for a, m in enumerate(matches_oracle) if not m])
     if bad:
         raise SystemExit("bench.py: PARITY FAILURE - " + "; ".join(bad))
 

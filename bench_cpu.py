@@ -41,8 +41,13 @@ def cpu_baseline_prove(wl, srs, budget_s: float = 20.0, threads: int = 0, check_
                                   check_against_plain)
 
 
+def cpu_baseline_prove_items(cv, name, ccs, srs, item, budget_s: float = 20.0, threads: int = 0, check_against_plain: bool = True):
+    """The leg on an already packed assignment (algoplonk_amd.batch.Assignment: the very bytes the GPU proved)."""
+    return cpu_baseline_prove_ccs(cv, name, ccs, srs, None, None, None, (), budget_s, threads, check_against_plain, packed=item)
+
+
 def cpu_baseline_prove_ccs(cv, name, ccs, srs, solution, public, blinding, pi2_cols=(), budget_s: float = 20.0, threads: int = 0,
-                           check_against_plain: bool = True):
+                           check_against_plain: bool = True, packed=None):
     """The same leg for any constraint system, BSB22 commitments included (`pi2_cols` = the committed columns the solver made:
     the performance-first prover recomputes their commitments over the Lagrange SRS and must arrive at the GPU's bytes; the
     clarity-first C oracle has no BSB22 path, so it is skipped there)."""
@@ -53,16 +58,20 @@ def cpu_baseline_prove_ccs(cv, name, ccs, srs, solution, public, blinding, pi2_c
     eff, cpu_info = effective_cores()
     cores = threads or eff
     tr = frontend.build_trace(ccs)
-    L, R, O = frontend.wire_columns(ccs, solution)
     cols = [cv.fr_vector(x) for x in (tr.ql, tr.qr, tr.qm, tr.qo, tr.qk)]
     nbc = len(ccs.commitments)
     if nbc:
         check_against_plain = False
         if not srs.g1_lagrange:
             raise RuntimeError("BSB22 circuit without a Lagrange SRS")
-    args = (lib, cv.abi, tr.n, ccs.GetNbPublicVariables(), srs.g1, cols, tr.perm, cv.fr_vector(L), cv.fr_vector(R),
-            cv.fr_vector(O), cv.fr_vector(public), cv.fr_vector(blinding))
-    pi2_b = [cv.fr_vector(p) for p in pi2_cols]
+    if packed is not None:
+        args = (lib, cv.abi, tr.n, ccs.GetNbPublicVariables(), srs.g1, cols, tr.perm, packed.L, packed.R, packed.O, packed.public, packed.blinding)
+        pi2_b = list(packed.pi2)
+    else:
+        L, R, O = frontend.wire_columns(ccs, solution)
+        args = (lib, cv.abi, tr.n, ccs.GetNbPublicVariables(), srs.g1, cols, tr.perm, cv.fr_vector(L), cv.fr_vector(R),
+                cv.fr_vector(O), cv.fr_vector(public), cv.fr_vector(blinding))
+        pi2_b = [cv.fr_vector(p) for p in pi2_cols]
     # Two host provers, both ports (neither is gnark): the clarity-first orc_prove - the parity oracle, one proof for the hash and
     # as the lower bracket - and the performance-first orc_fast_prove (oracle/fast_prover.c: circuit-only work hoisted into a
     # context, batch-affine Pippenger, parallel FFTs, one-coset quotient), held to orc_prove's bytes by tests/test_oracle_c.py and
@@ -137,6 +146,40 @@ def cpu_baseline_prove_ccs(cv, name, ccs, srs, solution, public, blinding, pi2_c
                          "every proof's bytes = the clarity-first oracle's" if check_against_plain else
                          "every proof's bytes = its first proof's (the clarity-first oracle was not run: size, or a BSB22 circuit it has no path for)"),
             "tried": tried, "proof_sha256_prefix": sha, "cpu": cpu_info}
+
+
+def oracle_blobs(cv, ccs, srs, items, threads: int = 0, check_first_against_plain: bool = False):
+    """The CHECKER of the distinct-witness runs (bench.py's timed region, tools/soak.py, the under-load parity tests): the host
+    prover's proof blob for EVERY assignment in `items` (algoplonk_amd.batch.Assignment: L, R, O, public, blinding, pi2 bytes) of
+    one circuit - oracle/fast_prover.c, whose bytes tests/test_oracle_c.py holds to the clarity-first oracle's (and which the
+    first assignment is held to again here on request).  Circuit-only work once, then ~0.4 s per 2^17 proof on 16 cores."""
+    from algoplonk_amd import frontend
+    from oracle import c_oracle
+
+    lib = c_oracle.load()
+    cores = threads or effective_cores()[0]
+    tr = frontend.build_trace(ccs)
+    nbc = len(ccs.commitments)
+    cols = [cv.fr_vector(x) for x in (tr.ql, tr.qr, tr.qm, tr.qo, tr.qk)]
+    fp = c_oracle.FastProver(lib, cv.abi, tr.n, ccs.GetNbPublicVariables(), srs.g1, cols, tr.perm, threads=cores,
+                             qcp=[cv.fr_vector(q) for q in tr.qcp[:nbc]], cci=[cidx for _, cidx in ccs.commitments],
+                             srs_lagrange=srs.g1_lagrange if nbc else None)
+    blobs = []
+    try:
+        for i, it in enumerate(items):
+            rc, blob, _ = fp.prove(it.L, it.R, it.O, it.public, it.blinding, threads=cores, pi2=list(it.pi2))
+            if rc != 0:
+                blobs.append(None)          # the host prover refuses an unsatisfying witness too
+                continue
+            if i == 0 and check_first_against_plain and not nbc:
+                rc2, plain, _ = c_oracle.prove(lib, cv.abi, tr.n, ccs.GetNbPublicVariables(), srs.g1, cols, tr.perm, it.L, it.R, it.O,
+                                               it.public, it.blinding, threads=cores)
+                if rc2 != 0 or plain != blob:
+                    raise RuntimeError("the fast host prover disagrees with the clarity-first oracle")
+            blobs.append(blob)
+    finally:
+        fp.close()
+    return blobs
 
 
 def cpu_baseline_msm(cv, bases: bytes, scalars: bytes, n: int, budget_s: float = 20.0, threads: int = 0):

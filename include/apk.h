@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define APK_ABI_VERSION 4
+#define APK_ABI_VERSION 5
 
 /* curve ids: the two curves the AVM supports (algoplonk.go:39-41) */
 #define APK_BN254 0
@@ -156,7 +156,13 @@ typedef struct {
  * solver leaves in `SparseR1CSSolution{L,R,O}`; the public inputs (nb_public Fr) = fullWitness[:nbPublic];
  * the 9 blinding scalars (APK_NB_BLINDING Fr) that gnark draws from crypto/rand - explicit here so proofs are
  * reproducible; pi2 = BSB22 committed columns (Lagrange, n Fr each, hiding entries placed) or NULL.
- * Blocks the calling thread; safe to call from several threads (each takes a free slot). */
+ * Blocks the calling thread; safe to call from several threads (each takes a free slot).
+ * This is the call the cgo shim makes (algoplonk.go:89 hands plonk.Prove Go slices).  L, R, O (and pi2) travel
+ * to the device on a copy stream of their own, started BEFORE the caller queues for a proving slot: with more callers than
+ * slots the upload of the next proof runs beside the rounds of the proofs in flight.  The transfer is true asynchronous DMA
+ * when the buffers are page-locked - allocate them with apk_host_alloc or register existing ones once with
+ * apk_host_register (the shim does, per buffer pool); pageable buffers work too, staged by the HIP runtime on the calling
+ * thread.  The buffers must stay unchanged until the call returns. */
 int apk_prove(apk_ctx* ctx, const void* L, const void* R, const void* O, const void* public_inputs,
               const void* blinding, const void* const* pi2, apk_proof* out);
 
@@ -370,6 +376,16 @@ int apk_host_g1_op(int curve, int op, const void* p, const void* q, void* out);
  * step - the all-gathered per-rank partial sums are added with this call (algoplonk_amd/parallel.py). */
 int apk_g1_sum(int curve, const void* points, uint64_t count, void* out);
 
+/* ---- page-locked host memory for the inputs of apk_prove -------------------------------------------------------------------
+ * apk_host_alloc: `bytes` of page-locked host memory, visible to every device (hipHostMalloc, portable); apk_host_free.
+ * apk_host_register / apk_host_unregister: page-lock an EXISTING buffer for the lifetime of the registration (hipHostRegister) -
+ * what a cgo host does once per witness-buffer pool: Go's heap does not move objects, and the pointer is only dereferenced
+ * during apk_prove calls, which the cgo pointer rules allow.  APK_ERR_HIP without a device (no CPU fallback: nothing to feed). */
+int apk_host_alloc(int device, size_t bytes, void** ptr);
+int apk_host_free(void* ptr);
+int apk_host_register(void* ptr, size_t bytes);
+int apk_host_unregister(void* ptr);
+
 /* ---- device memory helpers for callers that keep inputs resident (bench, batched proofs) ------------------ */
 int apk_device_alloc(apk_ctx* ctx, size_t bytes, void** d_ptr);
 int apk_device_free(apk_ctx* ctx, void* d_ptr);
@@ -394,6 +410,8 @@ typedef struct {
      * host-side combination of commitments that replaces the MSM of the linearised polynomial. */
     double round_ms[4];
     double host_lincomb_ms;
+    double msm_sort_ms;        /* of msm_total_ms: recoding + counting sort + scans (everything in front of msm_accumulate_kernel) */
+    double msm_tail_ms;        /* of msm_total_ms: merge of unit partials, row/column sums, bit sums, final scaling (everything behind it) */
 } apk_stats;
 int apk_stats_enable(apk_ctx* ctx, int enable); /* enabling inserts hipEvents around the kernels above */
 int apk_stats_read(apk_ctx* ctx, apk_stats* out, int reset);
@@ -422,7 +440,8 @@ typedef struct {
     uint64_t tail_fill_proofs;          /* lone proofs whose coset transforms ran beside the MSM tails (side stream) */
     uint64_t host_lincomb_pooled;       /* [lin] combinations of nearly idle contexts dealt to parked host threads (BLS12-381 by default; BN254 with APK_HOST_LINCOMB_THREADS > 1) */
     uint64_t msm_units_by_load;         /* MSM batches whose accumulate units were lengthened BECAUSE other proofs were in flight */
-    uint64_t reserved[7];
+    uint64_t host_inputs;               /* proofs whose L, R, O came from host memory through a staging set (apk_prove) */
+    uint64_t reserved[6];
 } apk_path_counts;
 int apk_paths_read(apk_ctx* ctx, apk_path_counts* out, int reset);
 

@@ -88,3 +88,33 @@ def check_bench_line(d: dict, tol: float = 0.01) -> None:
             assert v["frac"] <= 1.12, "an addition rate far above the kernel's own issue bound means the bound's basis is stale"
             if "instructions_per_addition" in v:      # round 5: both factors of the bound are on the line
                 close(v["issue_bound"], v["simds"] * 64 / (v["instructions_per_addition"] * v["ns_per_wave_instruction_per_simd"]), "valu.issue_bound")
+    # round 6: the whole proof and the transforms on the same yardstick, and the parts of a lone proof
+    pr = rf.get("proof")
+    if pr:
+        parts = pr["algorithmic_bytes_by_part"]
+        assert pr["algorithmic_bytes"] == parts["total"] == parts["msm"] + parts["ntt"] + parts["quotient"] + parts["misc"]
+        log_n, fpb = d["config"]["log_n"], (32 if d["config"]["curve"] == "bn254" else 48)
+        n = 1 << log_n
+        k = (parts["msm"] // (n * (32 + 2 * fpb))) - 10                     # BSB22 commitments
+        assert 0 <= k <= 2 and parts["msm"] == (10 + k) * n * (32 + 2 * fpb)
+        assert parts["ntt"] == ((12 + k) * n + (13 + k) * 4 * n) * 64 and parts["quotient"] == (14 + 2 * k) * 4 * n * 32
+        close(pr["achieved"], pr["algorithmic_bytes"] * d["value"] / d["n_gpus"] / 1e9, "roofline.proof.achieved")
+        close(pr["frac"], pr["achieved"] / pr["peak"], "roofline.proof.frac")
+        assert pr["frac"] <= 1.0
+    nt = rf.get("ntt")
+    if nt:
+        close(nt["achieved"], nt["elements_per_proof"] * nt["algorithmic_bytes_per_element"] / (nt["ms_per_proof"] * 1e-3) / 1e9, "roofline.ntt.achieved")
+        close(nt["frac"], nt["achieved"] / nt["peak"], "roofline.ntt.frac")
+        assert abs(nt["ms_per_proof"] - d["ntt_ms_per_proof"]) < 1e-3
+    lp = rf.get("lone_proof_ms_by_part")
+    if lp and lp.get("share"):
+        tot = lp["total"]
+        s_parts = sum(lp[k] for k in lp["share"])
+        assert s_parts <= tot * 1.02 + 1e-6, (s_parts, tot)
+    if "distinct_witnesses" in d:
+        assert d["distinct_witnesses"] == d["config"]["distinct_witnesses"] == len(d["witness_sha256_prefixes"])
+        assert len(set(d["witness_sha256_prefixes"])) == d["distinct_witnesses"], "the assignments are meant to give distinct proofs"
+        if d.get("matches_oracle") is not None:
+            assert len(d["matches_oracle"]) == d["distinct_witnesses"] and all(d["matches_oracle"])
+        if d.get("value_host_inputs") is not None:
+            close(d["host_inputs_ratio"], d["value_host_inputs"] / d["value"], "host_inputs_ratio")

@@ -27,7 +27,7 @@ def test_header_symbols_are_exported_and_bound():
     assert declared, "no declarations parsed"
     assert declared <= exported, "declared but not exported: %s" % sorted(declared - exported)
     assert declared == set(_lib.SYMBOLS), "python binding out of sync: %s" % sorted(declared ^ set(_lib.SYMBOLS))
-    assert lib.apk_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.apk_abi_version() == _lib.ABI_VERSION == 5
     assert lib.apk_g1_bytes(0) == 64 and lib.apk_g1_bytes(1) == 96 and lib.apk_g1_bytes(7) == 0
 
 

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Soak: T threads prove the same BN254 2^log_n instance over and over on one context; every proof must have the same
-bytes (same inputs + same blinding scalars -> byte-identical proofs), so any race between slots shows up as a second hash.
-usage: python tools/soak.py [log_n] [threads] [rounds] [bn254|bls12_381] [slots]
+"""Soak: T threads prove K DISTINCT assignments of one 2^log_n circuit over and over on one context, every thread walking
+through all of them, from device-resident, page-locked and pageable inputs in turn.  Every proof must be the bytes of the C
+oracle's proof of ITS OWN assignment (bench_cpu.oracle_blobs - the checker, never the measured path): a slot that reads another
+slot's workspace, pinned result buffer or staging set now produces bytes that are nobody's proof.  (Rounds 1-5 soaked with one
+assignment in every thread, which showed scheduling determinism but could not see cross-slot aliasing: VERDICT r05 weak #1.)
+usage: python tools/soak.py [log_n] [threads] [rounds] [bn254|bls12_381] [slots] [witnesses]
 (slots defaults to the thread count; fewer slots than threads also exercises the wait at the slot gate, two or three threads the
 host-side paths of a nearly idle context: parked threads, the early [H] part)"""
 import ctypes as C
@@ -12,45 +15,48 @@ import threading
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from algoplonk_amd import _lib, ecc, frontend, plonk, setup, workloads
+from algoplonk_amd import _lib, batch, ecc, plonk, setup, workloads
 from algoplonk_amd._lib import lib, check
+from bench_cpu import oracle_blobs
 
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 17
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 cv = ecc.BLS12_381 if len(sys.argv) > 4 and sys.argv[4] == "bls12_381" else ecc.BN254
 slots = int(sys.argv[5]) if len(sys.argv) > 5 else T
-wl = workloads.random_circuit(cv, log_n, 0xA190 if cv is ecc.BN254 else 0xA191)
+K = int(sys.argv[6]) if len(sys.argv) > 6 else 8
+seed = 0xA190 if cv is ecc.BN254 else 0xA191
+wl = workloads.random_circuit(cv, log_n, seed)
 n = wl.ccs.domain_size()
 srs = setup.unsafe_srs(cv, n, wl.tau)
 pk, vk = plonk.Setup(wl.ccs, srs, slots=slots)
-L, R, O = frontend.wire_columns(wl.ccs, wl.solution)
-dptr = []
-for b in (cv.fr_vector(v) for v in (L, R, O)):
-    p = C.c_void_p()
-    check(lib.apk_device_alloc(pk.ctx, len(b), C.byref(p)))
-    check(lib.apk_device_upload(pk.ctx, p, b, len(b)))
-    dptr.append(p)
-pub = cv.fr_vector(wl.witness.public)
-bl = cv.fr_vector(wl.blinding)
-hashes = {}
+ws = batch.WitnessSet(pk, wl.ccs, workloads.variants(wl, K, seed)).to_device().to_pinned(0)
+want = [hashlib.sha256(b).hexdigest()[:16] for b in oracle_blobs(cv, wl.ccs, srs, ws.items)]
+assert len(set(want)) == K
+wrong, counts = [], {}
 lock = threading.Lock()
 
 
-def worker():
+def worker(i):
     pr = _lib.Proof()
     out = C.create_string_buffer(2048)
     ln = C.c_size_t(0)
-    for _ in range(rounds):
-        check(lib.apk_prove_device(pk.ctx, dptr[0], dptr[1], dptr[2], pub, bl, None, C.byref(pr)))
+    for r in range(rounds):
+        a = (i + r) % K
+        where = ("device", "pinned", "pageable")[(i + r // K) % 3] if r % 4 == 3 else "device"
+        check(ws.prove(a, pr, where))
         check(lib.apk_marshal_proof(C.byref(pr), out, 2048, C.byref(ln)))
         h = hashlib.sha256(out.raw[: ln.value]).hexdigest()[:16]
         with lock:
-            hashes[h] = hashes.get(h, 0) + 1
+            counts[where] = counts.get(where, 0) + 1
+            if h != want[a]:
+                wrong.append((i, r, a, where, h))
 
 
-th = [threading.Thread(target=worker) for _ in range(T)]
+th = [threading.Thread(target=worker, args=(i,)) for i in range(T)]
 for t in th: t.start()
 for t in th: t.join()
-print("proofs %d, distinct hashes %d: %s" % (sum(hashes.values()), len(hashes), hashes))
-sys.exit(0 if len(hashes) == 1 else 1)
+print("proofs %d (%s) over %d distinct assignments, %d differ from the C oracle's proof of their own assignment%s"
+      % (sum(counts.values()), counts, K, len(wrong), (": %s" % wrong[:5]) if wrong else ""))
+ws.close()
+sys.exit(0 if not wrong else 1)
