@@ -18,6 +18,7 @@
 #include <memory>
 #include <mutex>
 #include <string.h>
+#include <time.h>
 #include <vector>
 
 #include "backend.h"
@@ -27,6 +28,7 @@
 #include "kernels_setup.h"
 #include "host_msm.h"
 #include "slot_gate.h"
+#include "gang.h"
 #include "sha256.h"
 
 namespace apk {
@@ -66,6 +68,13 @@ struct DevBuf {
 template <class T> static inline T* ptr(const DevBuf& b) { return reinterpret_cast<T*>(b.p); }
 
 static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// A slot's page-locked result buffer (the last kernel of a chain writes there through the buffer's device view):
+//   [PIN_AFF ..)     this proof's commitments after sync_results(), affine
+//   [PIN_XYZZ ..)    MSM sums as they leave the device, XYZZ: up to MSM_ARGS_MAX points - a gang's merged batch lands in its LEAD's
+//   [PIN_FR ..)      evaluations / the grand product's total
+//   PIN_TAIL, PIN_DENSITY   the quotient's tail flag, the wires' digit count
+constexpr size_t PIN_AFF = 0, PIN_XYZZ = 1024, PIN_FR = 4096, PIN_TAIL = 6144, PIN_DENSITY = 6208, PIN_BYTES = 8192;
 
 // kzg.ToLagrangeG1 on device buffers (defined at the end of this file): out[i] = [L_i(tau)]G1 from in[j] = [tau^j]G1
 template <class FRP, class FPP>
@@ -134,7 +143,15 @@ class CurveBackend : public Backend {
         bool operator==(const GraphKey& o) const { return table == o.table && memcmp(&a, &o.a, sizeof a) == 0; }
     };
     struct Slot {
-        hipStream_t stream = nullptr;
+        hipStream_t stream = nullptr;      // the stream this slot's launches go to: its own, or - as a gang member - its lead's
+        hipStream_t own_stream = nullptr;  // one of the context's stream_pool_, held while this slot leads a gang or proves alone (not owned)
+        // gang membership of the proof in flight on this slot (gang.h; set by MemberGuard)
+        Slot* lead = nullptr;              // whose stream, MSM workspace, transform scratch and XYZZ result area it uses (itself when alone)
+        int gang_idx = 0;
+        bool in_gang = false;
+        uint32_t res_off = 0;              // first point of this proof's pending MSM sums in the lead's XYZZ area
+        uint32_t res_write_off = 0;        // (as a lead) where the launch sequence being queued writes its sums in that area
+        Gang gang;                         // used when this slot leads
         hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
         size_t index = 0;          // position in slots_ = the slot's number at the gate
         // polynomials
@@ -184,6 +201,11 @@ class CurveBackend : public Backend {
     bool msm_only_ = false;
     std::unique_ptr<HostPool> lc_pool_;   // parked host threads for the [lin] combination of a lone proof (created on first use)
     bool many_slots_ = false;   // a throughput context (more than two proving slots): small MSMs may take the two-level sort under load
+    // gangs (gang.h, slot_gate.h): up to gang_cap_ proofs per stream, their MSM / NTT batches in one launch sequence.  A slot's MSM
+    // workspace, transform scratch and XYZZ result area are sized for ws_batch_ = MSM_MAX_BATCH x gang_cap_ operands.
+    int gang_cap_ = 1;
+    uint32_t ws_batch_ = MSM_MAX_BATCH;
+    Gang::Launcher gang_launcher_;
     uint32_t msm_bases_ = 0;  // bases the MSM workspaces are sized for
     uint32_t NB_ = 0;
     Fr omega_, omega_inv_, omega4_, omega4_inv_, shift_, shift_inv_, n_inv_, n4_inv_;
@@ -224,6 +246,9 @@ class CurveBackend : public Backend {
     Aff vk_pts_[8 + APK_MAX_COMMITMENTS];
     HostFixedBase<FPP> vk_fixed_;   // host tables of [Ql][Qr][Qm][Qo][S3] for the [lin] combination (host_msm.h)
     std::vector<Slot*> slots_;
+    // The context's streams: as many as it may run at a time (max 16), whichever of its slots lead.  A stream per SLOT - 32 slots
+    // for gangs of two - put 23 hardware queues to work within 150 ms and starved some of them for up to 90 ms.
+    std::vector<hipStream_t> stream_pool_;
     SlotGate gate_;            // who proves on which slot; its busy count picks the load-dependent kernel forms (slot_gate.h)
     // Host inputs (apk_prove: the call the cgo shim makes): a caller takes one of `in_sets_` BEFORE it takes a
     // proving slot and sends L, R, O on the context's copy stream - so the upload of a proof that still waits for a slot (32 callers
@@ -264,7 +289,7 @@ class CurveBackend : public Backend {
     } sc_;
     // which forms the load-dependent choices took (apk_paths_read): always counted, relaxed atomics
     enum PathIdx { P_PROOFS, P_MSM_BATCHES, P_SORT2, P_SORT2_LOAD, P_SORT_FUSED, P_LEAN_TAIL, P_ROWCOL_SERIAL, P_COMBINE_QUAD, P_SMALL_UNITS,
-                   P_ONE_LAUNCH, P_LAGRANGE_WIRES, P_NTT_SEQ, P_NTT_R4, P_NTT_R4_LOAD, P_TAIL_FILL, P_LINCOMB_POOL, P_UNIT_LOADED, P_HOST_INPUTS, P_COUNT };
+                   P_ONE_LAUNCH, P_LAGRANGE_WIRES, P_NTT_SEQ, P_NTT_R4, P_NTT_R4_LOAD, P_TAIL_FILL, P_LINCOMB_POOL, P_UNIT_LOADED, P_HOST_INPUTS, P_GANG_PROOFS, P_GANG_MSM, P_GANG_NTT, P_COUNT };
     std::atomic<uint64_t> paths_[P_COUNT] = {};
     void path(PathIdx i) { paths_[i].fetch_add(1, std::memory_order_relaxed); }
     int paths_read(apk_path_counts* out, int reset) override {
@@ -282,6 +307,7 @@ class CurveBackend : public Backend {
 
     ~CurveBackend() override {
         (void)hipSetDevice(device_);
+        for (hipStream_t st : stream_pool_) if (st) (void)hipStreamSynchronize(st);
         if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
         for (InputSet* is : in_sets_) {
             if (is->ready) (void)hipEventDestroy(is->ready);
@@ -289,7 +315,6 @@ class CurveBackend : public Backend {
         }
         if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
         for (Slot* s : slots_) {
-            if (s->stream) (void)hipStreamSynchronize(s->stream);
             for (auto& e : s->graphs) (void)hipGraphExecDestroy(e.second);
             if (s->ev0) (void)hipEventDestroy(s->ev0);
             if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -300,9 +325,9 @@ class CurveBackend : public Backend {
             if (s->ev_acc) (void)hipEventDestroy(s->ev_acc);
             if (s->ev_side) (void)hipEventDestroy(s->ev_side);
             if (s->ev_sync) (void)hipEventDestroy(s->ev_sync);
-            if (s->stream) (void)hipStreamDestroy(s->stream);
             delete s;
         }
+        for (hipStream_t st : stream_pool_) if (st) (void)hipStreamDestroy(st);
     }
 
     // ---------------------------------------------------------------------------------------------- NTT runner
@@ -310,6 +335,23 @@ class CurveBackend : public Backend {
     // sub_log > 0: a transform of 1 / 2^sub_log of the size, on the same twiddle table (sub-coset transforms)
     int run_ntt_batch(hipStream_t st, int which, bool inverse, int count, const Fr* const* ins, Fr* const* outs, const uint32_t* in_lens,
                       uint32_t out_len, const Fr* pre, const Fr* post, const Fr* scale, int sub_log = 0) {
+        Slot* m = gang_member();
+        if (m && m->in_gang && st == m->stream && count <= NTT_MAX_BATCH) {     // a merge point of the gang (gang_launch)
+            NttReq nr{};
+            nr.member = m; nr.which = which; nr.inverse = inverse; nr.count = count;
+            for (int i = 0; i < count; i++) { nr.ins[i] = ins[i]; nr.outs[i] = outs[i]; nr.in_lens[i] = in_lens[i]; }
+            nr.out_len = out_len; nr.pre = pre; nr.post = post; nr.scale = scale; nr.sub_log = sub_log;
+            GangReq r;
+            r.kind = GANG_KIND_NTT; r.args = &nr;
+            const int rc = m->lead->gang.meet(m->gang_idx, r, gang_launcher_);
+            if (rc != APK_OK) set_error("%s", r.err.c_str());
+            return rc;
+        }
+        return run_ntt_batch_now(st, which, inverse, count, ins, outs, in_lens, out_len, pre, post, scale, sub_log);
+    }
+    int run_ntt_batch_now(hipStream_t st, int which, bool inverse, int count, const Fr* const* ins, Fr* const* outs, const uint32_t* in_lens,
+                          uint32_t out_len, const Fr* pre, const Fr* post, const Fr* scale, int sub_log = 0) {
+        if (count < 1 || count > NTT_ARGS_MAX) { set_error("ntt: batch of %d", count); return APK_ERR_ARG; }
         const int log_n = (which ? (int)log_n_ + 2 : (int)log_n_) - sub_log;
         const Fr* tw = which ? (inverse ? ptr<Fr>(twi_4n_) : ptr<Fr>(tw_4n_)) : (inverse ? ptr<Fr>(twi_n_) : ptr<Fr>(twu_n_));
         // small transforms are latency-bound: 512-element tiles (18 KiB LDS) give >= 256 workgroups at 2^17.  Large ones were
@@ -332,7 +374,7 @@ class CurveBackend : public Backend {
         for (int i = 0; i < count; i++) { nb.in[i] = ins[i]; nb.out[i] = outs[i]; nb.in_len[i] = in_lens[i]; }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         Slot* owner = nullptr;
-        for (Slot* s : slots_) if (s->stream == st || (s->side && s->side == st)) owner = s;
+        for (Slot* s : slots_) if (s->own_stream == st || (s->side && s->side == st)) owner = s;    // (a gang's stream is its lead's own)
         if (passes > 1) {   // the passes hand each other unsaturated-limb elements through the slot's scratch
             if (!owner || log_n > 29) { set_error("ntt: no workspace for this stream"); return APK_ERR_STATE; }
             for (int i = 0; i < count; i++) nb.wide[i] = ptr<FeU<FRP>>(owner->ntt_wide) + ((size_t)i << log_n);
@@ -461,7 +503,7 @@ class CurveBackend : public Backend {
         if (!graphs || stats_on_) return run_msm_body(s, T, a, h_out);
         GraphKey key{};
         key.table = T.table.p; key.a = a;
-        for (uint32_t b = a.batch; b < MSM_MAX_BATCH; b++) { key.a.scalars[b] = nullptr; key.a.len[b] = 0; key.a.offset[b] = 0; }
+        for (uint32_t b = a.batch; b < MSM_ARGS_MAX; b++) { key.a.scalars[b] = nullptr; key.a.len[b] = 0; key.a.offset[b] = 0; }
         for (size_t i = 0; i < s.graphs.size(); i++)
             if (s.graphs[i].first == key) {
                 if (i) std::swap(s.graphs[i], s.graphs[0]);          // most recently used first
@@ -506,6 +548,7 @@ class CurveBackend : public Backend {
         hipStream_t st = s.stream;
         uint32_t maxlen = 0;
         uint64_t entries = 0;
+        if (a.batch == 0 || a.batch > ws_batch_ || a.batch > (uint32_t)MSM_ARGS_MAX) { set_error("msm: a batch of %u exceeds the workspace's %u", a.batch, ws_batch_); return APK_ERR_ARG; }
         for (uint32_t b = 0; b < a.batch; b++) {
             if (a.len[b] > T.n_bases || a.offset[b] > T.n_bases - a.len[b]) { set_error("msm: %u scalars exceed the %u bases", a.len[b], T.n_bases); return APK_ERR_ARG; }
             if (a.len[b] > maxlen) maxlen = a.len[b];
@@ -619,7 +662,7 @@ class CurveBackend : public Backend {
         static const int small_scan_env = env_int("APK_MSM_PART_SMALL_SCAN", 1, 0, 1);   // 0: always the three-launch scan (tests)
         const bool small_scan = small_scan_env && a.batch * P <= 2048u && G2 <= 128u;
         const uint64_t counts_words = s.counts.bytes / 4;
-        const bool sort2 = sort2_want && P >= 4 && s.sort_tmp.p && G2 <= MSM_PART_GMAX &&
+        const bool sort2 = sort2_want && P >= 4 && s.sort_tmp.p && G2 <= MSM_PART_GMAX && (uint64_t)a.batch * P <= (uint64_t)MSM_MAX_BATCH * MSM_PART_MAX &&
                            (uint64_t)a.batch * G2 * P * 2 + (uint64_t)a.batch * P * (1 + MSM_PART_CHUNKS) <= counts_words;
         if (!sort2 && !one_level_ok()) { set_error("msm: a %d-bit window sorts in two levels only, and this batch does not fit them (%u slices, %u partitions)", c_, G2, P); return APK_ERR_STATE; }
         if (sort2) { G = G2; gd = dim3(G, a.batch); }
@@ -650,7 +693,7 @@ class CurveBackend : public Backend {
             // BLS12-381 2^21 (1 024 slices x 1 024 partitions, 32 entries per run, two strided table loads per run) it took
             // 64 ms per 99 launches against the four-launch form's 21 (profiles/r04_kernel_trace_bls12381_2p21.txt, first cut).
             const bool fused = fused_env && !graphs_on /* a replayed capture would reuse one totals buffer */ && stage_cap / P >= 64u &&
-                               (uint64_t)per_slice * W_ <= part_stage_max() && s.ptot2.p &&
+                               (uint64_t)per_slice * W_ <= part_stage_max() && s.ptot2.p && (uint64_t)ws_batch_ * P <= (uint64_t)MSM_MAX_BATCH * MSM_PART_MAX &&
                                (uint64_t)a.batch * G * (P + 1) <= counts_words &&
                                (uint64_t)a.batch * G * stage_cap * 4 <= s.sort_tmp.bytes;
             if (fused) {
@@ -662,7 +705,8 @@ class CurveBackend : public Backend {
                 else msm_part1_kernel<FRP, false><<<gd, dth, (size_t)stage_cap * 4 + cursors_lds, st>>>(a, win_, pc, T.n_bases, G, ptr<uint32_t>(s.sort_tmp), stage_cap, pcounts, pt_cur);
                 KCHK();
                 msm_part_sort_runs_kernel<0><<<dim3(P, a.batch), 1024, (size_t)tile_cap * 4, st>>>(
-                    ptr<uint32_t>(s.sort_tmp), stage_cap, pcounts, pt_cur, pt_next, pc, G, NB_, ptr<uint32_t>(s.hist), ptr<uint32_t>(s.sorted), tile_cap);
+                    ptr<uint32_t>(s.sort_tmp), stage_cap, pcounts, pt_cur, pt_next, pc, G, NB_, ptr<uint32_t>(s.hist), ptr<uint32_t>(s.sorted), tile_cap,
+                    ws_batch_ * P);
                 KCHK();
             } else {
             if (a.plain) msm_part_kernel<FRP, false, true><<<gd, dth, cursors_lds, st>>>(a, win_, pc, NB_, T.n_bases, G, pcounts, nullptr, nullptr, 0);
@@ -712,7 +756,7 @@ class CurveBackend : public Backend {
             // workgroup then carries the totals step's 40 KiB of LDS and an agent-scope fence, and the step itself runs behind the
             // slowest of them instead of on an idle CU.  Off; three launches stay.
             static const int scan_fused = env_int("APK_MSM_SCAN_FUSED", 0, 0, 1);
-            uint32_t* scan_done = ptr<uint32_t>(s.done_count) + MSM_MAX_BATCH;
+            uint32_t* scan_done = ptr<uint32_t>(s.done_count) + MSM_ARGS_MAX;
 #define APK_SCAN_LOCAL(F, I) msm_scan_local_kernel<F, I><<<nblk, MSM_SCAN_BLOCK, 0, st>>>(ptr<uint32_t>(s.hist), total_buckets, unit, ptr<uint32_t>(s.offsets), \
                 ptr<uint32_t>(s.unit_off), ptr<uint32_t>(s.full_off), ptr<uint32_t>(s.rem_rank), ptr<uint32_t>(s.merge_rank), blk_tot, blk_bins, nblk, scan_done)
             if (scan_fused && items == 1) {
@@ -825,7 +869,8 @@ class CurveBackend : public Backend {
         else
             msm_rowcol_kernel<FPP><<<dim3(rows + cols, a.batch), 256, 0, st>>>(ptr<PtU>(s.bucket_sum), NB_, rows, cols, ptr<PtU>(s.rowcol));
         KCHK();
-        Pt* const res_out = s.d_pinned ? reinterpret_cast<Pt*>(s.d_pinned + 1024) : ptr<Pt>(s.result_xyzz);
+        if (s.res_write_off + a.batch > (uint32_t)MSM_ARGS_MAX) { set_error("msm: result area overflow"); return APK_ERR_STATE; }
+        Pt* const res_out = s.d_pinned ? reinterpret_cast<Pt*>(s.d_pinned + PIN_XYZZ) + s.res_write_off : ptr<Pt>(s.result_xyzz);
         // the sums leave the device in XYZZ form: the one field inversion of the affine conversion takes a lone GPU lane
         // ~100 us and the host a few; sync_results() finishes them into h_out (= the slot's pinned buffer)
         if (!APK_PHASE(16)) {
@@ -850,7 +895,7 @@ class CurveBackend : public Backend {
         }
         if (stats_on_) HIPCHK(hipEventRecord(s.ev1, st));
         (void)h_out;
-        if (!s.d_pinned) HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(s.h_pinned) + 1024, s.result_xyzz.p, a.batch * sizeof(Pt), hipMemcpyDeviceToHost, st));
+        if (!s.d_pinned) HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(s.h_pinned) + PIN_XYZZ + s.res_write_off * sizeof(Pt), s.result_xyzz.p, a.batch * sizeof(Pt), hipMemcpyDeviceToHost, st));
         s.pending_pts = a.batch;
         if (stats_on_) {
             HIPCHK(hipEventSynchronize(s.ev1));
@@ -878,6 +923,14 @@ class CurveBackend : public Backend {
     // sync_results(), after the stream has produced the scalar vectors - the launches queued in between (coset NTTs ...) run
     // on this GPU while the other GPUs commit.
     int commit(Slot& s, const MsmTables& T, int basis, const MsmBatchArgs& a, Aff* h_out) {
+        if (!hook_ && s.in_gang) {      // a merge point of the gang: ONE launch sequence for every member's batch (gang_launch)
+            MsmReq mr{&s, &T, a};
+            GangReq r;
+            r.kind = GANG_KIND_MSM; r.args = &mr;
+            const int rc = s.lead->gang.meet(s.gang_idx, r, gang_launcher_);
+            if (rc != APK_OK) set_error("%s", r.err.c_str());     // (the launch ran on another member's thread)
+            return rc;
+        }
         if (!hook_) return run_msm(s, T, a, h_out);
         for (uint32_t b = 0; b < a.batch; b++)
             if (a.len[b] > T.n_bases || a.offset[b] > T.n_bases - a.len[b]) { set_error("msm: %u scalars exceed the %u bases", a.len[b], T.n_bases); return APK_ERR_ARG; }
@@ -917,12 +970,29 @@ class CurveBackend : public Backend {
     // Wait for the slot's stream.  hipStreamSynchronize spins on the host (ROCm's default with many CPUs visible): right for a lone
     // proof (its six waits are on the critical path), wrong when 16 proving threads spin at once - on the GPU boxes of this build
     // the container's CPU quota is 16 cores for 256 visible CPUs, and N ranks of an N-GPU node share whatever the node grants.
-    // With other proofs in flight the thread therefore SLEEPS on an event created with hipEventBlockingSync (the wake-up latency
-    // hides behind the other proofs).  APK_SYNC_BLOCKING: -1 by load (default), 0 never, 1 always.
+    // With other proofs in flight the thread therefore sleeps between polls of an event (the wake-up latency hides behind the
+    // other proofs).
     int wait_stream(Slot& s) {
-        static const int mode = env_int("APK_SYNC_BLOCKING", -1, -1, 1);
-        const bool blocking = mode > 0 || (mode < 0 && slots_.size() > 2 && gate_.busy() > 2);
-        if (blocking && s.ev_sync) {
+        // mode: -1 by load (default: sleep-and-poll with other proofs in flight, spin alone), 0 always spin, 1 hipEventSynchronize on a
+        // hipEventBlockingSync event, 2 always sleep-and-poll.
+        // Round 6: the "blocking" event wait of rounds 3-5 does NOT give the CPU back on this runtime - a loaded context burned one
+        // core per proof in flight (17.6 cores for 16 proofs: bench.py host_cpu_timed_region), i.e. the whole 16-CPU quota of the
+        // boxes, and with 32 proofs in flight (gangs) the cgroup froze the process for most of every period.  So with other proofs
+        // in flight the thread now polls the event and SLEEPS in between (the wake-up hides behind the other proofs).
+        static const int mode = env_int("APK_SYNC_BLOCKING", -1, -1, 2);
+        static const int poll_us = env_int("APK_SYNC_POLL_US", 50, 1, 10000);
+        const bool loaded = slots_.size() > 2 && gate_.busy() > 2;
+        if (s.ev_sync && (mode == 2 || (mode < 0 && loaded))) {
+            HIPCHK(hipEventRecord(s.ev_sync, s.stream));
+            for (;;) {
+                const hipError_t e = hipEventQuery(s.ev_sync);
+                if (e == hipSuccess) return APK_OK;
+                if (e != hipErrorNotReady) { (void)hipGetLastError(); set_error("hipEventQuery: %s", hipGetErrorString(e)); return APK_ERR_HIP; }
+                struct timespec ts = {0, (long)poll_us * 1000L};
+                nanosleep(&ts, nullptr);
+            }
+        }
+        if (mode == 1 && s.ev_sync) {
             HIPCHK(hipEventRecord(s.ev_sync, s.stream));
             HIPCHK(hipEventSynchronize(s.ev_sync));
             return APK_OK;
@@ -950,7 +1020,9 @@ class CurveBackend : public Backend {
             s.pending_pts = 0;
             return APK_OK;
         }
-        const Pt* g = reinterpret_cast<const Pt*>(reinterpret_cast<const uint8_t*>(s.h_pinned) + 1024);
+        // (a gang's merged batch left its sums in the LEAD's buffer; this proof's start at res_off)
+        const Slot& from = s.lead ? *s.lead : s;
+        const Pt* g = reinterpret_cast<const Pt*>(reinterpret_cast<const uint8_t*>(from.h_pinned) + PIN_XYZZ) + s.res_off;
         Aff* o = reinterpret_cast<Aff*>(s.h_pinned);
         // the batch's affine conversions share ONE field inversion (Montgomery's trick on the ZZZ coordinates; an inverse is
         // unique, so the bytes are those of XYZZ::to_affine point by point): 3 of 4 host inversions of ~5 us leave the gap between
@@ -970,14 +1042,14 @@ class CurveBackend : public Backend {
     }
 
     int alloc_slot(Slot& s) {
-        HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        s.lead = &s;
         HIPCHK(hipEventCreate(&s.ev0));
         HIPCHK(hipEventCreate(&s.ev1));
         HIPCHK(hipEventCreate(&s.ev2));
         HIPCHK(hipEventCreate(&s.ev3));
         if (hipEventCreateWithFlags(&s.ev_sync, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); s.ev_sync = nullptr; }
-        HIPCHK(hipHostMalloc(&s.h_pinned, 4096, hipHostMallocDefault));
-        memset(s.h_pinned, 0, 4096);   // (the tail-flag word is only ever written by a failing proof)
+        HIPCHK(hipHostMalloc(&s.h_pinned, PIN_BYTES, hipHostMallocDefault));
+        memset(s.h_pinned, 0, PIN_BYTES);   // (the tail-flag word is only ever written by a failing proof)
         // MSM sums and evaluations are a few hundred bytes behind a chain of kernels: the kernel that produces them writes them
         // straight into this (coherent, device-visible) host buffer instead of a device buffer + a copy launch - one launch less
         // per batch, and under load every launch of a proof's chain waits ~0.1 ms for its turn.  APK_ZERO_COPY=0: device buffer + copy.
@@ -1008,8 +1080,8 @@ class CurveBackend : public Backend {
         CHK(s.scratch_in.alloc(f4));
         CHK(s.tail_flag.alloc(16));
         HIPCHK(hipMemset(s.tail_flag.p, 0, 16));
-        CHK(s.ntt_wide.alloc((size_t)NTT_MAX_BATCH * n4_ * sizeof(FeU<FRP>)));
-        return alloc_msm_workspace(s, MSM_MAX_BATCH);
+        CHK(s.ntt_wide.alloc((size_t)NTT_MAX_BATCH * gang_cap_ * n4_ * sizeof(FeU<FRP>)));
+        return alloc_msm_workspace(s, ws_batch_);
     }
 
     // MSM workspace sized for `batch` MSMs over all bases
@@ -1052,10 +1124,10 @@ class CurveBackend : public Backend {
             CHK(s.rowcol.alloc((size_t)batch * (rows + cols) * sizeof(PtU)));
         }
         CHK(s.bit_partial.alloc((size_t)batch * 2 * 32 * sizeof(PtU)));
-        CHK(s.result.alloc(MSM_MAX_BATCH * sizeof(Aff)));
-        CHK(s.result_xyzz.alloc(MSM_MAX_BATCH * sizeof(Pt)));
-        CHK(s.done_count.alloc((MSM_MAX_BATCH + 1) * sizeof(uint32_t)));   // per MSM: bit sums done; + 1: scan workgroups done
-        HIPCHK(hipMemset(s.done_count.p, 0, (MSM_MAX_BATCH + 1) * sizeof(uint32_t)));
+        CHK(s.result.alloc(MSM_ARGS_MAX * sizeof(Aff)));
+        CHK(s.result_xyzz.alloc(MSM_ARGS_MAX * sizeof(Pt)));
+        CHK(s.done_count.alloc((MSM_ARGS_MAX + 1) * sizeof(uint32_t)));   // per MSM: bit sums done; + 1: scan workgroups done
+        HIPCHK(hipMemset(s.done_count.p, 0, (MSM_ARGS_MAX + 1) * sizeof(uint32_t)));
         return APK_OK;
     }
 
@@ -1063,10 +1135,11 @@ class CurveBackend : public Backend {
     int ensure_input_sets() {
         std::lock_guard<std::mutex> lk(mu_);
         if (!in_sets_.empty()) return APK_OK;
-        // as many sets again as proving slots (callers waiting for a slot have their upload in flight), at most 32
-        static const int sets_env = env_int("APK_INPUT_SETS", 0, 0, 64);
+        // as many sets again as proving slots (callers waiting for a slot have their upload in flight), at most 64 - the most
+        // callers a context proves for at a time (16 streams of four)
+        static const int sets_env = env_int("APK_INPUT_SETS", 0, 0, 128);
         size_t count = sets_env ? (size_t)sets_env : 2 * slots_.size();
-        if (count > 32 && !sets_env) count = 32;
+        if (count > 64 && !sets_env) count = 64;
         if (count < 1) count = 1;
         if (!copy_stream_) HIPCHK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
         std::vector<InputSet*> made;
@@ -1103,7 +1176,7 @@ class CurveBackend : public Backend {
         explicit InputGuard(CurveBackend* b_) : b(b_) {}
         int take() {
             CHK(b->ensure_input_sets());
-            set = b->in_sets_[b->in_gate_.acquire()];
+            set = b->in_sets_[b->in_gate_.acquire().slot];
             return APK_OK;
         }
         ~InputGuard() {
@@ -1114,11 +1187,123 @@ class CurveBackend : public Backend {
         }
     };
 
-    Slot* acquire() { return slots_[gate_.acquire()]; }
+    // ---- gangs (gang.h) ----------------------------------------------------------------------------------------------------------
+    static int choose_gang(int log_n, int nslots, int max_slots) {
+        const int env = env_int("APK_GANG", 0, 0, GANG_MAX);
+        if (nslots <= max_slots) return 1;            // every caller gets a stream of its own
+        if (env) return env;
+        // Same box, 32 / 64 persistent callers with distinct witnesses (tools/sweep_gangs.sh, profiles/r06_gang_sweep.txt), proofs/s
+        // alone -> gangs of 2 (32 callers) -> gangs of 4 (64 callers):
+        //   BN254 2^13  2 175 -> . -> 3 846     BN254 2^15  1 499 -> 1 763 -> 1 825     BLS12-381 2^14  1 376 -> 1 604 -> 1 746 .. 1 775
+        //   BN254 2^16    958 -> 1 033 -> 1 026   BN254 2^17  538 -> 539 (VALU-bound: nothing left for wider launches to fill)
+        return log_n <= 15 ? 4 : log_n == 16 ? 2 : 1;
+    }
+    static Slot*& gang_member() { static thread_local Slot* p = nullptr; return p; }
+    bool gangs_allowed() const {
+        static const int graphs = env_int("APK_MSM_GRAPH", 0, 0, 1);
+        return gang_cap_ > 1 && !hook_ && !wire_hook_ && !sc_.on() && !stats_on_ && !graphs;
+    }
+    // a proof's slot, alone or as a member of a gang
+    struct MemberGuard {
+        CurveBackend* b; Slot* s; bool ok = false;
+        explicit MemberGuard(CurveBackend* b_) : b(b_) {
+            const SlotGate::Ticket t = b->gate_.acquire_member(b->gangs_allowed());
+            s = b->slots_[t.slot];
+            Slot* lead = b->slots_[t.lead];
+            s->lead = lead; s->gang_idx = t.idx; s->in_gang = t.size > 1; s->res_off = 0;
+            if (lead == s) s->own_stream = b->stream_pool_[(size_t)t.stream];
+            s->stream = b->stream_pool_[(size_t)t.stream];
+            if (s->in_gang) { lead->gang.enter(t.gen, t.size); gang_member() = s; b->path(P_GANG_PROOFS); }
+        }
+        ~MemberGuard() {
+            if (s->in_gang) {
+                gang_member() = nullptr;
+                // an error return may leave this proof's launches in flight on the shared stream: nobody may get this workspace before them
+                if (!ok) (void)hipStreamSynchronize(s->stream);
+                Slot* lead = s->lead;
+                lead->gang.leave(s->gang_idx);
+                if (lead == s) lead->gang.wait_empty();       // the others run on this slot's stream and MSM workspace
+            }
+            s->lead = s; s->in_gang = false; s->res_off = 0;
+            b->release(s);
+        }
+    };
+    enum { GANG_KIND_MSM = 1, GANG_KIND_NTT = 2 };
+    struct MsmReq { Slot* member; const MsmTables* T; MsmBatchArgs a; };
+    struct NttReq {
+        Slot* member; int which; bool inverse; int count;
+        const Fr* ins[NTT_MAX_BATCH]; Fr* outs[NTT_MAX_BATCH]; uint32_t in_lens[NTT_MAX_BATCH];
+        uint32_t out_len; const Fr *pre, *post, *scale; int sub_log;
+        bool same_shape(const NttReq& o) const {
+            return which == o.which && inverse == o.inverse && out_len == o.out_len && pre == o.pre && post == o.post && scale == o.scale && sub_log == o.sub_log;
+        }
+    };
+    // The merged launches of one meeting (called once, by the last member to arrive): requests that can share a launch sequence
+    // do - MSM batches over the same table, transforms of the same shape - anything else goes by itself, in member order.
+    void gang_launch(GangReq* const* reqs, int count) {
+        bool done[GANG_MAX] = {false, false, false, false};
+        uint32_t res_base = 0;       // MSM sums of this meeting's launch sequences sit one behind the other in the lead's XYZZ area
+        for (int i = 0; i < count; i++) {
+            if (done[i]) continue;
+            if (reqs[i]->kind == GANG_KIND_MSM) {
+                MsmReq* first = static_cast<MsmReq*>(reqs[i]->args);
+                Slot& lead = *first->member->lead;
+                MsmBatchArgs c{};
+                int grp[GANG_MAX], ng = 0;
+                for (int j = i; j < count; j++) {
+                    if (done[j] || reqs[j]->kind != GANG_KIND_MSM) continue;
+                    MsmReq* m = static_cast<MsmReq*>(reqs[j]->args);
+                    if (m->T != first->T || c.batch + m->a.batch > ws_batch_) continue;
+                    m->member->res_off = res_base + c.batch;
+                    for (uint32_t b = 0; b < m->a.batch; b++) { c.scalars[c.batch] = m->a.scalars[b]; c.len[c.batch] = m->a.len[b]; c.offset[c.batch] = m->a.offset[b]; c.batch++; }
+                    grp[ng++] = j;
+                    done[j] = true;
+                }
+                const uint32_t lead_pending = lead.pending_pts;       // (run_msm counts the whole sequence as the workspace owner's)
+                lead.res_write_off = res_base;
+                const int rc = run_msm(lead, *first->T, c, nullptr);
+                lead.res_write_off = 0;
+                lead.pending_pts = lead_pending;
+                res_base += c.batch;
+                if (ng > 1) path(P_GANG_MSM);
+                for (int k = 0; k < ng; k++) {
+                    MsmReq* m = static_cast<MsmReq*>(reqs[grp[k]]->args);
+                    m->member->pending_pts = rc == APK_OK ? m->a.batch : 0;
+                    reqs[grp[k]]->rc = rc;
+                    if (rc != APK_OK) reqs[grp[k]]->err = apk_last_error();
+                }
+            } else {
+                NttReq* first = static_cast<NttReq*>(reqs[i]->args);
+                Slot& lead = *first->member->lead;
+                const Fr* ins[NTT_ARGS_MAX]; Fr* outs[NTT_ARGS_MAX]; uint32_t lens[NTT_ARGS_MAX];
+                int total = 0, grp[GANG_MAX], ng = 0;
+                for (int j = i; j < count; j++) {
+                    if (done[j] || reqs[j]->kind != GANG_KIND_NTT) continue;
+                    NttReq* m = static_cast<NttReq*>(reqs[j]->args);
+                    if (!m->same_shape(*first) || total + m->count > NTT_MAX_BATCH * gang_cap_) continue;
+                    for (int t = 0; t < m->count; t++) { ins[total] = m->ins[t]; outs[total] = m->outs[t]; lens[total] = m->in_lens[t]; total++; }
+                    grp[ng++] = j;
+                    done[j] = true;
+                }
+                const int rc = run_ntt_batch_now(lead.own_stream, first->which, first->inverse, total, ins, outs, lens, first->out_len, first->pre,
+                                                 first->post, first->scale, first->sub_log);
+                if (ng > 1) path(P_GANG_NTT);
+                for (int k = 0; k < ng; k++) { reqs[grp[k]]->rc = rc; if (rc != APK_OK) reqs[grp[k]]->err = apk_last_error(); }
+            }
+        }
+    }
+
+    Slot* acquire() {
+        const SlotGate::Ticket t = gate_.acquire();
+        Slot* s = slots_[t.slot];
+        s->own_stream = s->stream = stream_pool_[(size_t)t.stream];
+        return s;
+    }
     void release(Slot* s) {
-        // an error return between a side-stream launch and the next sync leaves transforms in flight: whoever gets the slot next
+        // an error return between a side-stream launch and the next sync leaves transforms in flight: whoever gets the STREAM next
         // is ordered behind them
-        if (s->side_pending) { s->side_pending = false; (void)hipStreamWaitEvent(s->stream, s->ev_side, 0); }
+        if (s->side_pending) { s->side_pending = false; if (s->own_stream) (void)hipStreamWaitEvent(s->own_stream, s->ev_side, 0); }
+        s->own_stream = s->stream = nullptr;      // (the workspace lookup by stream must only ever find the slot that holds it now)
         gate_.release(s->index);
     }
     struct SlotGuard {
@@ -1273,6 +1458,7 @@ class CurveBackend : public Backend {
         HIPCHK(hipSetDevice(device_));
         { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_) == hipSuccess && cus > 0) simds_ = 4u * (uint32_t)cus; }
         msm_only_ = true;
+        ws_batch_ = 1;             // (alloc_slot sizes an MSM-only context's workspace for one MSM at a time)
         msm_bases_ = (uint32_t)count;
         n_ = (uint32_t)count;
         int lg = 0;
@@ -1287,6 +1473,9 @@ class CurveBackend : public Backend {
         Slot* s = new Slot();
         s->index = slots_.size();
         slots_.push_back(s);
+        hipStream_t ps = nullptr;
+        HIPCHK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+        stream_pool_.push_back(ps);
         gate_.resize(slots_.size());
         CHK(alloc_slot(*s));
         return APK_OK;
@@ -1391,17 +1580,35 @@ class CurveBackend : public Backend {
         // more than 16 concurrently active streams collapse the throughput (24: -25 %, 32: -40 %, 48: -55 % at 2^17); callers
         // beyond the cap wait for a slot, which also hides their host-side gaps
         static const int max_slots = env_int("APK_MAX_SLOTS", 16, 1, 64);
-        if (nslots > max_slots) nslots = max_slots;
+        // Gangs: a context asked for more slots than it may run streams lets up to gang_cap_ proofs share a stream (gang.h).
+        // APK_GANG: 1 = never, 2..4 = members per stream; default by size (choose_gang).  The operands of a merged launch must fit
+        // the scan's 2^21 buckets and the sort's totals buffers.
+        gang_cap_ = choose_gang((int)log_n_, nslots, max_slots);
+        while (gang_cap_ > 1 && ((uint64_t)MSM_MAX_BATCH * gang_cap_ * NB_ > (1ull << 21) || MSM_MAX_BATCH * gang_cap_ > MSM_ARGS_MAX ||
+                                 (part_cfg_.P && (uint64_t)MSM_MAX_BATCH * gang_cap_ * part_cfg_.P > (uint64_t)MSM_MAX_BATCH * MSM_PART_MAX)))
+            gang_cap_--;
+        ws_batch_ = (uint32_t)(MSM_MAX_BATCH * gang_cap_);
+        const int max_streams = nslots > max_slots ? max_slots : nslots;
+        if (nslots > max_slots * gang_cap_) nslots = max_slots * gang_cap_;
         many_slots_ = nslots > 2;
+        for (int i = 0; i < max_streams; i++) {
+            hipStream_t ps = nullptr;
+            HIPCHK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+            stream_pool_.push_back(ps);
+        }
         for (int i = 0; i < nslots; i++) {
             Slot* s = new Slot();
             s->index = slots_.size();
             slots_.push_back(s);
             CHK(alloc_slot(*s));
         }
-        gate_.resize(slots_.size());
-        CHK(setup_trace(d));
-        return APK_OK;
+        static const int gang_wait_us = env_int("APK_GANG_WAIT_US", 300, 0, 100000);
+        gate_.configure(slots_.size(), (size_t)max_streams, gang_cap_, gang_wait_us);
+        gang_launcher_ = [this](GangReq* const* reqs, int count) { gang_launch(reqs, count); };
+        slots_[0]->own_stream = slots_[0]->stream = stream_pool_[0];      // (the trace setup runs on slot 0 before anybody can take it)
+        const int trc = setup_trace(d);
+        slots_[0]->own_stream = slots_[0]->stream = nullptr;
+        return trc;
     }
 
     static Fr root_of_unity() {
@@ -1476,7 +1683,7 @@ class CurveBackend : public Backend {
         }
         CHK(run_msm(s, T, a, reinterpret_cast<Aff*>(s.h_pinned)));
         CHK(wait_stream(s));
-        const Pt* gsum = reinterpret_cast<const Pt*>(reinterpret_cast<const uint8_t*>(s.h_pinned) + 1024);
+        const Pt* gsum = reinterpret_cast<const Pt*>(reinterpret_cast<const uint8_t*>(s.h_pinned) + PIN_XYZZ);
         for (uint32_t b = 0; b < count; b++) { const Aff r = gsum[b].to_affine(); memcpy(reinterpret_cast<uint8_t*>(out) + b * sizeof(Aff), &r, sizeof r); }
         s.pending_pts = 0;
         return APK_OK;
@@ -1490,7 +1697,7 @@ class CurveBackend : public Backend {
         if ((G != 2 && G != 4 && G != 8) || k < 0 || k >= G) { set_error("sub-coset split: rank %d of %d (2, 4 or 8 ranks)", k, G); return APK_ERR_ARG; }
         if (!qk_direct_) { set_error("sub-coset split needs Qk completed inside the quotient kernel (at most %d written rows)", QK_INJECT_MAX); return APK_ERR_STATE; }
         if ((n4_ >> (G == 2 ? 1 : G == 4 ? 2 : 3)) < 16u) { set_error("sub-coset split: the domain is too small"); return APK_ERR_STATE; }
-        for (Slot* s : slots_) if (s->stream) HIPCHK(hipStreamSynchronize(s->stream));
+        for (hipStream_t ps : stream_pool_) HIPCHK(hipStreamSynchronize(ps));
         const int glog = G == 2 ? 1 : G == 4 ? 2 : 3;
         const uint32_t m = n4_ >> glog;
         const Fr ru = fr_u64(32);   // x R -> x R'
@@ -1619,7 +1826,7 @@ class CurveBackend : public Backend {
         eval_partial_kernel<FRP><<<dim3(nblocks, ea.count), POLY_THREADS, 0, st>>>(ea, pw, nblocks, ptr<Fr>(s.eval_partial)); KCHK();
         // (h_out lies in the slot's pinned buffer: with the zero-copy view the kernel writes the values there itself)
         const bool direct = s.d_pinned && reinterpret_cast<uint8_t*>(h_out) >= reinterpret_cast<uint8_t*>(s.h_pinned) &&
-                            reinterpret_cast<uint8_t*>(h_out) + ea.count * sizeof(Fr) <= reinterpret_cast<uint8_t*>(s.h_pinned) + 4096;
+                            reinterpret_cast<uint8_t*>(h_out) + ea.count * sizeof(Fr) <= reinterpret_cast<uint8_t*>(s.h_pinned) + PIN_BYTES;
         Fr* const ev_out = direct ? reinterpret_cast<Fr*>(s.d_pinned + (reinterpret_cast<uint8_t*>(h_out) - reinterpret_cast<uint8_t*>(s.h_pinned))) : ptr<Fr>(s.eval_result);
         eval_final_kernel<FRP><<<ea.count, POLY_THREADS, 0, st>>>(ptr<Fr>(s.eval_partial), nblocks, ev_out); KCHK();
         if (!direct) HIPCHK(hipMemcpyAsync(h_out, s.eval_result.p, ea.count * sizeof(Fr), hipMemcpyDeviceToHost, st));
@@ -1787,14 +1994,14 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         }
         HIPCHK(hipEventRecord(in.set->ready, in.set->copy));
     }
-    SlotGuard guard(this);
+    MemberGuard guard(this);
     Slot& s = *guard.s;
     hipStream_t st = s.stream;
     const uint32_t n = n_;
     const Fr* bl = reinterpret_cast<const Fr*>(blinding);
     const Fr* pubv = reinterpret_cast<const Fr*>(pub);
     Aff* hp = reinterpret_cast<Aff*>(s.h_pinned);
-    Fr* hfr = reinterpret_cast<Fr*>(reinterpret_cast<uint8_t*>(s.h_pinned) + 2048);
+    Fr* hfr = reinterpret_cast<Fr*>(reinterpret_cast<uint8_t*>(s.h_pinned) + PIN_FR);
     memset(out, 0, sizeof *out);
     out->curve = CURVE_ID;
     out->nb_commitments = nb_commit_;
@@ -1838,7 +2045,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     // proof waits for its own count) are below 90 % of what uniform scalars have.  Never with a commit hook installed (the
     // multi-GPU schedules deal canonical batches).
     constexpr uint32_t DENSITY_UNKNOWN = 0xffffffffu;
-    volatile uint32_t* h_density = reinterpret_cast<volatile uint32_t*>(reinterpret_cast<uint8_t*>(s.h_pinned) + 3200);
+    volatile uint32_t* h_density = reinterpret_cast<volatile uint32_t*>(reinterpret_cast<uint8_t*>(s.h_pinned) + PIN_DENSITY);
     bool use_lag = false, measuring = false;
     if (lagrange_possible() && !hook_ && wires_lag_mode_ != 0) {
         const uint32_t seq = proof_seq_.fetch_add(1, std::memory_order_relaxed);
@@ -1974,7 +2181,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
             g.data[0], g.data[1]);
         KCHK();
         gp_scan_block_kernel<FRP><<<dim3(nb, 2), POLY_THREADS, 0, st>>>(g, n); KCHK();
-        Fr* const tot_out = s.d_pinned ? reinterpret_cast<Fr*>(s.d_pinned + 2048) : g.tot[1] + nb;     // hfr[0], from the device
+        Fr* const tot_out = s.d_pinned ? reinterpret_cast<Fr*>(s.d_pinned + PIN_FR) : g.tot[1] + nb;     // hfr[0], from the device
         gp_scan_totals_kernel<FRP><<<2, POLY_THREADS, 0, st>>>(g, nb, tot_out); KCHK();
         if (!s.d_pinned) HIPCHK(hipMemcpyAsync(hfr, g.tot[1] + nb, sizeof(Fr), hipMemcpyDeviceToHost, st));
         CHK(sync_results(s));
@@ -2077,13 +2284,14 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         const uint32_t tail4 = (n4_ - 3 * (n + 2)) * (uint32_t)(sizeof(Fr) / 16);
         tail_nonzero_kernel<0><<<cdiv(tail4, 256 * 8) < 512 ? cdiv(tail4, 256 * 8) : 512, 256, 0, st>>>(
             reinterpret_cast<const uint4*>(ptr<Fr>(s.hcan) + 3 * (size_t)(n + 2)), tail4, s.epoch,
-            s.d_pinned ? reinterpret_cast<uint32_t*>(s.d_pinned + 3072) : ptr<uint32_t>(s.tail_flag)); KCHK();
-        if (!s.d_pinned) HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(s.h_pinned) + 3072, s.tail_flag.p, 4, hipMemcpyDeviceToHost, st));
+            s.d_pinned ? reinterpret_cast<uint32_t*>(s.d_pinned + PIN_TAIL) : ptr<uint32_t>(s.tail_flag)); KCHK();
+        if (!s.d_pinned) HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(s.h_pinned) + PIN_TAIL, s.tail_flag.p, 4, hipMemcpyDeviceToHost, st));
     }
     CHK(sync_results(s));
-    if (*reinterpret_cast<const volatile uint32_t*>(reinterpret_cast<const uint8_t*>(s.h_pinned) + 3072) == s.epoch) {
+    if (*reinterpret_cast<const volatile uint32_t*>(reinterpret_cast<const uint8_t*>(s.h_pinned) + PIN_TAIL) == s.epoch) {
         set_error("quotient is not a polynomial: the witness does not satisfy the circuit");
         in.ok = true;      // (the stream was just drained: nothing of this proof is still reading its inputs)
+        guard.ok = true;
         return APK_ERR_WITNESS;
     }
     Aff hcom[3] = {hp[0], hp[1], hp[2]};
@@ -2292,6 +2500,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
     memcpy(out->zeta, &zeta, sizeof(Fr)); memcpy(out->gamma_kzg, &gk, sizeof(Fr));
     mark(3);
     in.ok = true;
+    guard.ok = true;
     path(P_PROOFS);
     if (stats_on_) {
         double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();

@@ -20,6 +20,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <string>
 
 namespace apk {
 
@@ -29,6 +30,7 @@ struct GangReq {
     int kind = 0;        // what kind of merge point this is (the launcher groups compatible requests)
     void* args = nullptr;
     int rc = 0;          // filled in by the launcher
+    std::string err;     // ... with its error message when rc != 0 (the launch ran on another member's thread)
     bool done = false;
 };
 
@@ -36,9 +38,12 @@ class Gang {
   public:
     using Launcher = std::function<void(GangReq* const* reqs, int count)>;
 
-    // (re)start with `n` members; called by the lead before any member can reach a merge point
-    void start(int n) {
+    // Every member calls this first, with the gate's ticket (SlotGate::Ticket gen / size): the first one in (re)starts the gang
+    // with `n` members, the others find it started.  A member that has entered may meet() at once: the launch waits for all n.
+    void enter(uint64_t gen, int n) {
         std::lock_guard<std::mutex> lk(mu_);
+        if (started_ && gen_ == gen) return;
+        started_ = true; gen_ = gen;
         members_ = n; arrived_ = 0; pending_ = nullptr;
         for (int i = 0; i < GANG_MAX; i++) req_[i] = nullptr;
     }
@@ -88,6 +93,8 @@ class Gang {
     std::mutex mu_;
     std::condition_variable cv_, cv_done_;
     int members_ = 0, arrived_ = 0;
+    bool started_ = false;
+    uint64_t gen_ = 0;
     GangReq* req_[GANG_MAX] = {nullptr, nullptr, nullptr, nullptr};
     const Launcher* pending_ = nullptr;
 };

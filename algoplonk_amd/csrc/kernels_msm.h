@@ -22,7 +22,9 @@
 
 namespace apk {
 
-constexpr int MSM_MAX_BATCH = 4;
+constexpr int MSM_MAX_BATCH = 4;        // MSMs per batch of ONE proof (its three wire / quotient commitments + one to spare)
+constexpr int MSM_ARGS_MAX = 16;        // MSMs per LAUNCH SEQUENCE: a gang of up to four proofs shares its launches (gang.h); what a
+                                        // workspace is sized for is the context's choice (backend_impl.h ws_batch_)
 constexpr int MSM_UNIT = 16;        // entries per full accumulation work unit; a run-time value in the kernels (APK_MSM_UNIT).
                                     // With the remainder units sorted, 2^17: 16 -> 360, 24 -> 357, 32 -> 349, 64 -> 328 proofs/s
                                     // (longer units quantise worse over the 1024 SIMDs and halve the lanes of a lone MSM)
@@ -51,9 +53,9 @@ struct MsmWindows {
 };
 
 struct MsmBatchArgs {
-    const void* scalars[MSM_MAX_BATCH];  // device, Fr Montgomery, len[b] elements
-    uint32_t len[MSM_MAX_BATCH];
-    uint32_t offset[MSM_MAX_BATCH];      // first base index used by msm b (bases [offset, offset+len))
+    const void* scalars[MSM_ARGS_MAX];   // device, Fr Montgomery, len[b] elements
+    uint32_t len[MSM_ARGS_MAX];
+    uint32_t offset[MSM_ARGS_MAX];       // first base index used by msm b (bases [offset, offset+len))
     uint32_t batch;
     uint32_t plain;                      // the table holds the bases themselves, not R^-1 * P: the sort leaves the Montgomery form first, so
                                          // that SMALL values have few non-zero digits (Lagrange-basis wire commitments: backend_impl.h)
@@ -680,7 +682,7 @@ template <int DUMMY>
 __global__ void __launch_bounds__(1024) msm_part_sort_runs_kernel(const uint32_t* __restrict__ tmp, uint32_t cap, const uint32_t* __restrict__ runtab,
                                                                 const uint32_t* __restrict__ ptot, uint32_t* __restrict__ ptot_next, MsmPartCfg pc,
                                                                 uint32_t G, uint32_t nb, uint32_t* __restrict__ hist, uint32_t* __restrict__ sorted,
-                                                                uint32_t tile_cap) {
+                                                                uint32_t tile_cap, uint32_t zero_words /* of ptot_next: the workspace's batch capacity x P */) {
     wave_priority<APK_PRIO_SORT>();
     __shared__ uint32_t cnt[MSM_PART_COUNTERS], cur[MSM_PART_COUNTERS];
     __shared__ uint32_t s_red[16];
@@ -703,7 +705,7 @@ __global__ void __launch_bounds__(1024) msm_part_sort_runs_kernel(const uint32_t
         if (t < NC) cnt[t] = 0u;
         __syncthreads();
         if (t == 0) { uint32_t f = 0; for (uint32_t w = 0; w < (blockDim.x >> 6); w++) f += s_red[w]; s_first = f; }
-        if (p == 0 && b == 0) for (uint32_t q = t; q < MSM_MAX_BATCH * P; q += blockDim.x) ptot_next[q] = 0u;
+        if (p == 0 && b == 0) for (uint32_t q = t; q < zero_words; q += blockDim.x) ptot_next[q] = 0u;
         __syncthreads();
     }
     const uint32_t first = s_first;

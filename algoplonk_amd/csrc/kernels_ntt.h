@@ -25,12 +25,13 @@ __device__ __forceinline__ uint32_t bitrev32(uint32_t x, int bits) { return __br
 
 // up to NTT_MAX_BATCH same-size transforms per launch (blockIdx.y): the three wire polynomials share launches,
 // which triples the workgroup count of these latency-bound small transforms
-constexpr int NTT_MAX_BATCH = 4;
+constexpr int NTT_MAX_BATCH = 4;     // ... of ONE proof
+constexpr int NTT_ARGS_MAX = 16;     // ... per launch: a gang of up to four proofs shares its launches (gang.h)
 struct NttBatch {
-    const void* in[NTT_MAX_BATCH];
-    void* out[NTT_MAX_BATCH];
-    uint32_t in_len[NTT_MAX_BATCH];  // elements >= in_len read as zero (first pass only)
-    void* wide[NTT_MAX_BATCH];       // N unsaturated-limb elements (36 B): what the passes hand to each other
+    const void* in[NTT_ARGS_MAX];
+    void* out[NTT_ARGS_MAX];
+    uint32_t in_len[NTT_ARGS_MAX];   // elements >= in_len read as zero (first pass only)
+    void* wide[NTT_ARGS_MAX];        // N unsaturated-limb elements (36 B): what the passes hand to each other
 };
 
 struct NttPassArgs {

@@ -581,6 +581,31 @@ def roofline_from_stats(args, cv, st, pmc, issue=None):
     return roofline
 
 
+def host_cpu_snapshot() -> dict:
+    """Process CPU time and the cgroup's throttling counters (cpu.stat): the GPU boxes grant 16 CPUs' worth of time per 100 ms
+    period to a process that sees 256 - a process that burns more is frozen, ALL of its threads, until the next period."""
+    t = os.times()
+    snap = {"user_s": t.user, "sys_s": t.system}
+    try:
+        for ln in open("/sys/fs/cgroup/cpu.stat"):
+            k, v = ln.split()
+            if k in ("nr_periods", "nr_throttled", "throttled_usec"):
+                snap[k] = int(v)
+    except Exception:
+        pass
+    return snap
+
+
+def host_cpu_delta(a: dict, b: dict, wall_s: float) -> dict:
+    d = {"cpu_s": round(b["user_s"] - a["user_s"] + b["sys_s"] - a["sys_s"], 3), "wall_s": round(wall_s, 3)}
+    d["cores_used"] = round(d["cpu_s"] / wall_s, 2) if wall_s > 0 else None
+    if "nr_throttled" in a and "nr_throttled" in b:
+        d["cgroup_periods"] = b["nr_periods"] - a["nr_periods"]
+        d["cgroup_periods_throttled"] = b["nr_throttled"] - a["nr_throttled"]
+        d["cgroup_throttled_ms"] = round((b["throttled_usec"] - a["throttled_usec"]) / 1e3, 1)
+    return d
+
+
 def proof_algorithmic_bytes(cv, log_n: int, nb_commit: int) -> dict:
     """SURVEY.md section 8d's per-proof algorithmic bytes (the contract's HBM yardstick), per curve and size: 10 KZG commitments of n
     (scalar, point) pairs; the GPU-natural transform schedule 12 iNTT_n + 12 coset-NTT_4n + 1 iNTT_4n at 64 B per element; one
@@ -680,7 +705,9 @@ def bench_prove(args, cv, rk) -> None:
     sha = lambda p: hashlib.sha256(MarshalProof(plonk.Proof(cv, p))).hexdigest()[:16]
 
     pk.paths(reset=True)
+    cpu0 = host_cpu_snapshot()
     elapsed = rk.timed_callers(one, args.inflight, args.steps, args.warmup, args.step_barrier)
+    host_cpu = host_cpu_delta(cpu0, host_cpu_snapshot(), elapsed)       # (includes the callers' warm-up proofs: a few percent)
     if errors:
         raise SystemExit("apk_prove failed: %r" % (errors[0],))
     total_proofs = args.steps * args.inflight * rk.world
@@ -851,6 +878,7 @@ def bench_prove(args, cv, rk) -> None:
             "env_knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("APK_") and k != "APK_COMM_TOKEN"},
             "msm_window": pk.msm_window,
             "paths_under_load": paths_loaded, "paths_lone_proof": paths_lone,
+            "host_cpu_timed_region": host_cpu,
             "proof_sha256_prefix": lone_hashes[0], "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line), flush=True)

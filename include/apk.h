@@ -441,7 +441,10 @@ typedef struct {
     uint64_t host_lincomb_pooled;       /* [lin] combinations of nearly idle contexts dealt to parked host threads (BLS12-381 by default; BN254 with APK_HOST_LINCOMB_THREADS > 1) */
     uint64_t msm_units_by_load;         /* MSM batches whose accumulate units were lengthened BECAUSE other proofs were in flight */
     uint64_t host_inputs;               /* proofs whose L, R, O came from host memory through a staging set (apk_prove) */
-    uint64_t reserved[6];
+    uint64_t gang_proofs;               /* proofs made as members of a gang (two to four proofs sharing one stream and its MSM / NTT launches) */
+    uint64_t gang_msm_launches;         /* MSM launch sequences that carried the batches of more than one proof */
+    uint64_t gang_ntt_launches;         /* NTT launch sequences that carried the transforms of more than one proof */
+    uint64_t reserved[3];
 } apk_path_counts;
 int apk_paths_read(apk_ctx* ctx, apk_path_counts* out, int reset);
 

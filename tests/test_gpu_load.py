@@ -184,3 +184,70 @@ def test_host_memory_entry_points(gpu):
     check(lib.apk_host_free(None))
     ws.close()
     pk.close()
+
+
+# ---- gangs (csrc/gang.h): two to four proofs per stream, their MSM / NTT batches in ONE launch sequence -----------------------------
+@pytest.mark.parametrize("cname,log_n,gang", [("bn254", 17, 2), ("bn254", 15, 4), ("bls12-381", 14, 4), ("bls12-381", 14, 3)])
+def test_ganged_proofs_match_the_c_oracle(gpu, cname, log_n, gang, monkeypatch):
+    """With more callers than streams a context pairs its callers up (APK_GANG members per stream): the members run the unchanged
+    prover in lockstep on one stream and meet at every commitment batch and transform batch, where ONE launch sequence carries all
+    their operands.  Same kernels, same arithmetic: every blob must still be the C oracle's proof of its OWN inputs - here with
+    distinct assignments in the members of a gang, so a member reading its neighbour's sums out of the shared result area, or a
+    merged launch mixing operands up, cannot hide - and the counters must show that merged launches made them.  From device and
+    from host memory; one caller keeps handing in an unsatisfying witness and LEAVES its gang in round 3 every time."""
+    cv, ov = CURVES[cname]
+    seed = 0x6A06 + log_n
+    monkeypatch.setenv("APK_GANG", str(gang))
+    wl = workloads.random_circuit(cv, log_n, seed)
+    n = wl.ccs.domain_size()
+    srs = ap_setup.unsafe_srs(cv, n, wl.tau, device=gpu)
+    T, K, rounds = 16 * gang, 7, 3
+    pk, vk = ap_plonk.Setup(wl.ccs, srs, device=gpu, slots=T)
+    ws = batch.WitnessSet(pk, wl.ccs, workloads.variants(wl, K + 1, seed)).to_device().to_pinned(gpu)
+    ws.corrupt(K)
+    want = oracle_blobs(cv, wl.ccs, srs, ws.items[:K], threads=oracle_threads())
+    assert len(set(want)) == K
+    for where in ("device", "pinned"):
+        pk.paths(reset=True)
+        pick = lambda i, r: K if i == 3 else (i + 2 * r) % K
+        got, errors = _run_callers(ws, T, rounds, where, pick, expect_error={K: _lib.APK_ERR_WITNESS})
+        assert not errors, errors[0]
+        assert sum(got.values()) == (T - 1) * rounds
+        _assert_every_blob_is_its_own_oracle_proof(got, want, "gangs of %d, %s inputs" % (gang, where))
+        p = pk.paths(reset=True)
+        assert p["proofs"] == (T - 1) * rounds
+        assert p["gang_proofs"] >= p["proofs"] // 2, p                      # most proofs were made as gang members ...
+        assert p["gang_msm_launches"] >= 1 and p["gang_ntt_launches"] >= 1, p
+        assert p["msm_batches"] < 4 * p["proofs"], p                        # ... in fewer launch sequences than four per proof
+    # alone on the same context: no gang, the latency forms, the same bytes
+    pr = _lib.Proof()
+    for a in range(K):
+        check(ws.prove(a, pr, "device"))
+        assert _marshal(pr) == want[a]
+    alone = pk.paths(reset=True)
+    assert alone["gang_proofs"] == 0 and alone["proofs"] == K, alone
+    ws.close()
+    pk.close()
+
+
+def test_ganged_bsb22_proofs(gpu, monkeypatch):
+    """Gangs on a circuit with a BSB22 commitment: the Lagrange-basis commitment of every member's own committed column is a merge
+    point too (one launch over the Lagrange table for the gang), ahead of the canonical-basis batches."""
+    cv, ov = CURVES["bn254"]
+    monkeypatch.setenv("APK_GANG", "2")
+    seed, log_n = 0xA193, 14
+    ccs, w, bl, tau = workloads.random_circuit_bsb22(cv, log_n, seed, nb_commitments=1)
+    srs = ap_setup.unsafe_srs(cv, ccs.domain_size(), tau, device=gpu, lagrange=True)
+    T, K, rounds = 32, 4, 3
+    pk, vk = ap_plonk.Setup(ccs, srs, device=gpu, slots=T)
+    vs = [workloads.Variant(w, bl, None, [(0xA193, 0x3910A)])] + workloads.variant_inputs(ccs, K - 1, seed)
+    ws = batch.WitnessSet(pk, ccs, vs).to_device()
+    want = oracle_blobs(cv, ccs, srs, ws.items, threads=oracle_threads())
+    pk.paths(reset=True)
+    got, errors = _run_callers(ws, T, rounds, "device", lambda i, r: (i + r) % K)
+    assert not errors, errors[0]
+    _assert_every_blob_is_its_own_oracle_proof(got, want, "BSB22 in gangs of 2")
+    p = pk.paths(reset=True)
+    assert p["gang_proofs"] >= p["proofs"] // 2 and p["gang_msm_launches"] >= 1, p
+    ws.close()
+    pk.close()

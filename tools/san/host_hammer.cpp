@@ -2,18 +2,24 @@
 // many threads under -fsanitize=thread (or address).  Built and run by `make -C algoplonk_amd/csrc SAN=thread san-check`
 // (tests/test_sanitizers.py runs it in the CPU tier).  What runs here is the library's own code, not a model of it:
 //   * SlotGate (slot_gate.h)   - 32 callers on 4 / 16 slots: every slot has one owner at a time, the busy count is never torn
+//   * SlotGate + Gang (gang.h) - 48 callers on 32 slots / 8 streams in gangs of up to 2 / 4: never more streams than allowed, every
+//     member of a gang sees the same size, every meeting launches exactly once with every member's request, members that leave
+//     early (one in five) never strand the others, a lead outlives its followers
 //   * HostPool + host_lincomb (host_msm.h) - the [lin] combination on the context's parked threads, 32 callers racing for the pool;
 //     every result must be the single-threaded one
 // Exit code 0 = no mismatch (the sanitizer reports races on its own and fails the run through TSAN_OPTIONS=halt_on_error=1).
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include <vector>
 
 #include "../../algoplonk_amd/csrc/ff_params.h"
 #include "../../algoplonk_amd/csrc/host_msm.h"
 #include "../../algoplonk_amd/csrc/slot_gate.h"
+#include "../../algoplonk_amd/csrc/gang.h"
 
 using namespace apk;
 
@@ -92,7 +98,9 @@ static int hammer_lincomb(const char* name, const uint32_t* gx, const uint32_t* 
 }
 
 static int hammer_gate(int slots) {
-    SlotGate gate;
+    // (on the heap: std::mutex has no destructor the sanitizer sees, and a later gate at the same STACK address would inherit this one's lock history)
+    std::unique_ptr<SlotGate> gate_p(new SlotGate());
+    SlotGate& gate = *gate_p;
     gate.resize((size_t)slots);
     std::vector<std::atomic<int>> owner((size_t)slots);
     for (auto& o : owner) o = 0;
@@ -101,7 +109,7 @@ static int hammer_gate(int slots) {
     for (int t = 0; t < 32; t++)
         th.emplace_back([&, t] {
             for (int r = 0; r < 400; r++) {
-                const size_t i = gate.acquire();
+                const size_t i = gate.acquire().slot;
                 if (owner[i].fetch_add(1) != 0) bad++;          // two owners of one slot
                 const int b = gate.busy();
                 if (b < 1 || b > slots) bad++;
@@ -116,10 +124,70 @@ static int hammer_gate(int slots) {
     return bad.load();
 }
 
+// the prover's use of the gate and the gang, with counters in place of launches
+static int hammer_gangs(int gang_max) {
+    constexpr int SLOTS = 32, STREAMS = 8, CALLERS = 48, ROUNDS = 150, MEETINGS = 6;
+    std::unique_ptr<SlotGate> gate_p(new SlotGate());
+    SlotGate& gate = *gate_p;
+    gate.configure(SLOTS, STREAMS, gang_max, 200);
+    std::vector<Gang> gangs(SLOTS);
+    std::vector<std::atomic<int>> owner(SLOTS);
+    for (auto& o : owner) o = 0;
+    std::vector<std::atomic<int>> stream_owner(STREAMS);
+    for (auto& o : stream_owner) o = 0;
+    std::atomic<int> bad{0}, ganged{0}, launches{0}, served{0}, posted{0};
+    struct Args { int member; int value; int out; };
+    const Gang::Launcher launcher = [&](GangReq* const* reqs, int count) {
+        launches++;
+        int sum = 0;
+        for (int i = 0; i < count; i++) sum += static_cast<Args*>(reqs[i]->args)->value;
+        for (int i = 0; i < count; i++) { static_cast<Args*>(reqs[i]->args)->out = sum; reqs[i]->rc = count; served++; }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < CALLERS; t++)
+        th.emplace_back([&, t] {
+            for (int r = 0; r < ROUNDS; r++) {
+                const SlotGate::Ticket tk = gate.acquire_member((r + t) % 9 != 0);       // now and then a caller that must not be ganged
+                if (owner[tk.slot].fetch_add(1) != 0) bad++;
+                if (gate.streams() > STREAMS || tk.stream < 0 || tk.stream >= STREAMS) bad++;
+                if (tk.lead == tk.slot && stream_owner[tk.stream].fetch_add(1) != 0) bad++;      // two gangs on one stream
+                if (tk.size < 1 || tk.size > gang_max || tk.idx < 0 || tk.idx >= tk.size || (tk.size == 1 && tk.lead != tk.slot)) bad++;
+                if (tk.size > 1) {
+                    ganged++;
+                    Gang& g = gangs[tk.lead];
+                    g.enter(tk.gen, tk.size);
+                    const int quit_at = (t * 7 + r) % 5 == 0 ? (t + r) % MEETINGS : MEETINGS;     // one in five leaves early
+                    for (int m = 0; m < quit_at; m++) {
+                        Args a{tk.idx, 1 << tk.idx, 0};
+                        GangReq q;
+                        q.kind = 1; q.args = &a;
+                        posted++;
+                        const int rc = g.meet(tk.idx, q, launcher);
+                        if (rc < 1 || rc > tk.size || !(a.out & (1 << tk.idx))) bad++;         // launched with at least this member's request
+                    }
+                    g.leave(tk.idx);
+                    if (tk.lead == tk.slot) g.wait_empty();
+                } else std::this_thread::sleep_for(std::chrono::microseconds(100));     // a lone "proof" takes a while too: 48 callers crowd 8 streams
+                owner[tk.slot].fetch_sub(1);
+                if (tk.lead == tk.slot) stream_owner[tk.stream].fetch_sub(1);
+                gate.release(tk.slot);
+            }
+        });
+    for (auto& t : th) t.join();
+    if (gate.busy() != 0 || gate.streams() != 0) bad++;
+    if (served.load() != posted.load()) bad++;                                                     // every request was served exactly once
+    printf("gate + gangs of up to %d: %d callers x %d rounds on %d slots / %d streams, %d ganged proofs, %d requests in %d launches, %d violations\n",
+           gang_max, CALLERS, ROUNDS, SLOTS, STREAMS, ganged.load(), posted.load(), launches.load(), bad.load());
+    if (ganged.load() == 0) { printf("no gang ever formed\n"); return 1; }
+    return bad.load();
+}
+
 int main() {
     int bad = 0;
     bad += hammer_gate(4);
     bad += hammer_gate(16);
+    bad += hammer_gangs(2);
+    bad += hammer_gangs(4);
     // generators: BN254 (1, 2); BLS12-381 G1 generator (canonical little-endian 32-bit words)
     static const uint32_t bn_x[8] = {1, 0, 0, 0, 0, 0, 0, 0}, bn_y[8] = {2, 0, 0, 0, 0, 0, 0, 0};
     static const uint32_t bls_x[12] = {0xdb22c6bb, 0xfb3af00a, 0xf97a1aef, 0x6c55e83f, 0x171bac58, 0xa14e3a3f, 0x9774b905, 0xc3688c4f,

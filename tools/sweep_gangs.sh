@@ -1,0 +1,26 @@
+mkdir -p gpurun_out/r6d
+run() { # curve logn gang inflight
+  env APK_GANG=$3 $5 python bench.py --curve $1 --log-n $2 --inflight $4 --steps 20 --warmup 3 --no-pmc --no-cpu-baseline --no-host-inputs --no-oracle-check > gpurun_out/r6d/b_$1_$2_g$3_i$4.json 2> gpurun_out/r6d/err.txt || tail -3 gpurun_out/r6d/err.txt
+  python - <<PY
+import json
+d=json.load(open("gpurun_out/r6d/b_$1_$2_g$3_i$4.json"))
+p=d["paths_under_load"]
+print("$1 2^$2 gang=$3 inflight=$4 $5: %.1f proofs/s  lone %.3f ms  gang_proofs %d/%d msm_batches %d ok=%s cpu=%s" % (d["value"], d["proof_latency_ms"], p["gang_proofs"], p["proofs"], p["msm_batches"], d["proofs_under_load_match_lone_proofs"], d.get("host_cpu_timed_region")))
+PY
+}
+run bls12_381 14 1 32 APK_SYNC_POLL_US=10
+run bls12_381 14 1 32 APK_SYNC_POLL_US=20
+run bls12_381 14 1 32 APK_SYNC_POLL_US=100
+run bls12_381 14 4 64 APK_SYNC_POLL_US=10
+run bls12_381 14 4 64 APK_SYNC_POLL_US=20
+run bls12_381 14 4 64 APK_SYNC_POLL_US=100
+run bn254 17 1 32 APK_SYNC_POLL_US=20
+run bn254 17 2 32 APK_SYNC_POLL_US=20
+run bn254 15 1 32
+run bn254 15 2 32
+run bn254 15 4 64
+run bn254 16 1 32
+run bn254 16 2 32
+run bn254 16 4 64
+run bn254 13 1 32
+run bn254 13 4 64
