@@ -248,15 +248,18 @@ def _run(target, world, extra_ports=1):
     assert sorted(res) == [(r, "ok") for r in range(world)], res
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_msm_over_the_c_communicator(world):
-    """BASELINE.json configs[3]: ONE MSM split by index range, one all-gather of a point per rank, local additions."""
+    """BASELINE.json configs[3]: ONE MSM split by index range, one all-gather of a point per rank, local additions.
+    World 8 = the node the driver's scaling run uses: eight processes exist here for the first time, not on the hardware."""
     _run(_sharded_worker, world)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_split_proof_schedule_over_the_c_communicator(world):
-    """commitment batches dealt by index range + wires dealt by polynomial; leader / worker loop."""
+    """commitment batches dealt by index range + wires dealt by polynomial; leader / worker loop; the
+    replicated prover's local commitments and the sub-coset split's all-gather (prove-split and prove-spmd of bench.py).  At
+    world 8 five ranks get no wire and, in the batches of five to eleven scalars, some ranks an empty share."""
     _run(_split_worker, world)
 
 

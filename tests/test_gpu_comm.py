@@ -119,24 +119,29 @@ def test_split_proof_and_sharded_msm_between_processes_sharing_the_gpu(gpu, cnam
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,extra", [("prove-split", ["--curve", "bls12_381", "--log-n", "12"]), ("msm-sharded", ["--log-n", "12"]),
-                                        ("prove-spmd", ["--curve", "bls12_381", "--log-n", "12"]),
-                                        ("prove", ["--log-n", "12", "--inflight", "2"])])
-def test_bench_py_runs_its_multi_rank_modes_under_the_contract_launcher(gpu, mode, extra):
-    """`python bench.py --gpus 2 ...` re-executes itself under torch.distributed.run (the contract's command line), the two ranks
-    rendezvous on libapk's communicator and rank 0 prints ONE JSON line with n_gpus = 2.  Functional only: both ranks share the
+@pytest.mark.parametrize("mode,extra,gpus", [("prove-split", ["--curve", "bls12_381", "--log-n", "12"], 2), ("msm-sharded", ["--log-n", "12"], 2),
+                                             ("prove-spmd", ["--curve", "bls12_381", "--log-n", "12"], 2),
+                                             ("prove", ["--log-n", "12", "--inflight", "2"], 2),
+                                             # the world the driver's scaling run uses: EIGHT ranks exist here first (sharing the one GPU
+                                             # over HIP IPC), so that the first real 8-GPU run exercises nothing but RCCL itself
+                                             ("msm-sharded", ["--log-n", "12"], 8), ("prove-split", ["--log-n", "12"], 8),
+                                             ("prove-spmd", ["--curve", "bls12_381", "--log-n", "12"], 8),
+                                             ("prove", ["--log-n", "12", "--inflight", "2"], 8)])
+def test_bench_py_runs_its_multi_rank_modes_under_the_contract_launcher(gpu, mode, extra, gpus):
+    """`python bench.py --gpus N ...` re-executes itself under torch.distributed.run (the contract's command line), the N ranks
+    rendezvous on libapk's communicator and rank 0 prints ONE JSON line with n_gpus = N.  Functional only: the ranks share the
     box's one GPU (APK_BENCH_SHARE_GPU=1), so the numbers mean nothing."""
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["APK_BENCH_SHARE_GPU"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", mode, "--steps", "3", "--warmup", "1",
-                        "--no-pmc", "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--mode", mode, "--steps", "3", "--warmup", "1",
+                        "--no-pmc", "--no-cpu-baseline", "--no-oracle-check", "--no-host-inputs"] + extra, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     line = lines[0]
-    assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["steps"] == 3
+    assert line["n_gpus"] == gpus and line["config"]["world_size"] == gpus and line["steps"] == 3
     if mode in ("prove-split", "prove-spmd"):
         assert line["matches_single_gpu_proof"] is True and line["scaling"] == "strong"
     if mode == "prove":
@@ -149,6 +154,7 @@ def test_bench_py_runs_its_multi_rank_modes_under_the_contract_launcher(gpu, mod
     if mode == "prove-spmd":
         ph = line["phase_ms_per_proof_rank0"]
         assert ph["msm_ms"] > 0 and ph["sums_exchange_ms"] > 0 and ph["commit_rounds_per_proof"] == 4.0 and ph["non_msm_ms"] > 0, ph
+        assert ph["subcoset_split"] is True and ph["subcoset_gather_ms"] > 0, ph        # round 3 on sub-cosets at world 2 and world 8
 
 
 @pytest.mark.gpu
@@ -260,6 +266,34 @@ def test_subcoset_split_of_round_3_is_byte_identical(gpu, cname, G, log_n, bsb):
     assert MarshalProof(ap_plonk.Prove(ccs, pks[1], w, bl, **kw)) == plain
     for pk in pks:
         pk.close()
+
+
+@pytest.mark.gpu
+def test_a_communicator_outlives_its_context(gpu):
+    """a host with finalizers may destroy the context BEFORE the communicator that installed hooks on it (Python's
+    teardown order, a Go finalizer).  apk_comm_destroy / apk_comm_bind then find the context gone in libapk's registry of live
+    contexts and forget it instead of calling into freed memory; the communicator's device buffers go back to the runtime."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from algoplonk_amd import parallel, plonk as ap_plonk, setup as ap_setup, MarshalProof
+    from helpers import CURVES, blinding, random_chain_ccs
+    from oracle.prng import tau_from_seed
+    cv, ov = CURVES["bn254"]
+    ccs, w, sol = random_chain_ccs(cv, 8, 3)
+    srs = ap_setup.unsafe_srs(cv, ccs.domain_size(), tau_from_seed(4, cv.r), device=gpu)
+    for how in ("destroy", "rebind"):
+        pk, vk = ap_plonk.Setup(ccs, srs, device=gpu)
+        comm = parallel.Comm(0, 1)
+        comm.bind(pk.ctx)
+        comm.spmd_begin()
+        assert len(MarshalProof(ap_plonk.Prove(ccs, pk, w, blinding(cv, 2)))) == 768
+        pk.close()                                # the context goes first, hooks and all
+        if how == "rebind":
+            pk2, _ = ap_plonk.Setup(ccs, srs, device=gpu)
+            comm.bind(pk2.ctx)                    # must not touch the dead context
+            assert len(MarshalProof(ap_plonk.Prove(ccs, pk2, w, blinding(cv, 2)))) == 768
+            comm.bind(None)
+            pk2.close()
+        comm.close()
 
 
 @pytest.mark.gpu

@@ -337,6 +337,36 @@ def test_msm_only_context_and_index_range_sharding(gpu, cname):
     assert cv.g1_from_bytes(acc) == ov.mul(ov.g1, oplonk.poly_eval(scalars, tau, cv.r))
 
 
+def test_config_3_as_stated_eight_index_ranges_of_2p14(gpu):
+    """BASELINE.json configs[3] exactly as written - "BN254 2^17 constraints, single MSM sharded across 8" - on the one GPU of this
+    tier: seed 0xA192 (uniform scalars, SRS-shaped points [tau^i]G1, tau = SHA-256(seed) mod r), EIGHT MSM-only
+    contexts over the eight 2^14-point index ranges (what the eight ranks of bench.py --mode msm-sharded each hold), the eight
+    partial sums added with apk_g1_sum (the local half of the one exchange step) - and the result must be the C oracle's orc_msm
+    over all 2^17 pairs, byte for byte."""
+    from algoplonk_amd import parallel
+    from oracle import c_oracle
+    cv, ov = CURVES["bn254"]
+    n, world = 1 << 17, 8
+    g = SplitMix64(0xA192)
+    tau = tau_from_seed(0xA192, cv.r)
+    srs = ap_setup.unsafe_srs(cv, n, tau, device=gpu)
+    nb = 2 * cv.fp_bytes
+    bases = srs.g1[: n * nb]
+    sc_bytes = cv.fr_vector([g.fr(cv.r) for _ in range(n)])
+    want = C.create_string_buffer(nb)
+    assert c_oracle.load().orc_msm(cv.abi, bases, sc_bytes, n, oracle_threads(), want) == 0
+    partial = b""
+    for rank in range(world):
+        sm = parallel.ShardedMsm(cv, bases, device=gpu, comm=parallel.Comm(0, 1), share=(rank, world))
+        assert (sm.lo, sm.hi) == (rank << 14, (rank + 1) << 14)
+        sm.upload(sc_bytes)
+        partial += sm.run()
+        sm.close()
+    got = C.create_string_buffer(nb)
+    check(lib.apk_g1_sum(cv.abi, partial, world, got))
+    assert got.raw == want.raw
+
+
 @pytest.mark.parametrize("cname", ["bn254", "bls12-381"])
 def test_msm_over_degenerate_bases_hits_the_doubling_and_cancellation_paths(gpu, cname):
     """SRS-shaped bases from tau = 1, -1 and a 4th root of unity repeat the same few points (and their negatives), so a
