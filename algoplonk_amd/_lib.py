@@ -108,8 +108,8 @@ class PathCounts(C.Structure):
     _names = ["proofs", "msm_batches", "msm_sort_two_level", "msm_sort_two_level_by_load", "msm_sort_fused", "msm_lean_tail",
               "msm_rowcol_serial", "msm_combine_quad", "msm_small_units", "msm_one_launch", "msm_lagrange_wires", "ntt_sequences",
               "ntt_radix4", "ntt_radix4_by_load", "tail_fill_proofs", "host_lincomb_pooled", "msm_units_by_load", "host_inputs",
-              "gang_proofs", "gang_msm_launches", "gang_ntt_launches"]
-    _fields_ = [(n, C.c_uint64) for n in _names] + [("reserved", C.c_uint64 * 3)]
+              "gang_proofs", "gang_msm_launches", "gang_ntt_launches", "gang_kernel_launches"]
+    _fields_ = [(n, C.c_uint64) for n in _names] + [("reserved", C.c_uint64 * 2)]
 
     def as_dict(self) -> dict:
         return {n: int(getattr(self, n)) for n in self._names}

@@ -16,6 +16,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <memory>
+#include <new>
 #include <mutex>
 #include <string.h>
 #include <time.h>
@@ -25,6 +26,7 @@
 #include "kernels_msm.h"
 #include "kernels_ntt.h"
 #include "kernels_poly.h"
+#include "gang_kernel.h"
 #include "kernels_setup.h"
 #include "host_msm.h"
 #include "slot_gate.h"
@@ -142,6 +144,14 @@ class CurveBackend : public Backend {
         const void* table; MsmBatchArgs a;
         bool operator==(const GraphKey& o) const { return table == o.table && memcmp(&a, &o.a, sizeof a) == 0; }
     };
+    // a recorded launch of a gang member (klaunch / flush_cmds below)
+    static constexpr size_t CMD_BLOB = 1024;
+    struct Cmd {
+        dim3 grid, block;
+        uint32_t lds = 0;
+        int (*multi)(hipStream_t, const Cmd* const*, int) = nullptr;   // launches this kernel for `count` recorded instances
+        alignas(16) unsigned char blob[CMD_BLOB];                       // Pack<P...>: the instance's arguments
+    };
     struct Slot {
         hipStream_t stream = nullptr;      // the stream this slot's launches go to: its own, or - as a gang member - its lead's
         hipStream_t own_stream = nullptr;  // one of the context's stream_pool_, held while this slot leads a gang or proves alone (not owned)
@@ -152,6 +162,7 @@ class CurveBackend : public Backend {
         uint32_t res_off = 0;              // first point of this proof's pending MSM sums in the lead's XYZZ area
         uint32_t res_write_off = 0;        // (as a lead) where the launch sequence being queued writes its sums in that area
         Gang gang;                         // used when this slot leads
+        std::vector<Cmd> cmds;             // launches recorded since the last merge point (as a gang member)
         hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
         size_t index = 0;          // position in slots_ = the slot's number at the gate
         // polynomials
@@ -289,7 +300,7 @@ class CurveBackend : public Backend {
     } sc_;
     // which forms the load-dependent choices took (apk_paths_read): always counted, relaxed atomics
     enum PathIdx { P_PROOFS, P_MSM_BATCHES, P_SORT2, P_SORT2_LOAD, P_SORT_FUSED, P_LEAN_TAIL, P_ROWCOL_SERIAL, P_COMBINE_QUAD, P_SMALL_UNITS,
-                   P_ONE_LAUNCH, P_LAGRANGE_WIRES, P_NTT_SEQ, P_NTT_R4, P_NTT_R4_LOAD, P_TAIL_FILL, P_LINCOMB_POOL, P_UNIT_LOADED, P_HOST_INPUTS, P_GANG_PROOFS, P_GANG_MSM, P_GANG_NTT, P_COUNT };
+                   P_ONE_LAUNCH, P_LAGRANGE_WIRES, P_NTT_SEQ, P_NTT_R4, P_NTT_R4_LOAD, P_TAIL_FILL, P_LINCOMB_POOL, P_UNIT_LOADED, P_HOST_INPUTS, P_GANG_PROOFS, P_GANG_MSM, P_GANG_NTT, P_GANG_KERNELS, P_COUNT };
     std::atomic<uint64_t> paths_[P_COUNT] = {};
     void path(PathIdx i) { paths_[i].fetch_add(1, std::memory_order_relaxed); }
     int paths_read(apk_path_counts* out, int reset) override {
@@ -342,7 +353,7 @@ class CurveBackend : public Backend {
             for (int i = 0; i < count; i++) { nr.ins[i] = ins[i]; nr.outs[i] = outs[i]; nr.in_lens[i] = in_lens[i]; }
             nr.out_len = out_len; nr.pre = pre; nr.post = post; nr.scale = scale; nr.sub_log = sub_log;
             GangReq r;
-            r.kind = GANG_KIND_NTT; r.args = &nr;
+            r.kind = GANG_KIND_NTT; r.args = &nr; r.member = m;
             const int rc = m->lead->gang.meet(m->gang_idx, r, gang_launcher_);
             if (rc != APK_OK) set_error("%s", r.err.c_str());
             return rc;
@@ -926,7 +937,7 @@ class CurveBackend : public Backend {
         if (!hook_ && s.in_gang) {      // a merge point of the gang: ONE launch sequence for every member's batch (gang_launch)
             MsmReq mr{&s, &T, a};
             GangReq r;
-            r.kind = GANG_KIND_MSM; r.args = &mr;
+            r.kind = GANG_KIND_MSM; r.args = &mr; r.member = &s;
             const int rc = s.lead->gang.meet(s.gang_idx, r, gang_launcher_);
             if (rc != APK_OK) set_error("%s", r.err.c_str());     // (the launch ran on another member's thread)
             return rc;
@@ -1002,6 +1013,12 @@ class CurveBackend : public Backend {
     }
 
     int sync_results(Slot& s) {
+        if (s.in_gang) {     // the launches this member recorded since its last merge point go out now, with the other members'
+            GangReq r;
+            r.kind = GANG_KIND_FLUSH; r.member = &s;
+            const int rc = s.lead->gang.meet(s.gang_idx, r, gang_launcher_);
+            if (rc != APK_OK) { set_error("%s", r.err.c_str()); return rc; }
+        }
         CHK(wait_stream(s));
         // whatever the main stream is handed from here on runs behind the side stream's transforms
         if (s.side_pending) { s.side_pending = false; HIPCHK(hipStreamWaitEvent(s.stream, s.ev_side, 0)); }
@@ -1187,6 +1204,80 @@ class CurveBackend : public Backend {
         }
     };
 
+    // ---- deferred launches of a gang member (gang_kernel.h) -----------------------------------------------------------------------
+    // Every element-wise / scan / reduction kernel of the prover goes through klaunch().  Alone, it is an ordinary launch.  As a
+    // gang member (with the zero-copy result buffer: nothing but kernels then touches the stream between two merge points) it is
+    // RECORDED - grid, block, the arguments by value - and launched at the member's next merge point or stream wait, together with
+    // the same kernel of the other members: ONE launch, blockIdx.z = member.
+    template <class K, int BOUNDS, class... P>
+    static int launch_multi(hipStream_t st, const Cmd* const* cmds, int count) {
+        static_assert(sizeof(Pack<P...>) <= CMD_BLOB, "kernel arguments exceed a recorded launch's blob");
+        static_assert(sizeof(GangPack<P...>) <= 4096, "a gang's arguments exceed the kernel argument segment");
+        if (count == 1) {
+            const Pack<P...>& one = *reinterpret_cast<const Pack<P...>*>(cmds[0]->blob);
+            GangPack<P...> g{};
+            g.m[0] = one;
+            polyG_kernel<K, BOUNDS, P...><<<cmds[0]->grid, cmds[0]->block, cmds[0]->lds, st>>>(g);
+            KCHK();
+            return APK_OK;
+        }
+        GangPack<P...> g{};
+        for (int i = 0; i < count; i++) g.m[i] = *reinterpret_cast<const Pack<P...>*>(cmds[i]->blob);
+        dim3 grid = cmds[0]->grid;
+        grid.z = (uint32_t)count;
+        polyG_kernel<K, BOUNDS, P...><<<grid, cmds[0]->block, cmds[0]->lds, st>>>(g);
+        KCHK();
+        return APK_OK;
+    }
+    template <class K, int BOUNDS, class... P>
+    int klaunch(hipStream_t st, dim3 grid, dim3 block, size_t lds, P... p) {
+        Slot* m = gang_member();
+        static const int defer = env_int("APK_GANG_DEFER", 1, 0, 1);
+        if (defer && m && m->in_gang && m->d_pinned && st == m->stream && grid.z == 1) {
+            m->cmds.emplace_back();
+            Cmd& c = m->cmds.back();
+            c.grid = grid; c.block = block; c.lds = (uint32_t)lds;
+            c.multi = &launch_multi<K, BOUNDS, P...>;
+            new (c.blob) Pack<P...>(make_pack_impl(p...));
+            return APK_OK;
+        }
+        poly1_kernel<K, BOUNDS, P...><<<grid, block, lds, st>>>(p...);
+        KCHK();
+        return APK_OK;
+    }
+    // launch what the members of a meeting have recorded: instance i of every member in ONE launch when they are the same kernel
+    // with the same launch shape (they are: the members run the same prover over the same circuit), else one by one
+    int flush_cmds(GangReq* const* reqs, int count, hipStream_t st) {
+        Slot* ms[GANG_MAX];
+        int nm = 0;
+        size_t longest = 0;
+        for (int i = 0; i < count; i++) {
+            Slot* m = static_cast<Slot*>(reqs[i]->member);
+            if (m && !m->cmds.empty()) { ms[nm++] = m; if (m->cmds.size() > longest) longest = m->cmds.size(); }
+        }
+        int rc = APK_OK;
+        for (size_t i = 0; i < longest && rc == APK_OK; i++) {
+            bool done[GANG_MAX] = {false, false, false, false};
+            for (int a = 0; a < nm && rc == APK_OK; a++) {
+                if (done[a] || i >= ms[a]->cmds.size()) continue;
+                const Cmd& ca = ms[a]->cmds[i];
+                const Cmd* grp[GANG_MAX];
+                int ng = 0;
+                for (int b = a; b < nm; b++) {
+                    if (done[b] || i >= ms[b]->cmds.size()) continue;
+                    const Cmd& cb = ms[b]->cmds[i];
+                    if (cb.multi != ca.multi || cb.grid.x != ca.grid.x || cb.grid.y != ca.grid.y || cb.block.x != ca.block.x || cb.lds != ca.lds) continue;
+                    grp[ng++] = &cb;
+                    done[b] = true;
+                }
+                rc = ca.multi(st, grp, ng);
+                if (ng > 1) path(P_GANG_KERNELS);
+            }
+        }
+        for (int a = 0; a < nm; a++) ms[a]->cmds.clear();
+        return rc;
+    }
+
     // ---- gangs (gang.h) ----------------------------------------------------------------------------------------------------------
     static int choose_gang(int log_n, int nslots, int max_slots) {
         const int env = env_int("APK_GANG", 0, 0, GANG_MAX);
@@ -1225,10 +1316,11 @@ class CurveBackend : public Backend {
                 if (lead == s) lead->gang.wait_empty();       // the others run on this slot's stream and MSM workspace
             }
             s->lead = s; s->in_gang = false; s->res_off = 0;
+            s->cmds.clear();
             b->release(s);
         }
     };
-    enum { GANG_KIND_MSM = 1, GANG_KIND_NTT = 2 };
+    enum { GANG_KIND_MSM = 1, GANG_KIND_NTT = 2, GANG_KIND_FLUSH = 3 };
     struct MsmReq { Slot* member; const MsmTables* T; MsmBatchArgs a; };
     struct NttReq {
         Slot* member; int which; bool inverse; int count;
@@ -1243,8 +1335,18 @@ class CurveBackend : public Backend {
     void gang_launch(GangReq* const* reqs, int count) {
         bool done[GANG_MAX] = {false, false, false, false};
         uint32_t res_base = 0;       // MSM sums of this meeting's launch sequences sit one behind the other in the lead's XYZZ area
+        // first what the members recorded on their way here (the kernels in front of this merge point), merged
+        {
+            Slot* any = static_cast<Slot*>(reqs[0]->member);
+            const int frc = any ? flush_cmds(reqs, count, any->stream) : APK_OK;
+            if (frc != APK_OK) {
+                for (int i = 0; i < count; i++) { reqs[i]->rc = frc; reqs[i]->err = apk_last_error(); }
+                return;
+            }
+        }
         for (int i = 0; i < count; i++) {
             if (done[i]) continue;
+            if (reqs[i]->kind == GANG_KIND_FLUSH) { reqs[i]->rc = APK_OK; done[i] = true; continue; }
             if (reqs[i]->kind == GANG_KIND_MSM) {
                 MsmReq* first = static_cast<MsmReq*>(reqs[i]->args);
                 Slot& lead = *first->member->lead;
@@ -1315,16 +1417,12 @@ class CurveBackend : public Backend {
     int powers(hipStream_t st, Fr* out, uint32_t count, const Fr& w, const Fr& scale) {
         PowersBatch<FRP> pb{};
         pb.out[0] = out; pb.w[0] = w; pb.scale[0] = scale;
-        powers_kernel<FRP><<<dim3(cdiv(cdiv(count, 8), 256), 1), 256, 0, st>>>(pb, count);
-        KCHK();
-        return APK_OK;
+        return klaunch<PowersK<FRP>, 256>(st, dim3(cdiv(cdiv(count, 8), 256), 1), 256, 0, pb, count);
     }
     int powers_batch(hipStream_t st, int k, Fr* const* outs, const Fr* ws, uint32_t count) {
         PowersBatch<FRP> pb{};
         for (int i = 0; i < k; i++) { pb.out[i] = outs[i]; pb.w[i] = ws[i]; pb.scale[i] = Fr::one(); }
-        powers_kernel<FRP><<<dim3(cdiv(cdiv(count, 8), 256), k), 256, 0, st>>>(pb, count);
-        KCHK();
-        return APK_OK;
+        return klaunch<PowersK<FRP>, 256>(st, dim3(cdiv(cdiv(count, 8), 256), k), 256, 0, pb, count);
     }
 
     // LDS of the sort kernels: 32-bit counters, or packed 16-bit pairs from 2^16 buckets (c = 17)
@@ -1793,13 +1891,13 @@ class CurveBackend : public Backend {
     int scan_inplace(hipStream_t st, Fr* data, uint32_t count, bool rev, bool mul_op, Fr* tot, Fr* out, int shift) {
         const uint32_t nb = cdiv(count, SCAN_BLOCK);
         if (mul_op) {
-            scan_block_kernel<FRP, OpMul><<<nb, POLY_THREADS, 0, st>>>(data, count, rev, tot); KCHK();
-            scan_totals_kernel<FRP, OpMul><<<1, POLY_THREADS, 0, st>>>(tot, nb); KCHK();
-            scan_apply_kernel<FRP, OpMul><<<cdiv(count, POLY_THREADS), POLY_THREADS, 0, st>>>(data, count, rev, tot, out, shift); KCHK();
+            CHK((klaunch<ScanBlockK<FRP, OpMul>, POLY_THREADS>(st, nb, POLY_THREADS, 0, data, count, rev, tot)));
+            CHK((klaunch<ScanTotalsK<FRP, OpMul>, POLY_THREADS>(st, 1, POLY_THREADS, 0, tot, nb)));
+            CHK((klaunch<ScanApplyK<FRP, OpMul>, POLY_THREADS>(st, cdiv(count, POLY_THREADS), POLY_THREADS, 0, (const Fr*)data, count, rev, (const Fr*)tot, out, shift)));
         } else {
-            scan_block_kernel<FRP, OpAdd><<<nb, POLY_THREADS, 0, st>>>(data, count, rev, tot); KCHK();
-            scan_totals_kernel<FRP, OpAdd><<<1, POLY_THREADS, 0, st>>>(tot, nb); KCHK();
-            scan_apply_kernel<FRP, OpAdd><<<cdiv(count, POLY_THREADS), POLY_THREADS, 0, st>>>(data, count, rev, tot, out, shift); KCHK();
+            CHK((klaunch<ScanBlockK<FRP, OpAdd>, POLY_THREADS>(st, nb, POLY_THREADS, 0, data, count, rev, tot)));
+            CHK((klaunch<ScanTotalsK<FRP, OpAdd>, POLY_THREADS>(st, 1, POLY_THREADS, 0, tot, nb)));
+            CHK((klaunch<ScanApplyK<FRP, OpAdd>, POLY_THREADS>(st, cdiv(count, POLY_THREADS), POLY_THREADS, 0, (const Fr*)data, count, rev, (const Fr*)tot, out, shift)));
         }
         return APK_OK;
     }
@@ -1808,13 +1906,13 @@ class CurveBackend : public Backend {
     int kzg_quotient(Slot& s, const Fr* f, uint32_t len, const Fr* pw, const Fr* pwi, bool z_is_zero, Fr* q) {
         hipStream_t st = s.stream;
         if (z_is_zero) {
-            shift_down_kernel<FRP><<<cdiv(len, 256), 256, 0, st>>>(f, len, q); KCHK();
+            CHK((klaunch<ShiftDownK<FRP>, 256>(st, cdiv(len, 256), 256, 0, f, len, q)));
             return APK_OK;
         }
         Fr* t = ptr<Fr>(s.tmp);
-        mul_kernel<FRP><<<cdiv(len, 256), 256, 0, st>>>(t, f, pw, len); KCHK();
+        CHK((klaunch<MulK<FRP>, 256>(st, cdiv(len, 256), 256, 0, t, f, pw, len)));
         CHK(scan_inplace(st, t, len, true, false, ptr<Fr>(s.scan_tot), t, 0));
-        div_finish_kernel<FRP><<<cdiv(len, 256), 256, 0, st>>>(t, pwi, len, q); KCHK();
+        CHK((klaunch<DivFinishK<FRP>, POLY_THREADS>(st, cdiv(len, 256), 256, 0, (const Fr*)t, pwi, len, q)));
         return APK_OK;
     }
 
@@ -1823,12 +1921,12 @@ class CurveBackend : public Backend {
         uint32_t maxlen = 0;
         for (int i = 0; i < ea.count; i++) if (ea.len[i] > maxlen) maxlen = ea.len[i];
         const uint32_t nblocks = cdiv(maxlen, EVAL_BLOCK);
-        eval_partial_kernel<FRP><<<dim3(nblocks, ea.count), POLY_THREADS, 0, st>>>(ea, pw, nblocks, ptr<Fr>(s.eval_partial)); KCHK();
+        CHK((klaunch<EvalPartialK<FRP>, POLY_THREADS>(st, dim3(nblocks, ea.count), POLY_THREADS, 0, ea, pw, nblocks, ptr<Fr>(s.eval_partial))));
         // (h_out lies in the slot's pinned buffer: with the zero-copy view the kernel writes the values there itself)
         const bool direct = s.d_pinned && reinterpret_cast<uint8_t*>(h_out) >= reinterpret_cast<uint8_t*>(s.h_pinned) &&
                             reinterpret_cast<uint8_t*>(h_out) + ea.count * sizeof(Fr) <= reinterpret_cast<uint8_t*>(s.h_pinned) + PIN_BYTES;
         Fr* const ev_out = direct ? reinterpret_cast<Fr*>(s.d_pinned + (reinterpret_cast<uint8_t*>(h_out) - reinterpret_cast<uint8_t*>(s.h_pinned))) : ptr<Fr>(s.eval_result);
-        eval_final_kernel<FRP><<<ea.count, POLY_THREADS, 0, st>>>(ptr<Fr>(s.eval_partial), nblocks, ev_out); KCHK();
+        CHK((klaunch<EvalFinalK<FRP>, POLY_THREADS>(st, ea.count, POLY_THREADS, 0, (const Fr*)ptr<Fr>(s.eval_partial), nblocks, ev_out)));
         if (!direct) HIPCHK(hipMemcpyAsync(h_out, s.eval_result.p, ea.count * sizeof(Fr), hipMemcpyDeviceToHost, st));
         return APK_OK;
     }
@@ -2088,7 +2186,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
             b3.p[j] = canon[j]; b3.b[j].v[0] = bl[2 * j]; b3.b[j].v[1] = bl[2 * j + 1];
             b3.lag[j] = use_lag ? lagv[j] : nullptr;     // the blinding scalars behind the n witness values: the scalars of D_0, D_1
         }
-        blind3_kernel<FRP><<<3, 64, 0, st>>>(b3, n, 2); KCHK();
+        CHK((klaunch<Blind3K<FRP>, 256>(st, 3, 64, 0, b3, n, 2)));
     }
     const int fill = tail_fill(s);
     if (fill) path(P_TAIL_FILL);
@@ -2175,24 +2273,23 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         GpScan<FRP> g{};
         g.data[0] = ptr<Fr>(s.ratio); g.data[1] = ptr<Fr>(s.tmp);
         g.tot[0] = ptr<Fr>(s.scan_tot); g.tot[1] = ptr<Fr>(s.scan_tot) + nb + 1;
-        gp_terms_kernel<FRP><<<cdiv(n, POLY_THREADS), POLY_THREADS, 0, st>>>(
-            dL, dR, dO, ptr<Fr>(s_lag_[0]), ptr<Fr>(s_lag_[1]), ptr<Fr>(s_lag_[2]), ptr<Fr>(tw_n_), n, beta * fr_u64(32), gamma, beta_u * fr_u64(32),
-            beta_u2 * fr_u64(32),   // the kernel multiplies on unsaturated limbs: the challenges in the product's radix R' = 32 R
-            g.data[0], g.data[1]);
-        KCHK();
-        gp_scan_block_kernel<FRP><<<dim3(nb, 2), POLY_THREADS, 0, st>>>(g, n); KCHK();
+        // (the kernel multiplies on unsaturated limbs: the challenges in the product's radix R' = 32 R)
+        CHK((klaunch<GpTermsK<FRP>, POLY_THREADS>(st, cdiv(n, POLY_THREADS), POLY_THREADS, 0, dL, dR, dO, (const Fr*)ptr<Fr>(s_lag_[0]),
+                                                  (const Fr*)ptr<Fr>(s_lag_[1]), (const Fr*)ptr<Fr>(s_lag_[2]), (const Fr*)ptr<Fr>(tw_n_), n, beta * fr_u64(32), gamma,
+                                                  beta_u * fr_u64(32), beta_u2 * fr_u64(32), g.data[0], g.data[1])));
+        CHK((klaunch<GpScanBlockK<FRP>, POLY_THREADS>(st, dim3(nb, 2), POLY_THREADS, 0, g, n)));
         Fr* const tot_out = s.d_pinned ? reinterpret_cast<Fr*>(s.d_pinned + PIN_FR) : g.tot[1] + nb;     // hfr[0], from the device
-        gp_scan_totals_kernel<FRP><<<2, POLY_THREADS, 0, st>>>(g, nb, tot_out); KCHK();
+        CHK((klaunch<GpScanTotalsK<FRP>, POLY_THREADS>(st, 2, POLY_THREADS, 0, g, nb, tot_out)));
         if (!s.d_pinned) HIPCHK(hipMemcpyAsync(hfr, g.tot[1] + nb, sizeof(Fr), hipMemcpyDeviceToHost, st));
         CHK(sync_results(s));
         const Fr den_total_inv = Fr::inv(hfr[0]);
-        gp_finish_kernel<FRP><<<cdiv(n, POLY_THREADS), POLY_THREADS, 0, st>>>(g, n, den_total_inv, ptr<Fr>(s.zlag)); KCHK();
+        CHK((klaunch<GpFinishK<FRP>, POLY_THREADS>(st, cdiv(n, POLY_THREADS), POLY_THREADS, 0, g, n, den_total_inv, ptr<Fr>(s.zlag))));
     }
     CHK(inv_ntt_n(st, ptr<Fr>(s.zlag), ptr<Fr>(s.cz)));
     {
         Fr4<FRP> b{};
         b.v[0] = bl[6]; b.v[1] = bl[7]; b.v[2] = bl[8];
-        blind_kernel<FRP><<<1, 64, 0, st>>>(ptr<Fr>(s.cz), n, b, 3); KCHK();
+        CHK((klaunch<BlindK<FRP>, 256>(st, 1, 64, 0, ptr<Fr>(s.cz), n, b, 3)));
         MsmBatchArgs a{};
         a.batch = 1; a.scalars[0] = s.cz.p; a.len[0] = n + 3; a.offset[0] = 0;
         s.mark_acc = fill;
@@ -2253,7 +2350,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         for (int j = 0; j < q.nb_inject; j++) q.inj_delta[j] = q.inj_delta[j] * c5;
         q.n4 = n4_;
         if (!sc_.on()) {
-            quotient_kernel<FRP><<<cdiv(n4_, POLY_THREADS), POLY_THREADS, 0, st>>>(q, ptr<Fr>(s.quot)); KCHK();
+            CHK((klaunch<QuotientK<FRP>, POLY_THREADS>(st, cdiv(n4_, POLY_THREADS), POLY_THREADS, 0, q, ptr<Fr>(s.quot))));
             CHK(run_ntt(st, 1, true, ptr<Fr>(s.quot), ptr<Fr>(s.hcan), n4_, n4_, nullptr, ptr<Fr>(coset_post_inv_), nullptr));
         } else {
             // sub-coset split: the quotient on this rank's m points, the local part of the inverse transform, ONE all-gather,
@@ -2282,9 +2379,9 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
         // h[3(n+2) .. 4n) must vanish (OR-reduce on the device, one flag word back)
         s.epoch++;
         const uint32_t tail4 = (n4_ - 3 * (n + 2)) * (uint32_t)(sizeof(Fr) / 16);
-        tail_nonzero_kernel<0><<<cdiv(tail4, 256 * 8) < 512 ? cdiv(tail4, 256 * 8) : 512, 256, 0, st>>>(
-            reinterpret_cast<const uint4*>(ptr<Fr>(s.hcan) + 3 * (size_t)(n + 2)), tail4, s.epoch,
-            s.d_pinned ? reinterpret_cast<uint32_t*>(s.d_pinned + PIN_TAIL) : ptr<uint32_t>(s.tail_flag)); KCHK();
+        CHK((klaunch<TailNonzeroK<0>, 256>(st, cdiv(tail4, 256 * 8) < 512 ? cdiv(tail4, 256 * 8) : 512, 256, 0,
+                                            reinterpret_cast<const uint4*>(ptr<Fr>(s.hcan) + 3 * (size_t)(n + 2)), tail4, s.epoch,
+                                            s.d_pinned ? reinterpret_cast<uint32_t*>(s.d_pinned + PIN_TAIL) : ptr<uint32_t>(s.tail_flag))));
         if (!s.d_pinned) HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(s.h_pinned) + PIN_TAIL, s.tail_flag.p, 4, hipMemcpyDeviceToHost, st));
     }
     CHK(sync_results(s));
@@ -2337,7 +2434,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
             DerivePowers<FRP> dp{};
             dp.in[0] = outs[0]; dp.out[0] = outs[1]; dp.inverse[0] = 0;
             dp.in[1] = outs[2]; dp.out[1] = outs[3]; dp.inverse[1] = 1;
-            derive_powers_kernel<FRP><<<dim3(cdiv(n + 3, POLY_THREADS), 2), POLY_THREADS, 0, st>>>(dp, ptr<Fr>(twu_n_), n, n + 3); KCHK();
+            CHK((klaunch<DerivePowersK<FRP>, POLY_THREADS>(st, dim3(cdiv(n + 3, POLY_THREADS), 2), POLY_THREADS, 0, dp, (const Fr*)ptr<Fr>(twu_n_), n, n + 3)));
         }
     }
     std::vector<Fr> lag_w, lag_den;
@@ -2484,7 +2581,7 @@ int CurveBackend<FRP, FPP, CURVE_ID>::prove(const void* L, const void* R, const 
             const Fr c32 = fr_u64(32);
             for (int k = 0; k < c; k++) lc.coef[k] = lc.coef[k] * c32;
         }
-        lincomb_kernel<FRP><<<cdiv(n + 3, POLY_THREADS), POLY_THREADS, 0, st>>>(lc, ptr<Fr>(s.folded)); KCHK();
+        CHK((klaunch<LincombK<FRP>, POLY_THREADS>(st, cdiv(n + 3, POLY_THREADS), POLY_THREADS, 0, lc, ptr<Fr>(s.folded))));
         CHK(kzg_quotient(s, ptr<Fr>(s.folded), n + 3, ptr<Fr>(s.pw_z), ptr<Fr>(s.pw_zi), z0, ptr<Fr>(s.q1)));
         // both opening proofs in one batch: W_zeta (batched opening) and W_omega*zeta (kzg.Open of Z [UPSTREAM])
         MsmBatchArgs a{};

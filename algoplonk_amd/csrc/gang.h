@@ -29,6 +29,7 @@ constexpr int GANG_MAX = 4;
 struct GangReq {
     int kind = 0;        // what kind of merge point this is (the launcher groups compatible requests)
     void* args = nullptr;
+    void* member = nullptr;   // the posting member (opaque here: the backend's Slot)
     int rc = 0;          // filled in by the launcher
     std::string err;     // ... with its error message when rc != 0 (the launch ran on another member's thread)
     bool done = false;

@@ -218,32 +218,36 @@ struct PowersBatch {
     Fe<FR> scale[POWERS_MAX_BATCH];
 };
 template <class FR>
-__global__ void __launch_bounds__(256) powers_kernel(PowersBatch<FR> pb, uint32_t count) {
-    using Fr = Fe<FR>;
-    using U = FeU<FR>;
-    constexpr uint32_t PER = 8;
-    Fr* __restrict__ out = pb.out[blockIdx.y];
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t start = t * PER;
-    if (start >= count) return;
-    // The whole dependent chain (square-and-multiply to w^start, then PER steps) runs on the carry-free product: w is taken
-    // into the product's own Montgomery domain R' (closed under mul), the block's first power comes back to gnark's radix R
-    // with one product, and the walk multiplies R-radix values by w R'.
-    const U wu = U::from_fe(pb.w[blockIdx.y]);           // w R'
-    U r = U::one();                                       // R'
-    bool started = false;
-    for (int b = 31; b >= 0; b--) {
-        if (started) r = U::sqr(r);
-        if ((start >> b) & 1u) { r = started ? U::mul(r, wu) : wu; started = true; }
+struct PowersK {
+    static __device__ __forceinline__ void run(PowersBatch<FR> pb, uint32_t count) {
+        using Fr = Fe<FR>;
+        using U = FeU<FR>;
+        constexpr uint32_t PER = 8;
+        Fr* __restrict__ out = pb.out[blockIdx.y];
+        uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+        uint32_t start = t * PER;
+        if (start >= count) return;
+        // The whole dependent chain (square-and-multiply to w^start, then PER steps) runs on the carry-free product: w is taken
+        // into the product's own Montgomery domain R' (closed under mul), the block's first power comes back to gnark's radix R
+        // with one product, and the walk multiplies R-radix values by w R'.
+        const U wu = U::from_fe(pb.w[blockIdx.y]);           // w R'
+        U r = U::one();                                       // R'
+        bool started = false;
+        for (int b = 31; b >= 0; b--) {
+            if (started) r = U::sqr(r);
+            if ((start >> b) & 1u) { r = started ? U::mul(r, wu) : wu; started = true; }
+        }
+        Fr first = r.to_fe();                                 // w^start R
+        U cur = U::mul(U::unpack(first.l), U::from_fe(pb.scale[blockIdx.y]));   // scale w^start, R radix, canonical
+        for (uint32_t k = 0; k < PER && start + k < count; k++) {
+            Fr o;
+            cur.pack(o.l);
+            out[start + k] = o;
+            cur = U::mul(wu, cur);
+        }
     }
-    Fr first = r.to_fe();                                 // w^start R
-    U cur = U::mul(U::unpack(first.l), U::from_fe(pb.scale[blockIdx.y]));   // scale w^start, R radix, canonical
-    for (uint32_t k = 0; k < PER && start + k < count; k++) {
-        Fr o;
-        cur.pack(o.l);
-        out[start + k] = o;
-        cur = U::mul(wu, cur);
-    }
-}
+};
+template <class FR>
+__global__ void __launch_bounds__(256) powers_kernel(PowersBatch<FR> pb, uint32_t count) { PowersK<FR>::run(pb, count); }
 
 }  // namespace apk

@@ -28,13 +28,17 @@ __global__ void fill_zero_kernel(Fe<FR>* p, uint32_t count) {
 
 // p(X) += b(X) (X^n - 1), deg b = d-1 <= 2;  p has capacity n+d and holds n coefficients: p[n..n+d) is assigned, not added to
 template <class FR>
-__global__ void blind_kernel(Fe<FR>* p, uint32_t n, Fr4<FR> b, int d) {
-    int i = threadIdx.x;
-    if (i < d) {
-        p[i] = p[i] - b.v[i];
-        p[n + i] = b.v[i];
+struct BlindK {
+    static __device__ __forceinline__ void run(Fe<FR>* p, uint32_t n, Fr4<FR> b, int d) {
+        int i = threadIdx.x;
+        if (i < d) {
+            p[i] = p[i] - b.v[i];
+            p[n + i] = b.v[i];
+        }
     }
-}
+};
+template <class FR>
+__global__ void blind_kernel(Fe<FR>* p, uint32_t n, Fr4<FR> b, int d) { BlindK<FR>::run(p, n, b, d); }
 // the three wire polynomials in one launch (blockIdx.x = wire)
 template <class FR>
 struct Blind3 {
@@ -44,26 +48,34 @@ struct Blind3 {
                       // the blinding points [tau^(n+k)] - [tau^k] of the extended Lagrange table (backend_impl.h, round 1)
 };
 template <class FR>
-__global__ void blind3_kernel(Blind3<FR> a, uint32_t n, int d) {
-    int i = threadIdx.x;
-    Fe<FR>* p = a.p[blockIdx.x];
-    if (i < d) {
-        const Fe<FR> v = a.b[blockIdx.x].v[i];
-        if (p) {
-            p[i] = p[i] - v;
-            p[n + i] = v;
+struct Blind3K {
+    static __device__ __forceinline__ void run(Blind3<FR> a, uint32_t n, int d) {
+        int i = threadIdx.x;
+        Fe<FR>* p = a.p[blockIdx.x];
+        if (i < d) {
+            const Fe<FR> v = a.b[blockIdx.x].v[i];
+            if (p) {
+                p[i] = p[i] - v;
+                p[n + i] = v;
+            }
+            if (a.lag[blockIdx.x]) a.lag[blockIdx.x][n + i] = v;
         }
-        if (a.lag[blockIdx.x]) a.lag[blockIdx.x][n + i] = v;
     }
-}
+};
+template <class FR>
+__global__ void blind3_kernel(Blind3<FR> a, uint32_t n, int d) { Blind3K<FR>::run(a, n, d); }
 
 // out[i] = a[i] * b[i]  (b indexed with offset/stride so tables can be reused)
 template <class FR>
-__global__ void mul_kernel(Fe<FR>* out, const Fe<FR>* a, const Fe<FR>* b, uint32_t count) {
-    wave_priority<APK_PRIO_FR>();
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) out[i] = a[i] * b[i];
-}
+struct MulK {
+    static __device__ __forceinline__ void run(Fe<FR>* out, const Fe<FR>* a, const Fe<FR>* b, uint32_t count) {
+        wave_priority<APK_PRIO_FR>();
+        uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < count) out[i] = a[i] * b[i];
+    }
+};
+template <class FR>
+__global__ void mul_kernel(Fe<FR>* out, const Fe<FR>* a, const Fe<FR>* b, uint32_t count) { MulK<FR>::run(out, a, b, count); }
 
 // ---- grand product ------------------------------------------------------------------------------------------
 // Z[0] = 1, Z[k] = prod_{i<k} num_i / den_i with
@@ -72,35 +84,44 @@ __global__ void mul_kernel(Fe<FR>* out, const Fe<FR>* a, const Fe<FR>* b, uint32
 // a forward product scan of num, a reverse product scan of den and ONE field inversion of the total give
 //   Z[k] = (prod_{i<k} num_i) * (prod_{i>=k} den_i) * (prod_i den_i)^-1.
 template <class FR>
-__global__ void __launch_bounds__(POLY_THREADS) gp_terms_kernel(const Fe<FR>* __restrict__ L, const Fe<FR>* __restrict__ R,
+struct GpTermsK {
+    static __device__ __forceinline__ void run(const Fe<FR>* __restrict__ L, const Fe<FR>* __restrict__ R,
                                                                 const Fe<FR>* __restrict__ O, const Fe<FR>* __restrict__ S1,
                                                                 const Fe<FR>* __restrict__ S2, const Fe<FR>* __restrict__ S3,
                                                                 const Fe<FR>* __restrict__ tw, uint32_t n, Fe<FR> beta,
                                                                 Fe<FR> gamma, Fe<FR> beta_u, Fe<FR> beta_u2,
                                                                 Fe<FR>* __restrict__ num, Fe<FR>* __restrict__ den) {
-    wave_priority<APK_PRIO_FR>();
-    using Fr = Fe<FR>;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    // On unsaturated limbs, lazily.  beta, beta_u, beta_u2 arrive as 32 x (the product's radix R' = 32 R), so beta * w is exact;
-    // the two value x value products of each triple leave num and den BOTH divided by 1024 - which cancels in
-    // Z[k] = prod_{i<k} num * prod_{i>=k} den / prod den (k factors, n - k factors, n factors).  Sums below 4 r, products below 2 r.
-    using U = FeU<FR>;
-    static_assert(U::HEADROOM >= 64, "factors below 4 r");
-    auto ld = [](const Fr* p, uint32_t k) { Fr v = p[k]; return U::unpack(v.l); };
-    Fr wf = i < n / 2 ? tw[i] : Fr::neg(tw[i - n / 2]);
-    const U w = U::unpack(wf.l), gm = U::unpack(gamma.l), b = U::unpack(beta.l), bu = U::unpack(beta_u.l), bu2 = U::unpack(beta_u2.l);
-    const U l = U::add_n(ld(L, i), gm), r = U::add_n(ld(R, i), gm), o = U::add_n(ld(O, i), gm);      // < 2
-    U nu = U::mul_nr(U::add_n(l, U::mul_nr(b, w)), U::add_n(r, U::mul_nr(bu, w)));                      // factors < 4
-    nu = U::mul_nr(nu, U::add_n(o, U::mul_nr(bu2, w)));
-    U de = U::mul_nr(U::add_n(l, U::mul_nr(b, ld(S1, i))), U::add_n(r, U::mul_nr(b, ld(S2, i))));
-    de = U::mul_nr(de, U::add_n(o, U::mul_nr(b, ld(S3, i))));
-    Fr on, od;
-    U::template canon<1>(nu).pack(on.l);
-    U::template canon<1>(de).pack(od.l);
-    num[i] = on;
-    den[i] = od;
-}
+        wave_priority<APK_PRIO_FR>();
+        using Fr = Fe<FR>;
+        uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= n) return;
+        // On unsaturated limbs, lazily.  beta, beta_u, beta_u2 arrive as 32 x (the product's radix R' = 32 R), so beta * w is exact;
+        // the two value x value products of each triple leave num and den BOTH divided by 1024 - which cancels in
+        // Z[k] = prod_{i<k} num * prod_{i>=k} den / prod den (k factors, n - k factors, n factors).  Sums below 4 r, products below 2 r.
+        using U = FeU<FR>;
+        static_assert(U::HEADROOM >= 64, "factors below 4 r");
+        auto ld = [](const Fr* p, uint32_t k) { Fr v = p[k]; return U::unpack(v.l); };
+        Fr wf = i < n / 2 ? tw[i] : Fr::neg(tw[i - n / 2]);
+        const U w = U::unpack(wf.l), gm = U::unpack(gamma.l), b = U::unpack(beta.l), bu = U::unpack(beta_u.l), bu2 = U::unpack(beta_u2.l);
+        const U l = U::add_n(ld(L, i), gm), r = U::add_n(ld(R, i), gm), o = U::add_n(ld(O, i), gm);      // < 2
+        U nu = U::mul_nr(U::add_n(l, U::mul_nr(b, w)), U::add_n(r, U::mul_nr(bu, w)));                      // factors < 4
+        nu = U::mul_nr(nu, U::add_n(o, U::mul_nr(bu2, w)));
+        U de = U::mul_nr(U::add_n(l, U::mul_nr(b, ld(S1, i))), U::add_n(r, U::mul_nr(b, ld(S2, i))));
+        de = U::mul_nr(de, U::add_n(o, U::mul_nr(b, ld(S3, i))));
+        Fr on, od;
+        U::template canon<1>(nu).pack(on.l);
+        U::template canon<1>(de).pack(od.l);
+        num[i] = on;
+        den[i] = od;
+    }
+};
+template <class FR>
+__global__ void __launch_bounds__(POLY_THREADS) gp_terms_kernel(const Fe<FR>* __restrict__ L, const Fe<FR>* __restrict__ R,
+                                                                const Fe<FR>* __restrict__ O, const Fe<FR>* __restrict__ S1,
+                                                                const Fe<FR>* __restrict__ S2, const Fe<FR>* __restrict__ S3,
+                                                                const Fe<FR>* __restrict__ tw, uint32_t n, Fe<FR> beta,
+                                                                Fe<FR> gamma, Fe<FR> beta_u, Fe<FR> beta_u2,
+                                                                Fe<FR>* __restrict__ num, Fe<FR>* __restrict__ den) { GpTermsK<FR>::run(L, R, O, S1, S2, S3, tw, n, beta, gamma, beta_u, beta_u2, num, den); }
 
 // ---- generic scans over Fr: op = multiply (grand product) or add (suffix sums for the KZG quotient) ------
 struct OpMul { template <class F> __device__ static F apply(const F& a, const F& b) { return a * b; }
@@ -147,11 +168,16 @@ __device__ __forceinline__ void scan_block_body(Fe<FR>* __restrict__ data, uint3
     if (t == POLY_THREADS - 1) block_tot[blockIdx.x] = mine;
 }
 template <class FR, class OP>
-__global__ void __launch_bounds__(POLY_THREADS) scan_block_kernel(Fe<FR>* __restrict__ data, uint32_t count, bool rev,
+struct ScanBlockK {
+    static __device__ __forceinline__ void run(Fe<FR>* __restrict__ data, uint32_t count, bool rev,
                                                                   Fe<FR>* __restrict__ block_tot) {
-    wave_priority<APK_PRIO_FR>();
-    scan_block_body<FR, OP>(data, count, rev, block_tot);
-}
+        wave_priority<APK_PRIO_FR>();
+        scan_block_body<FR, OP>(data, count, rev, block_tot);
+    }
+};
+template <class FR, class OP>
+__global__ void __launch_bounds__(POLY_THREADS) scan_block_kernel(Fe<FR>* __restrict__ data, uint32_t count, bool rev,
+                                                                  Fe<FR>* __restrict__ block_tot) { ScanBlockK<FR, OP>::run(data, count, rev, block_tot); }
 
 // phase 2: single block, exclusive scan of block totals in place (nblocks <= POLY_THREADS * 64)
 // Returns (in the last thread) the total over all blocks.
@@ -184,10 +210,14 @@ __device__ __forceinline__ Fe<FR> scan_totals_body(Fe<FR>* __restrict__ tot, uin
     return acc;
 }
 template <class FR, class OP>
-__global__ void __launch_bounds__(POLY_THREADS) scan_totals_kernel(Fe<FR>* __restrict__ tot, uint32_t nblocks) {
-    wave_priority<APK_PRIO_FR>();
-    scan_totals_body<FR, OP>(tot, nblocks);
-}
+struct ScanTotalsK {
+    static __device__ __forceinline__ void run(Fe<FR>* __restrict__ tot, uint32_t nblocks) {
+        wave_priority<APK_PRIO_FR>();
+        scan_totals_body<FR, OP>(tot, nblocks);
+    }
+};
+template <class FR, class OP>
+__global__ void __launch_bounds__(POLY_THREADS) scan_totals_kernel(Fe<FR>* __restrict__ tot, uint32_t nblocks) { ScanTotalsK<FR, OP>::run(tot, nblocks); }
 
 // ---- the grand product's pair of scans: blockIdx.y = 0 forward over num, 1 reverse over den ------------------
 template <class FR>
@@ -196,49 +226,67 @@ struct GpScan {
     Fe<FR>* tot[2];   // tot[1] has one extra slot: the product of all denominators
 };
 template <class FR>
-__global__ void __launch_bounds__(POLY_THREADS) gp_scan_block_kernel(GpScan<FR> g, uint32_t count) {
-    wave_priority<APK_PRIO_FR>();
-    scan_block_body<FR, OpMul>(g.data[blockIdx.y], count, blockIdx.y != 0, g.tot[blockIdx.y]);
-}
+struct GpScanBlockK {
+    static __device__ __forceinline__ void run(GpScan<FR> g, uint32_t count) {
+        wave_priority<APK_PRIO_FR>();
+        scan_block_body<FR, OpMul>(g.data[blockIdx.y], count, blockIdx.y != 0, g.tot[blockIdx.y]);
+    }
+};
 template <class FR>
-__global__ void __launch_bounds__(POLY_THREADS) gp_scan_totals_kernel(GpScan<FR> g, uint32_t nblocks, Fe<FR>* __restrict__ total_out) {
-    wave_priority<APK_PRIO_FR>();
-    Fe<FR> total = scan_totals_body<FR, OpMul>(g.tot[blockIdx.x], nblocks);
-    // the product of all denominators: inverted on the HOST (a lone GPU lane needs ~100 us for one Kaliski inversion); total_out
-    // is the slot's pinned host buffer seen from the device, or a device word the host copies back
-    if (blockIdx.x == 1 && threadIdx.x == POLY_THREADS - 1) *total_out = total;
-}
+__global__ void __launch_bounds__(POLY_THREADS) gp_scan_block_kernel(GpScan<FR> g, uint32_t count) { GpScanBlockK<FR>::run(g, count); }
+template <class FR>
+struct GpScanTotalsK {
+    static __device__ __forceinline__ void run(GpScan<FR> g, uint32_t nblocks, Fe<FR>* __restrict__ total_out) {
+        wave_priority<APK_PRIO_FR>();
+        Fe<FR> total = scan_totals_body<FR, OpMul>(g.tot[blockIdx.x], nblocks);
+        // the product of all denominators: inverted on the HOST (a lone GPU lane needs ~100 us for one Kaliski inversion); total_out
+        // is the slot's pinned host buffer seen from the device, or a device word the host copies back
+        if (blockIdx.x == 1 && threadIdx.x == POLY_THREADS - 1) *total_out = total;
+    }
+};
+template <class FR>
+__global__ void __launch_bounds__(POLY_THREADS) gp_scan_totals_kernel(GpScan<FR> g, uint32_t nblocks, Fe<FR>* __restrict__ total_out) { GpScanTotalsK<FR>::run(g, nblocks, total_out); }
 // Z[0] = 1; Z[k] = num_prefix_incl[k-1] * den_suffix_incl[k] / den_total
 template <class FR>
-__global__ void __launch_bounds__(POLY_THREADS) gp_finish_kernel(GpScan<FR> g, uint32_t n, Fe<FR> den_total_inv, Fe<FR>* __restrict__ z) {
-    wave_priority<APK_PRIO_FR>();
-    using Fr = Fe<FR>;
-    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    if (k == 0) { z[0] = Fr::one(); return; }
-    Fr np = g.tot[0][(k - 1) / SCAN_BLOCK] * g.data[0][k - 1];
-    Fr ds = g.tot[1][(n - 1 - k) / SCAN_BLOCK] * g.data[1][k];
-    z[k] = np * (ds * den_total_inv);
-}
+struct GpFinishK {
+    static __device__ __forceinline__ void run(GpScan<FR> g, uint32_t n, Fe<FR> den_total_inv, Fe<FR>* __restrict__ z) {
+        wave_priority<APK_PRIO_FR>();
+        using Fr = Fe<FR>;
+        uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+        if (k >= n) return;
+        if (k == 0) { z[0] = Fr::one(); return; }
+        Fr np = g.tot[0][(k - 1) / SCAN_BLOCK] * g.data[0][k - 1];
+        Fr ds = g.tot[1][(n - 1 - k) / SCAN_BLOCK] * g.data[1][k];
+        z[k] = np * (ds * den_total_inv);
+    }
+};
+template <class FR>
+__global__ void __launch_bounds__(POLY_THREADS) gp_finish_kernel(GpScan<FR> g, uint32_t n, Fe<FR> den_total_inv, Fe<FR>* __restrict__ z) { GpFinishK<FR>::run(g, n, den_total_inv, z); }
 
 // phase 3: fold the block prefix in.  `shift` turns the inclusive scan into the exclusive one the grand
 // product wants: out[0] = identity, out[i] = inclusive[i-1] (forward scans only).
 template <class FR, class OP>
-__global__ void __launch_bounds__(POLY_THREADS) scan_apply_kernel(const Fe<FR>* __restrict__ data, uint32_t count, bool rev,
+struct ScanApplyK {
+    static __device__ __forceinline__ void run(const Fe<FR>* __restrict__ data, uint32_t count, bool rev,
                                                                   const Fe<FR>* __restrict__ block_excl,
                                                                   Fe<FR>* __restrict__ out, int shift) {
-    wave_priority<APK_PRIO_FR>();
-    using Fr = Fe<FR>;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    Fr v = OP::apply(block_excl[i / SCAN_BLOCK], data[scan_idx(i, count, rev)]);
-    if (shift) {
-        if (i + 1 < count) out[i + 1] = v;
-        if (i == 0) out[0] = OP::template identity<Fr>();
-    } else {
-        out[scan_idx(i, count, rev)] = v;
+        wave_priority<APK_PRIO_FR>();
+        using Fr = Fe<FR>;
+        uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= count) return;
+        Fr v = OP::apply(block_excl[i / SCAN_BLOCK], data[scan_idx(i, count, rev)]);
+        if (shift) {
+            if (i + 1 < count) out[i + 1] = v;
+            if (i == 0) out[0] = OP::template identity<Fr>();
+        } else {
+            out[scan_idx(i, count, rev)] = v;
+        }
     }
-}
+};
+template <class FR, class OP>
+__global__ void __launch_bounds__(POLY_THREADS) scan_apply_kernel(const Fe<FR>* __restrict__ data, uint32_t count, bool rev,
+                                                                  const Fe<FR>* __restrict__ block_excl,
+                                                                  Fe<FR>* __restrict__ out, int shift) { ScanApplyK<FR, OP>::run(data, count, rev, block_excl, out, shift); }
 
 // ---- quotient numerator on the 4n coset, divided by Z_H ---------------------------------------------------
 // gate + alpha*(Z(wX) prod(w_j + beta S_j + gamma) - Z(X) prod(w_j + beta u^j X + gamma)) + alpha^2 L_0 (Z - 1)
@@ -275,48 +323,52 @@ struct QuotientArgs {
 //     alpha2 as 2^10 alpha^2 (one value product behind it); gamma stays in R (it is added, not multiplied).
 // Bounds (R'/r >= 71): sums of a few products stay below 16 r, every product of such a sum with a canonical factor below 2 r.
 template <class FR>
-__global__ void __launch_bounds__(POLY_THREADS) quotient_kernel(QuotientArgs<FR> a, Fe<FR>* __restrict__ out) {
-    wave_priority<APK_PRIO_FR>();
-    using Fr = Fe<FR>;
-    using U = FeU<FR>;
-    static_assert(U::HEADROOM >= 64, "lazy sums of up to 16 r times a canonical factor must stay below 2 r");
-    const uint32_t jj = blockIdx.x * blockDim.x + threadIdx.x;   // index into the per-proof vectors
-    if (jj >= a.n4) return;
-    const uint32_t i = (jj << a.sub_glog) + a.sub_k;             // index into the per-circuit tables (the point of the 4n coset)
-    auto ld = [](const Fr* p, uint32_t k) { Fr v = p[k]; return U::unpack(v.l); };
-    auto cst = [](const Fr& v) { return U::unpack(v.l); };
-    const U l = ld(a.l, jj), r = ld(a.r, jj), o = ld(a.o, jj), z = ld(a.z, jj);
-    uint32_t is;
-    const Fr* zsp = a.z;
-    if (a.sub_glog <= 2) is = jj + (4u >> a.sub_glog);
-    else { is = jj + (a.sub_k + 4u >= 8u ? 1u : 0u); zsp = a.zs; }
-    if (is >= a.n4) is -= a.n4;
-    const U zs = ld(zsp, is);
-    U gate = U::add_n(U::mul_nr(ld(a.ql, i), l), U::mul_nr(ld(a.qr, i), r));
-    gate = U::add_n(gate, U::mul_nr(ld(a.qm, i), U::mul_nr(l, r)));
-    gate = U::add_n(gate, U::mul_nr(ld(a.qo, i), o));
-    gate = U::add_n(gate, ld(a.qk, i));
-    for (int k = 0; k < a.nb_commit; k++) gate = U::add_n(gate, U::mul_nr(ld(a.qcp[k], i), ld(a.pi2[k], jj)));
-    for (int j = 0; j < a.nb_inject; j++) gate = U::add_n(gate, U::mul_nr(cst(a.inj_delta[j]), ld(a.inj_tab[j], i)));
-    const U gm = cst(a.gamma), beta = cst(a.beta);
-    const U lg = U::add_n(l, gm), rg = U::add_n(r, gm), og = U::add_n(o, gm);          // < 2
-    const U x = ld(a.x, i);
-    U pa = U::mul_nr(zs, U::add_n(lg, U::mul_nr(beta, ld(a.s1, i))));                   // factors < 4, products < 1.1
-    pa = U::mul_nr(pa, U::add_n(rg, U::mul_nr(beta, ld(a.s2, i))));
-    pa = U::mul_nr(pa, U::add_n(og, U::mul_nr(beta, ld(a.s3, i))));
-    U pb = U::mul_nr(z, U::add_n(lg, U::mul_nr(beta, x)));
-    pb = U::mul_nr(pb, U::add_n(rg, U::mul_nr(cst(a.beta_u), x)));
-    pb = U::mul_nr(pb, U::add_n(og, U::mul_nr(cst(a.beta_u2), x)));
-    const U perm = U::mul_nr(cst(a.alpha), U::template sub_k<2>(pa, pb));
-    const Fr one_r = Fr::one();
-    const U one = U::unpack(one_r.l);
-    const U loc = U::mul_nr(cst(a.alpha2), U::mul_nr(ld(a.l0, i), U::template sub_k<1>(z, one)));
-    const U num = U::add_n(U::add_n(gate, perm), loc);                                   // < 16
-    const U res = U::template canon<1>(U::mul_nr(cst(a.zh_inv[i & 3]), num));
-    Fr w;
-    res.pack(w.l);
-    out[jj] = w;
-}
+struct QuotientK {
+    static __device__ __forceinline__ void run(QuotientArgs<FR> a, Fe<FR>* __restrict__ out) {
+        wave_priority<APK_PRIO_FR>();
+        using Fr = Fe<FR>;
+        using U = FeU<FR>;
+        static_assert(U::HEADROOM >= 64, "lazy sums of up to 16 r times a canonical factor must stay below 2 r");
+        const uint32_t jj = blockIdx.x * blockDim.x + threadIdx.x;   // index into the per-proof vectors
+        if (jj >= a.n4) return;
+        const uint32_t i = (jj << a.sub_glog) + a.sub_k;             // index into the per-circuit tables (the point of the 4n coset)
+        auto ld = [](const Fr* p, uint32_t k) { Fr v = p[k]; return U::unpack(v.l); };
+        auto cst = [](const Fr& v) { return U::unpack(v.l); };
+        const U l = ld(a.l, jj), r = ld(a.r, jj), o = ld(a.o, jj), z = ld(a.z, jj);
+        uint32_t is;
+        const Fr* zsp = a.z;
+        if (a.sub_glog <= 2) is = jj + (4u >> a.sub_glog);
+        else { is = jj + (a.sub_k + 4u >= 8u ? 1u : 0u); zsp = a.zs; }
+        if (is >= a.n4) is -= a.n4;
+        const U zs = ld(zsp, is);
+        U gate = U::add_n(U::mul_nr(ld(a.ql, i), l), U::mul_nr(ld(a.qr, i), r));
+        gate = U::add_n(gate, U::mul_nr(ld(a.qm, i), U::mul_nr(l, r)));
+        gate = U::add_n(gate, U::mul_nr(ld(a.qo, i), o));
+        gate = U::add_n(gate, ld(a.qk, i));
+        for (int k = 0; k < a.nb_commit; k++) gate = U::add_n(gate, U::mul_nr(ld(a.qcp[k], i), ld(a.pi2[k], jj)));
+        for (int j = 0; j < a.nb_inject; j++) gate = U::add_n(gate, U::mul_nr(cst(a.inj_delta[j]), ld(a.inj_tab[j], i)));
+        const U gm = cst(a.gamma), beta = cst(a.beta);
+        const U lg = U::add_n(l, gm), rg = U::add_n(r, gm), og = U::add_n(o, gm);          // < 2
+        const U x = ld(a.x, i);
+        U pa = U::mul_nr(zs, U::add_n(lg, U::mul_nr(beta, ld(a.s1, i))));                   // factors < 4, products < 1.1
+        pa = U::mul_nr(pa, U::add_n(rg, U::mul_nr(beta, ld(a.s2, i))));
+        pa = U::mul_nr(pa, U::add_n(og, U::mul_nr(beta, ld(a.s3, i))));
+        U pb = U::mul_nr(z, U::add_n(lg, U::mul_nr(beta, x)));
+        pb = U::mul_nr(pb, U::add_n(rg, U::mul_nr(cst(a.beta_u), x)));
+        pb = U::mul_nr(pb, U::add_n(og, U::mul_nr(cst(a.beta_u2), x)));
+        const U perm = U::mul_nr(cst(a.alpha), U::template sub_k<2>(pa, pb));
+        const Fr one_r = Fr::one();
+        const U one = U::unpack(one_r.l);
+        const U loc = U::mul_nr(cst(a.alpha2), U::mul_nr(ld(a.l0, i), U::template sub_k<1>(z, one)));
+        const U num = U::add_n(U::add_n(gate, perm), loc);                                   // < 16
+        const U res = U::template canon<1>(U::mul_nr(cst(a.zh_inv[i & 3]), num));
+        Fr w;
+        res.pack(w.l);
+        out[jj] = w;
+    }
+};
+template <class FR>
+__global__ void __launch_bounds__(POLY_THREADS) quotient_kernel(QuotientArgs<FR> a, Fe<FR>* __restrict__ out) { QuotientK<FR>::run(a, out); }
 
 // Sub-coset mode, the last log2(G) stages of the inverse 4n transform on every rank: part[k][c'] = omega_4n^(-k c') * (size-m inverse
 // transform of rank k's quotient values, unscaled)[c'] for the G classes k (all-gathered), m = 4n / G.  Coefficient c = c' + m t:
@@ -371,77 +423,91 @@ constexpr int EVAL_PER_THREAD = 8;
 constexpr int EVAL_BLOCK = POLY_THREADS * EVAL_PER_THREAD;
 
 template <class FR>
-__global__ void __launch_bounds__(POLY_THREADS) eval_partial_kernel(EvalArgs<FR> a, const Fe<FR>* __restrict__ pw,
+struct EvalPartialK {
+    static __device__ __forceinline__ void run(EvalArgs<FR> a, const Fe<FR>* __restrict__ pw,
                                                                     uint32_t nblocks, Fe<FR>* __restrict__ partial) {
-    wave_priority<APK_PRIO_FR>();
-    using Fr = Fe<FR>;
-    __shared__ Fr sm[POLY_THREADS];
-    const int p = blockIdx.y;
-    const uint32_t t = threadIdx.x;
-    const Fr* f = a.f[p];
-    const Fr* __restrict__ pwp = a.pw[p] ? a.pw[p] : pw;
-    const uint32_t len = a.len[p];
-    // the EVAL_PER_THREAD products of a lane on unsaturated limbs: value x value products come out as f pw / 32 (both operands
-    // are in gnark's radix R, the product's own radix is R' = 32 R) - the HOST multiplies the few results by 32 (eval_many's caller)
-    using U = FeU<FR>;
-    static_assert(U::HEADROOM >= 64 && EVAL_PER_THREAD * 2 <= 16, "8 products below 2 r each");
-    U accu = U::zero();
-    for (int k = 0; k < EVAL_PER_THREAD; k++) {
-        uint32_t i = blockIdx.x * EVAL_BLOCK + k * POLY_THREADS + t;
-        if (i < len) { Fr a0 = f[i], b0 = pwp[i]; accu = U::add_n(accu, U::mul_nr(U::unpack(a0.l), U::unpack(b0.l))); }
-    }
-    Fr acc;
-    U::template canon<8>(accu).pack(acc.l);
-    sm[t] = acc;
-    __syncthreads();
-    for (uint32_t d = POLY_THREADS / 2; d >= 1; d >>= 1) {
-        if (t < d) { acc = acc + sm[t + d]; sm[t] = acc; }
+        wave_priority<APK_PRIO_FR>();
+        using Fr = Fe<FR>;
+        __shared__ Fr sm[POLY_THREADS];
+        const int p = blockIdx.y;
+        const uint32_t t = threadIdx.x;
+        const Fr* f = a.f[p];
+        const Fr* __restrict__ pwp = a.pw[p] ? a.pw[p] : pw;
+        const uint32_t len = a.len[p];
+        // the EVAL_PER_THREAD products of a lane on unsaturated limbs: value x value products come out as f pw / 32 (both operands
+        // are in gnark's radix R, the product's own radix is R' = 32 R) - the HOST multiplies the few results by 32 (eval_many's caller)
+        using U = FeU<FR>;
+        static_assert(U::HEADROOM >= 64 && EVAL_PER_THREAD * 2 <= 16, "8 products below 2 r each");
+        U accu = U::zero();
+        for (int k = 0; k < EVAL_PER_THREAD; k++) {
+            uint32_t i = blockIdx.x * EVAL_BLOCK + k * POLY_THREADS + t;
+            if (i < len) { Fr a0 = f[i], b0 = pwp[i]; accu = U::add_n(accu, U::mul_nr(U::unpack(a0.l), U::unpack(b0.l))); }
+        }
+        Fr acc;
+        U::template canon<8>(accu).pack(acc.l);
+        sm[t] = acc;
         __syncthreads();
+        for (uint32_t d = POLY_THREADS / 2; d >= 1; d >>= 1) {
+            if (t < d) { acc = acc + sm[t + d]; sm[t] = acc; }
+            __syncthreads();
+        }
+        if (t == 0) partial[p * nblocks + blockIdx.x] = acc;
     }
-    if (t == 0) partial[p * nblocks + blockIdx.x] = acc;
-}
+};
+template <class FR>
+__global__ void __launch_bounds__(POLY_THREADS) eval_partial_kernel(EvalArgs<FR> a, const Fe<FR>* __restrict__ pw,
+                                                                    uint32_t nblocks, Fe<FR>* __restrict__ partial) { EvalPartialK<FR>::run(a, pw, nblocks, partial); }
 
 template <class FR>
-__global__ void __launch_bounds__(POLY_THREADS) eval_final_kernel(const Fe<FR>* __restrict__ partial, uint32_t nblocks,
+struct EvalFinalK {
+    static __device__ __forceinline__ void run(const Fe<FR>* __restrict__ partial, uint32_t nblocks,
                                                                   Fe<FR>* __restrict__ result) {
-    wave_priority<APK_PRIO_FR>();
-    using Fr = Fe<FR>;
-    __shared__ Fr sm[POLY_THREADS];
-    const int p = blockIdx.x;
-    const uint32_t t = threadIdx.x;
-    Fr acc = Fr::zero();
-    for (uint32_t i = t; i < nblocks; i += POLY_THREADS) acc = acc + partial[p * nblocks + i];
-    sm[t] = acc;
-    __syncthreads();
-    for (uint32_t d = POLY_THREADS / 2; d >= 1; d >>= 1) {
-        if (t < d) { acc = acc + sm[t + d]; sm[t] = acc; }
+        wave_priority<APK_PRIO_FR>();
+        using Fr = Fe<FR>;
+        __shared__ Fr sm[POLY_THREADS];
+        const int p = blockIdx.x;
+        const uint32_t t = threadIdx.x;
+        Fr acc = Fr::zero();
+        for (uint32_t i = t; i < nblocks; i += POLY_THREADS) acc = acc + partial[p * nblocks + i];
+        sm[t] = acc;
         __syncthreads();
+        for (uint32_t d = POLY_THREADS / 2; d >= 1; d >>= 1) {
+            if (t < d) { acc = acc + sm[t + d]; sm[t] = acc; }
+            __syncthreads();
+        }
+        if (t == 0) result[p] = acc;
     }
-    if (t == 0) result[p] = acc;
-}
+};
+template <class FR>
+__global__ void __launch_bounds__(POLY_THREADS) eval_final_kernel(const Fe<FR>* __restrict__ partial, uint32_t nblocks,
+                                                                  Fe<FR>* __restrict__ result) { EvalFinalK<FR>::run(partial, nblocks, result); }
 
 // ---- (omega z)^i from z^i: out[i] = in[i] * omega^(+-i), one product per element where the square-and-multiply walk of
 // powers_kernel costs ~6.  twu[j] = omega^j in the radix R' for j < n / 2; omega^(n/2) = -1.  inverse: omega^-i = omega^(n - i mod n).
 template <class FR>
 struct DerivePowers { const Fe<FR>* in[2]; Fe<FR>* out[2]; int inverse[2]; };
 template <class FR>
-__global__ void __launch_bounds__(POLY_THREADS) derive_powers_kernel(DerivePowers<FR> a, const Fe<FR>* __restrict__ twu, uint32_t n, uint32_t count) {
-    wave_priority<APK_PRIO_FR>();
-    using Fr = Fe<FR>;
-    using U = FeU<FR>;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const int p = blockIdx.y;
-    uint32_t e = i & (n - 1u);                       // omega^n = 1
-    if (a.inverse[p]) e = (n - e) & (n - 1u);
-    const bool neg = e >= n / 2;
-    Fr w = twu[e & (n / 2 - 1u)], v = a.in[p][i];
-    U r = U::template canon<1>(U::mul_nr(U::unpack(w.l), U::unpack(v.l)));
-    Fr o;
-    r.pack(o.l);
-    if (neg) o = Fr::neg(o);
-    a.out[p][i] = o;
-}
+struct DerivePowersK {
+    static __device__ __forceinline__ void run(DerivePowers<FR> a, const Fe<FR>* __restrict__ twu, uint32_t n, uint32_t count) {
+        wave_priority<APK_PRIO_FR>();
+        using Fr = Fe<FR>;
+        using U = FeU<FR>;
+        const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= count) return;
+        const int p = blockIdx.y;
+        uint32_t e = i & (n - 1u);                       // omega^n = 1
+        if (a.inverse[p]) e = (n - e) & (n - 1u);
+        const bool neg = e >= n / 2;
+        Fr w = twu[e & (n / 2 - 1u)], v = a.in[p][i];
+        U r = U::template canon<1>(U::mul_nr(U::unpack(w.l), U::unpack(v.l)));
+        Fr o;
+        r.pack(o.l);
+        if (neg) o = Fr::neg(o);
+        a.out[p][i] = o;
+    }
+};
+template <class FR>
+__global__ void __launch_bounds__(POLY_THREADS) derive_powers_kernel(DerivePowers<FR> a, const Fe<FR>* __restrict__ twu, uint32_t n, uint32_t count) { DerivePowersK<FR>::run(a, twu, n, count); }
 
 // ---- out[i] = sum_k coef[k] * f_k[i]  (linearised polynomial, folded opening polynomial) -------------------
 constexpr int LC_MAX = 20;   // folded opening polynomial: 11 + k terms of the linearised polynomial, 5 + k folded ones (k <= 2)
@@ -455,56 +521,74 @@ struct LinCombArgs {
 };
 
 template <class FR>
-__global__ void __launch_bounds__(POLY_THREADS) lincomb_kernel(LinCombArgs<FR> a, Fe<FR>* __restrict__ out) {
-    wave_priority<APK_PRIO_FR>();
-    using Fr = Fe<FR>;
-    // unsaturated limbs, lazily (like the quotient kernel): the coefficients arrive as 32 c (the product's radix R' = 32 R), every
-    // product is below 2 r, up to LC_MAX of them add up below 64 r, ONE canonicalisation at the end - 206 instead of ~300
-    // instructions per term
-    using U = FeU<FR>;
-    static_assert(U::HEADROOM >= 64 && LC_MAX * 2 <= 64, "the sum of LC_MAX products below 2 r each must stay below 64 r");
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.out_len) return;
-    U acc = U::zero();
-    for (int k = 0; k < a.count; k++)
-        if (i < a.len[k]) { Fr v = a.f[k][i]; acc = U::add_n(acc, U::mul_nr(U::unpack(a.coef[k].l), U::unpack(v.l))); }
-    const U res = U::template canon<32>(acc);
-    Fr w;
-    res.pack(w.l);
-    out[i] = w;
-}
+struct LincombK {
+    static __device__ __forceinline__ void run(LinCombArgs<FR> a, Fe<FR>* __restrict__ out) {
+        wave_priority<APK_PRIO_FR>();
+        using Fr = Fe<FR>;
+        // unsaturated limbs, lazily (like the quotient kernel): the coefficients arrive as 32 c (the product's radix R' = 32 R), every
+        // product is below 2 r, up to LC_MAX of them add up below 64 r, ONE canonicalisation at the end - 206 instead of ~300
+        // instructions per term
+        using U = FeU<FR>;
+        static_assert(U::HEADROOM >= 64 && LC_MAX * 2 <= 64, "the sum of LC_MAX products below 2 r each must stay below 64 r");
+        uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= a.out_len) return;
+        U acc = U::zero();
+        for (int k = 0; k < a.count; k++)
+            if (i < a.len[k]) { Fr v = a.f[k][i]; acc = U::add_n(acc, U::mul_nr(U::unpack(a.coef[k].l), U::unpack(v.l))); }
+        const U res = U::template canon<32>(acc);
+        Fr w;
+        res.pack(w.l);
+        out[i] = w;
+    }
+};
+template <class FR>
+__global__ void __launch_bounds__(POLY_THREADS) lincomb_kernel(LinCombArgs<FR> a, Fe<FR>* __restrict__ out) { LincombK<FR>::run(a, out); }
 
 // q[j] = zinv_pw[j+1] * suffix[j+1], j < len-1   where suffix[i] = sum_{k>=i} f[k] z^k
 template <class FR>
-__global__ void __launch_bounds__(POLY_THREADS) div_finish_kernel(const Fe<FR>* __restrict__ suffix,
+struct DivFinishK {
+    static __device__ __forceinline__ void run(const Fe<FR>* __restrict__ suffix,
                                                                   const Fe<FR>* __restrict__ zinv_pw, uint32_t len,
                                                                   Fe<FR>* __restrict__ q) {
-    wave_priority<APK_PRIO_FR>();
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j + 1 >= len) return;
-    q[j] = suffix[j + 1] * zinv_pw[j + 1];
-}
+        wave_priority<APK_PRIO_FR>();
+        uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+        if (j + 1 >= len) return;
+        q[j] = suffix[j + 1] * zinv_pw[j + 1];
+    }
+};
+template <class FR>
+__global__ void __launch_bounds__(POLY_THREADS) div_finish_kernel(const Fe<FR>* __restrict__ suffix,
+                                                                  const Fe<FR>* __restrict__ zinv_pw, uint32_t len,
+                                                                  Fe<FR>* __restrict__ q) { DivFinishK<FR>::run(suffix, zinv_pw, len, q); }
 
 // The quotient is a polynomial of degree < 3(n+2) iff the witness satisfies the circuit: OR-reduce ALL the words of the
 // coefficients above it (h[3(n+2) .. 4n)).  A non-zero word stamps the proof's epoch into *flag (atomicMax: no zeroing between
 // proofs, nothing is written in the normal case); the host compares the flag with the epoch after the stream sync.
 template <int DUMMY>
-__global__ void __launch_bounds__(256) tail_nonzero_kernel(const uint4* __restrict__ words, uint32_t count4, uint32_t epoch, uint32_t* __restrict__ flag) {
-    uint32_t acc = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += gridDim.x * blockDim.x) {
-        const uint4 v = words[i];
-        acc |= v.x | v.y | v.z | v.w;
+struct TailNonzeroK {
+    static __device__ __forceinline__ void run(const uint4* __restrict__ words, uint32_t count4, uint32_t epoch, uint32_t* __restrict__ flag) {
+        uint32_t acc = 0;
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += gridDim.x * blockDim.x) {
+            const uint4 v = words[i];
+            acc |= v.x | v.y | v.z | v.w;
+        }
+        // every writer stores the same word (the slot's epochs only grow and its proofs run one after the other), so a plain store
+        // does: `flag` may be host memory, where a device atomic is not a given
+        if (__ballot(acc != 0) != 0 && (threadIdx.x & 63) == 0) *reinterpret_cast<volatile uint32_t*>(flag) = epoch;
     }
-    // every writer stores the same word (the slot's epochs only grow and its proofs run one after the other), so a plain store
-    // does: `flag` may be host memory, where a device atomic is not a given
-    if (__ballot(acc != 0) != 0 && (threadIdx.x & 63) == 0) *reinterpret_cast<volatile uint32_t*>(flag) = epoch;
-}
+};
+template <int DUMMY>
+__global__ void __launch_bounds__(256) tail_nonzero_kernel(const uint4* __restrict__ words, uint32_t count4, uint32_t epoch, uint32_t* __restrict__ flag) { TailNonzeroK<DUMMY>::run(words, count4, epoch, flag); }
 
 // z == 0 fallback: q[j] = f[j+1]
 template <class FR>
-__global__ void shift_down_kernel(const Fe<FR>* __restrict__ f, uint32_t len, Fe<FR>* __restrict__ q) {
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j + 1 < len) q[j] = f[j + 1];
-}
+struct ShiftDownK {
+    static __device__ __forceinline__ void run(const Fe<FR>* __restrict__ f, uint32_t len, Fe<FR>* __restrict__ q) {
+        uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+        if (j + 1 < len) q[j] = f[j + 1];
+    }
+};
+template <class FR>
+__global__ void shift_down_kernel(const Fe<FR>* __restrict__ f, uint32_t len, Fe<FR>* __restrict__ q) { ShiftDownK<FR>::run(f, len, q); }
 
 }  // namespace apk

@@ -444,7 +444,8 @@ typedef struct {
     uint64_t gang_proofs;               /* proofs made as members of a gang (two to four proofs sharing one stream and its MSM / NTT launches) */
     uint64_t gang_msm_launches;         /* MSM launch sequences that carried the batches of more than one proof */
     uint64_t gang_ntt_launches;         /* NTT launch sequences that carried the transforms of more than one proof */
-    uint64_t reserved[3];
+    uint64_t gang_kernel_launches;      /* other kernels (grand product, quotient, evaluations, openings ...) launched once for several proofs */
+    uint64_t reserved[2];
 } apk_path_counts;
 int apk_paths_read(apk_ctx* ctx, apk_path_counts* out, int reset);
 

@@ -217,7 +217,7 @@ def test_ganged_proofs_match_the_c_oracle(gpu, cname, log_n, gang, monkeypatch):
         p = pk.paths(reset=True)
         assert p["proofs"] == (T - 1) * rounds
         assert p["gang_proofs"] >= p["proofs"] // 2, p                      # most proofs were made as gang members ...
-        assert p["gang_msm_launches"] >= 1 and p["gang_ntt_launches"] >= 1, p
+        assert p["gang_msm_launches"] >= 1 and p["gang_ntt_launches"] >= 1 and p["gang_kernel_launches"] >= 1, p
         assert p["msm_batches"] < 4 * p["proofs"], p                        # ... in fewer launch sequences than four per proof
     # alone on the same context: no gang, the latency forms, the same bytes
     pr = _lib.Proof()

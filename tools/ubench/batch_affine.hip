@@ -18,7 +18,14 @@
 #include <vector>
 #include "ec.h"
 
+// -DUBENCH_BLS21 (round 6): the regime the round-3 analysis named as the one where batch-affine COULD pay - BLS12-381 (3 771
+// instructions per XYZZ addition against ~2 300 for 5 products + 1 square), 2^21 bases x 14 windows of 19 bits = a 2.8 GB table that
+// no cache holds, 64-entry units in the XYZZ loop, K = 64 .. 512 additions per lane and inversion.
+#ifdef UBENCH_BLS21
+using FP = FpBLS12381;
+#else
 using FP = FpBN254;
+#endif
 using F = FeU<FP>;
 using PT = XYZZ<FP, F>;
 using Rec = Affine<FP>;
@@ -80,12 +87,21 @@ static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
 static uint32_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (uint32_t)(rng_state >> 16); }
 
 int main() {
+#ifdef UBENCH_BLS21
+    const uint32_t n = 1u << 21, W = 14, table_n = n * W;               // the 2.8 GB windowed table of a 2^21 BLS12-381 context (c = 19)
+#else
     const uint32_t n = 1u << 17, W = 16, table_n = n * W;               // the 134 MB windowed table of a 2^17 BN254 context
+#endif
+    constexpr int NL = FP::N;
     std::vector<Rec> h_table(table_n);
-    for (auto& r : h_table) for (int i = 0; i < 8; i++) { r.x.l[i] = rnd() & (i == 7 ? 0x1fffffffu : ~0u); r.y.l[i] = rnd() & (i == 7 ? 0x1fffffffu : ~0u); }
+    for (auto& r : h_table) for (int i = 0; i < NL; i++) { r.x.l[i] = rnd() & (i == NL - 1 ? 0x0fffffffu : ~0u); r.y.l[i] = rnd() & (i == NL - 1 ? 0x0fffffffu : ~0u); }
     Rec* d_table; HCHK(hipMalloc(&d_table, sizeof(Rec) * table_n)); HCHK(hipMemcpy(d_table, h_table.data(), sizeof(Rec) * table_n, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; HCHK(hipEventCreate(&e0)); HCHK(hipEventCreate(&e1));
+#ifdef UBENCH_BLS21
+    for (uint32_t mult : {1u, 3u}) {     // one MSM, a batch of three (29 M / 88 M additions: the device is saturated either way)
+#else
     for (uint32_t mult : {1u, 8u}) {
+#endif
         const uint64_t adds = (uint64_t)table_n * mult;                   // one MSM = n * W additions
         std::vector<uint32_t> h_idx(adds * 2);
         for (auto& v : h_idx) v = (rnd() % table_n) | (rnd() & 0x80000000u);
@@ -102,9 +118,15 @@ int main() {
             ms /= reps;
             printf("%-44s x%u MSM: %8.3f ms  %7.2f G additions/s%s\n", name, mult, ms, adds / (ms * 1e-3) / 1e9, extra < 0 ? "" : "");
         };
+#ifdef UBENCH_BLS21
+        const uint32_t unit = 64, units = (uint32_t)(adds / unit);
+        timeit([&] { xyzz_kernel<<<(units + 127) / 128, 128>>>(d_table, d_idx, units, unit, (PT*)d_out); }, "xyzz  (madd_lazy, 64 per lane)", -1);
+        for (uint32_t K : {32u, 64u, 128u, 256u, 512u}) {
+#else
         const uint32_t unit = 16, units = (uint32_t)(adds / unit);
         timeit([&] { xyzz_kernel<<<(units + 127) / 128, 128>>>(d_table, d_idx, units, unit, (PT*)d_out); }, "xyzz  (madd_lazy, 16 per lane)", -1);
         for (uint32_t K : {8u, 16u, 32u, 64u, 256u}) {
+#endif
             const uint32_t lanes = (uint32_t)(adds / K);
             char nm[96];
             snprintf(nm, sizeof nm, "affine K=%-3u no inversion (batch -> inf)", K);
