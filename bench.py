@@ -74,7 +74,7 @@ def parse_args(argv=None):
                          "workloads.skewed_circuit; the default run reports the bit-heavy rate beside the headline (`witness_bits`)")
     ap.add_argument("--witnesses", type=int, default=0,
                     help="distinct assignments of the circuit the concurrent callers prove (every caller walks through all of them; "
-                         "default 16 up to 2^18, 8 at 2^19, 4 from 2^20; never more than --inflight)")
+                         "default 16 up to 2^18, 8 at 2^19, 2 from 2^20 - generating an assignment of a 2^21 circuit takes the Python harness half a minute; never more than --inflight)")
     ap.add_argument("--no-oracle-check", action="store_true",
                     help="skip the per-witness comparison of the timed region's proofs with the C oracle's (bench_cpu.oracle_blobs)")
     ap.add_argument("--no-host-inputs", action="store_true", help="skip the apk_prove (host pointers) legs")
@@ -347,6 +347,33 @@ def pmc_traffic(curve: str, log_n: int, window: int, timeout_s: float = 420.0):
             res["valu_int64_share"] = out["SQ_INSTS_VALU_INT64"][0] / max(out["SQ_INSTS_VALU"][0], 1.0)
             res["valu_int32_share"] = out.get("SQ_INSTS_VALU_INT32", (0.0, 0))[0] / max(out["SQ_INSTS_VALU"][0], 1.0)
     return res
+
+
+def pmc_valu_per_proof(curve: str, log_n: int, callers: int, bsb22: int, timeout_s: float = 300.0):
+    """VALU wave instructions of ONE proof made under load (the loaded forms of the kernels, gangs included), measured NOW: two
+    rocprofv3 --pmc SQ_INSTS_VALU runs of tools/prof_loaded_proofs.py that differ by 2 x callers proofs; the difference of their
+    totals over every kernel / the proofs in between.  None when rocprofv3 is missing or a run fails."""
+    if not shutil.which("rocprofv3"):
+        return None
+    import sqlite3
+    import tempfile
+    env = dict(os.environ, TMPDIR="/tmp")
+    tot = {}
+    for rounds in (1, 3):
+        d = tempfile.mkdtemp(prefix="apk_pmcv_", dir="/tmp")
+        try:
+            subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", "SQ_INSTS_VALU", "-d", d, "-o", "p", "--", sys.executable,
+                            os.path.join(ROOT, "tools", "prof_loaded_proofs.py"), curve, str(log_n), str(callers), str(rounds), str(bsb22)],
+                           cwd="/tmp", env=env, capture_output=True, timeout=timeout_s, check=True)
+            dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("_results.db")]
+            db = sqlite3.connect(dbs[0])
+            tot[rounds] = sum(v for (v,) in db.execute("select value from counters_collection where counter_name = 'SQ_INSTS_VALU'"))
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    proofs = 2 * callers
+    return {"wave_instructions_per_proof": (tot[3] - tot[1]) / proofs, "proofs_between_the_runs": proofs, "callers": callers}
 
 
 # ---------------------------------------------------------------------------------------------------- modes
@@ -647,7 +674,7 @@ def extra_rooflines(args, cv, st, value_per_rank: float, lat_stats_ms: float) ->
 
 
 def default_witnesses(args) -> int:
-    k = args.witnesses or (16 if args.log_n <= 18 else 8 if args.log_n == 19 else 4)
+    k = args.witnesses or (16 if args.log_n <= 18 else 8 if args.log_n == 19 else 2)
     return max(1, min(k, args.inflight))
 
 
@@ -822,6 +849,18 @@ def bench_prove(args, cv, rk) -> None:
             cpu_baseline["go_probe"] = probe
     roofline = roofline_from_stats(args, cv, st, pmc, valu_issue_rate() if (rk.rank == 0 and pmc) else None)
     roofline.update(extra_rooflines(args, cv, st, value / rk.world, lat_stats_ms))
+    # the whole device under load against its VALU issue rate: instructions of a proof made under load (counter runs of this
+    # invocation) x proofs/s, priced at the issue rate of the accumulate kernel's instruction mix (the bulk of them)
+    v1 = roofline.get("valu") or {}
+    if rk.rank == 0 and rk.world == 1 and pmc and v1.get("ns_per_wave_instruction_per_simd"):
+        vp = pmc_valu_per_proof(args.curve, args.log_n, args.inflight, args.bsb22, timeout_s=300.0 if args.log_n < 20 else 2400.0)
+        if vp:
+            bound = v1["simds"] / (vp["wave_instructions_per_proof"] * v1["ns_per_wave_instruction_per_simd"] * 1e-9)
+            roofline["valu_under_load"] = {"wave_instructions_per_proof": round(vp["wave_instructions_per_proof"], 1),
+                                           "ns_per_wave_instruction_per_simd": v1["ns_per_wave_instruction_per_simd"], "simds": v1["simds"],
+                                           "issue_bound_proofs_per_s": round(bound, 2), "proofs_per_s": round(value, 2), "frac": round(value / bound, 4),
+                                           "basis": "SQ_INSTS_VALU over every kernel of %d proofs made by %d concurrent callers (two counter runs of this invocation, "
+                                                    "their difference) x this run's proofs/s, at the issue rate of the accumulate kernel's instruction mix" % (vp["proofs_between_the_runs"], vp["callers"])}
     plane = rk.data_plane_probe(pk.ctx)
 
     # ---- parity of everything this run produced.  Per assignment a: the lone proof's hash; every proof made under load for a (the
