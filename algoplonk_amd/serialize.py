@@ -3,10 +3,9 @@
 `utils.SerializeCompiledCircuit` gob-encodes `CompiledCircuitBytes{Ccs, Pk, Vk []byte; Curve ecc.ID}` where the three byte
 slices are gnark's `WriteTo` outputs; `DeserializeCompiledCircuit` reverses it.  This module mirrors those two functions
 (same names) and the layers underneath.  WHAT IS INTEROPERABLE WITH A GO PROCESS TODAY: the gob envelope and the kzg SRS
-encodings (pinned by the reference's own files).  What is NOT: the plonk Vk / Pk blobs (restated from memory, unpinned - and
-gnark's list very likely also carries the KZG verifying key's precomputed pairing lines `Kzg.Lines` between Kzg.G2[1] and
-CommitmentConstraintIndexes, which this writer does not emit; the reader skips a block of exactly that size when the key's
-length fits no other way, and says so in `vk.kzg_lines_bytes`) and the
+encodings (pinned by the reference's own files).  What is NOT: the plonk Vk / Pk blobs (restated from memory, unpinned: the reader
+accepts exactly what this writer emits and refuses everything else - round 6 removed the tolerance for a guessed `Kzg.Lines`
+block: no layout this package cannot pin is read) and the
 constraint system (own tagged encoding; gnark's file is CBOR + intcomp-compressed blocks).  Files written
 here are therefore read back HERE; a circuit compiled by Go reaches libapk through the cgo shim, not a file.
 
@@ -250,18 +249,12 @@ def write_plonk_vk(vk: plonk.VerifyingKey) -> bytes:
     return out
 
 
-# kzg.VerifyingKey.Lines (gnark-crypto >= 0.12: the precomputed pairing lines of G2[0] and G2[1], [2][2][len(LoopCounter) - 1]
-# LineEvaluationAff{R0, R1 E2}, written as raw Fp words without a length prefix) [UPSTREAM, sizes from memory: unpinned].  This
-# package neither writes nor uses them (apk_verify derives its own lines); the reader TOLERATES a block of exactly this size
-# between Kzg.G2[1] and CommitmentConstraintIndexes, because a key written by gnark (tools/gnark_dump's vk_write_to) very likely
-# carries it - and only when the key's total length fits that layout exactly; it reports what it did in `vk.kzg_lines_bytes`.
-KZG_LINES_BYTES = {"bn254": 2 * 2 * 65 * 4 * 32, "bls12_381": 2 * 2 * 63 * 4 * 48}
-
-
 def read_plonk_vk(cv: ecc.ID, r: io.BytesIO, embedded: bool = False) -> plonk.VerifyingKey:
-    """embedded = False: the key is everything that is left in `r` (a vk file) and the layout follows from the REMAINING LENGTH;
-    embedded = True: the key is followed by more data (inside a proving key: kzg.ProvingKey next, whose point count must be
-    Size + 3) and the layout is the one whose continuation is well formed."""
+    """Reads what write_plonk_vk wrote - and nothing else.  embedded = False: the key is everything that is left in `r` (a vk
+    file): its length must be exactly this layout's; embedded = True: the key is followed by more data (inside a proving key: the
+    kzg.ProvingKey, whose point count must be Size + 3).  A key in any other layout - e.g. one written by gnark, whose list very
+    likely carries more fields (the KZG key's precomputed pairing lines) - is refused: the plonk key layout is UNPINNED here
+    (tools/gnark_dump + tests/test_gnark_dump.py settle it where Go exists), and nothing unpinned is guessed at."""
     fr = lambda: int.from_bytes(r.read(32), "big")
     g1 = lambda: setup.decompress_g1(cv, r.read(cv.fp_bytes))
     (size,) = struct.unpack(">Q", r.read(8))
@@ -275,48 +268,26 @@ def read_plonk_vk(cv: ecc.ID, r: io.BytesIO, embedded: bool = False) -> plonk.Ve
     kg1 = g1()
     w = 2 * cv.fp_bytes
     g2 = _g2_decompress(cv, r.read(w)) + _g2_decompress(cv, r.read(w))
-    # with or without Kzg.Lines in front of CommitmentConstraintIndexes (u32 count + count x u64; one index per Qcp)
     here = r.tell()
-    tail = 4 + 8 * nq
-    LB = KZG_LINES_BYTES[cv.name]
-
-    def well_formed(skip: int) -> bool:
-        r.seek(here + skip)
-        head = r.read(4)
-        if len(head) != 4 or struct.unpack(">I", head)[0] != nq:
-            return False
-        if not embedded:
-            return True
-        r.seek(here + skip + tail)
+    tail = 4 + 8 * nq                                     # CommitmentConstraintIndexes: u32 count + count x u64, one index per Qcp
+    head = r.read(4)
+    ok = len(head) == 4 and struct.unpack(">I", head)[0] == nq
+    if ok and not embedded:
+        ok = len(r.getbuffer()) - here == tail
+    if ok and embedded:
+        r.seek(here + tail)
         nxt = r.read(4)                                   # kzg.ProvingKey: its G1 count is Size + 3 (setup/setup.go:113-114)
-        return len(nxt) == 4 and struct.unpack(">I", nxt)[0] == size + 3
-
-    if not embedded:
-        remaining = len(r.getbuffer()) - here
-        if remaining == tail and well_formed(0):
-            lines_bytes = 0
-        elif remaining == LB + tail and well_formed(LB):
-            lines_bytes = LB
-        else:
-            raise ValueError("plonk verifying key: %d bytes left after Kzg.G2, expected %d (CommitmentConstraintIndexes of %d entries) "
-                             "or %d (a Kzg.Lines block first): the plonk key layout here is unpinned" % (remaining, tail, nq, LB + tail))
-    elif well_formed(0):
-        lines_bytes = 0
-    elif well_formed(LB):
-        lines_bytes = LB
-    else:
-        raise ValueError("plonk verifying key: no CommitmentConstraintIndexes list of %d entries followed by a kzg proving key of %d "
-                         "points after Kzg.G2 (with or without a %d-byte Kzg.Lines block): the plonk key layout here is unpinned"
-                         % (nq, size + 3, LB))
-    r.seek(here + lines_bytes + 4)
-    nc = nq
-    cci = [struct.unpack(">Q", r.read(8))[0] for _ in range(nc)]
+        ok = len(nxt) == 4 and struct.unpack(">I", nxt)[0] == size + 3
+    if not ok:
+        raise ValueError("plonk verifying key: what follows Kzg.G2 is not this package's layout (a CommitmentConstraintIndexes list of %d "
+                         "entries%s): the plonk key layout here is unpinned and keys written elsewhere are not read"
+                         % (nq, " and then a kzg proving key of %d points" % (size + 3) if embedded else ", then the end of the key"))
+    r.seek(here + 4)
+    cci = [struct.unpack(">Q", r.read(8))[0] for _ in range(nq)]
     if size == 0 or size & (size - 1) or size_inv * size % cv.r != 1 or pow(gen, size, cv.r) != 1:
         raise ValueError("plonk verifying key: inconsistent domain fields")
-    vk = plonk.VerifyingKey(curve=cv, Size=size, SizeInv=size_inv, Generator=gen, CosetShift=shift, NbPublicVariables=nbp, Ql=ql, Qr=qr,
-                            Qm=qm, Qo=qo, Qk=qk, S=S, Qcp=qcp, CommitmentConstraintIndexes=cci, KzgG1=kg1, tau=None, KzgG2=g2)
-    vk.kzg_lines_bytes = lines_bytes          # 0, or the size of the block that was skipped (not interpreted)
-    return vk
+    return plonk.VerifyingKey(curve=cv, Size=size, SizeInv=size_inv, Generator=gen, CosetShift=shift, NbPublicVariables=nbp, Ql=ql, Qr=qr,
+                              Qm=qm, Qo=qo, Qk=qk, S=S, Qcp=qcp, CommitmentConstraintIndexes=cci, KzgG1=kg1, tau=None, KzgG2=g2)
 
 
 def write_plonk_pk(vk: plonk.VerifyingKey, srs: setup.SRS) -> bytes:
