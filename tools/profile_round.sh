@@ -4,18 +4,23 @@
 TAG=${1:-rXX}
 O=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout 400 python bench.py > $O/${TAG}_bench_bn254_2p17.log 2>&1; tail -1 $O/${TAG}_bench_bn254_2p17.log > $O/${TAG}_bench_bn254_2p17.json
-timeout 300 python bench.py --curve bls12_381 --log-n 14 > $O/${TAG}_bench_bls12381_2p14.log 2>&1; tail -1 $O/${TAG}_bench_bls12381_2p14.log > $O/${TAG}_bench_bls12381_2p14.json
-timeout 1500 python bench.py --curve bls12_381 --log-n 21 --bsb22 1 --inflight 8 --steps 4 --warmup 1 $BLS21_FLAGS > $O/${TAG}_bench_bls12381_2p21_bsb22.log 2>&1; tail -1 $O/${TAG}_bench_bls12381_2p21_bsb22.log > $O/${TAG}_bench_bls12381_2p21_bsb22.json
+timeout 600 python bench.py > $O/${TAG}_bench_bn254_2p17.log 2>&1; tail -1 $O/${TAG}_bench_bn254_2p17.log > $O/${TAG}_bench_bn254_2p17.json
+timeout 500 python bench.py --curve bls12_381 --log-n 14 > $O/${TAG}_bench_bls12381_2p14.log 2>&1; tail -1 $O/${TAG}_bench_bls12381_2p14.log > $O/${TAG}_bench_bls12381_2p14.json
+timeout 3000 python bench.py --curve bls12_381 --log-n 21 --bsb22 1 --inflight 8 --steps 4 --warmup 1 $BLS21_FLAGS > $O/${TAG}_bench_bls12381_2p21_bsb22.log 2>&1; tail -1 $O/${TAG}_bench_bls12381_2p21_bsb22.log > $O/${TAG}_bench_bls12381_2p21_bsb22.json
+timeout 500 python bench.py --curve bls12_381 --log-n 14 --inflight 64 > $O/${TAG}_bench_bls12381_2p14_64callers.log 2>&1; tail -1 $O/${TAG}_bench_bls12381_2p14_64callers.log > $O/${TAG}_bench_bls12381_2p14_64callers.json
 timeout 200 python bench.py --mode msm-sharded --steps 50 > $O/${TAG}_bench_msm_sharded.log 2>&1; tail -1 $O/${TAG}_bench_msm_sharded.log > $O/${TAG}_bench_msm_sharded.json
 timeout 200 python bench.py --mode prove-split --curve bls12_381 --log-n 21 --steps 5 --warmup 1 > $O/${TAG}_bench_prove_split_2p21.log 2>&1; tail -1 $O/${TAG}_bench_prove_split_2p21.log > $O/${TAG}_bench_prove_split_2p21.json
 # kernel traces: one proof at a time (sequential) and the bench's 32 callers (saturated)
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_kt1 -o r -- python bench.py --inflight 1 --steps 8 --warmup 2 --no-cpu-baseline --no-pmc > $O/${TAG}_kt1.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_kt1 -o r -- python bench.py --inflight 1 --steps 8 --warmup 2 --no-cpu-baseline --no-pmc --no-oracle-check > $O/${TAG}_kt1.log 2>&1
 python tools/rocprof_summary.py $O/${TAG}_kt1/r_results.db > $O/${TAG}_kernel_trace_bn254_2p17.txt
 grep '"metric"' $O/${TAG}_kt1.log | tail -1 > $O/${TAG}_kernel_trace_bn254_2p17_benchline.json
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_kt24 -o r -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc > $O/${TAG}_kt24.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_kt24 -o r -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --no-oracle-check --no-host-inputs > $O/${TAG}_kt24.log 2>&1
 python tools/rocprof_summary.py $O/${TAG}_kt24/r_results.db > $O/${TAG}_kernel_trace_bn254_2p17_saturated.txt
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_ktbls -o r -- python bench.py --curve bls12_381 --log-n 14 --inflight 1 --steps 8 --warmup 2 --no-cpu-baseline --no-pmc > $O/${TAG}_ktbls.log 2>&1
+python tools/stream_timeline.py $O/${TAG}_kt24/r_results.db 150 60 > $O/${TAG}_streams_bn254_2p17_saturated.txt
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_ktbls64 -o r -- python bench.py --curve bls12_381 --log-n 14 --inflight 64 --steps 6 --warmup 1 --no-cpu-baseline --no-pmc --no-host-inputs --no-oracle-check > $O/${TAG}_ktbls64.log 2>&1
+python tools/rocprof_summary.py $O/${TAG}_ktbls64/r_results.db > $O/${TAG}_kernel_trace_bls12381_2p14_gangs.txt
+python tools/stream_timeline.py $O/${TAG}_ktbls64/r_results.db 100 60 > $O/${TAG}_streams_bls12381_2p14_gangs.txt
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_ktbls -o r -- python bench.py --curve bls12_381 --log-n 14 --inflight 1 --steps 8 --warmup 2 --no-cpu-baseline --no-pmc --no-oracle-check > $O/${TAG}_ktbls.log 2>&1
 python tools/rocprof_summary.py $O/${TAG}_ktbls/r_results.db > $O/${TAG}_kernel_trace_bls12381_2p14.txt
 # PMC passes (one counter group per pass, kernel trace only: no other trace domains).  Every pass leaves its per-kernel table as
 # text AND as JSON (with prof_msm.py's facts about the run); tools/pmc_accumulate.py writes the summary FROM those.
@@ -48,5 +53,5 @@ timeout 300 rocprofv3 --kernel-trace -d /tmp/${TAG}_tl17 -o r -- python tools/pr
 python tools/timeline.py $(find /tmp/${TAG}_tl17 -name r_results.db | head -1) 3.35 > $O/${TAG}_timeline_bn254_2p17.txt
 timeout 300 rocprofv3 --kernel-trace -d /tmp/${TAG}_tl14 -o r -- python tools/prof_msm.py 14 0 4 bls12_381 > /dev/null 2>&1
 python tools/timeline.py $(find /tmp/${TAG}_tl14 -name r_results.db | head -1) 2.85 > $O/${TAG}_timeline_bls12381_2p14.txt
-rm -rf $O/${TAG}_kt1 $O/${TAG}_kt24 $O/${TAG}_ktbls $O/${TAG}_facts_*.json
+rm -rf $O/${TAG}_kt1 $O/${TAG}_kt24 $O/${TAG}_ktbls $O/${TAG}_ktbls64 $O/${TAG}_facts_*.json
 ls -la $O | grep ${TAG} | tail -40
