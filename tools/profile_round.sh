@@ -14,6 +14,11 @@ timeout 200 python bench.py --mode prove-split --curve bls12_381 --log-n 21 --st
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_kt1 -o r -- python bench.py --inflight 1 --steps 8 --warmup 2 --no-cpu-baseline --no-pmc --no-oracle-check > $O/${TAG}_kt1.log 2>&1
 python tools/rocprof_summary.py $O/${TAG}_kt1/r_results.db > $O/${TAG}_kernel_trace_bn254_2p17.txt
 grep '"metric"' $O/${TAG}_kt1.log | tail -1 > $O/${TAG}_kernel_trace_bn254_2p17_benchline.json
+# ... and twelve lone proofs and nothing else (tools/prof_msm.py): the population bench.py's HIP-event statistics time - the average
+# msm_accumulate_kernel duration of THIS table is the one to hold against the line's roofline.avg_launch_ms
+APK_PROF_SLOTS=32 timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_ktlone -o r -- python tools/prof_msm.py 17 0 12 > $O/${TAG}_ktlone.log 2>&1
+python tools/rocprof_summary.py $O/${TAG}_ktlone/r_results.db > $O/${TAG}_kernel_trace_bn254_2p17_lone_proofs.txt
+rm -rf $O/${TAG}_ktlone
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_kt24 -o r -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --no-oracle-check --no-host-inputs > $O/${TAG}_kt24.log 2>&1
 python tools/rocprof_summary.py $O/${TAG}_kt24/r_results.db > $O/${TAG}_kernel_trace_bn254_2p17_saturated.txt
 python tools/stream_timeline.py $O/${TAG}_kt24/r_results.db 150 60 > $O/${TAG}_streams_bn254_2p17_saturated.txt
