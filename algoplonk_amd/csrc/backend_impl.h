@@ -1287,7 +1287,8 @@ class CurveBackend : public Backend {
         // alone -> gangs of 2 (32 callers) -> gangs of 4 (64 callers):
         //   BN254 2^13  2 175 -> . -> 3 846     BN254 2^15  1 499 -> 1 763 -> 1 825     BLS12-381 2^14  1 376 -> 1 604 -> 1 746 .. 1 775
         //   BN254 2^16    958 -> 1 033 -> 1 026   BN254 2^17  538 -> 539 (VALU-bound: nothing left for wider launches to fill)
-        return log_n <= 15 ? 4 : log_n == 16 ? 2 : 1;
+        //   BLS12-381 2^15  852 -> 933 -> 961;  BLS12-381 2^16  501.6 -> 497.4 with pairs (neutral: off);  BN254 2^14  1 997 -> 2 704 -> 3 029
+        return log_n <= 15 ? 4 : (log_n == 16 && FPP::N <= 8) ? 2 : 1;
     }
     static Slot*& gang_member() { static thread_local Slot* p = nullptr; return p; }
     bool gangs_allowed() const {
