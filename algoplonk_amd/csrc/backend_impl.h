@@ -258,7 +258,8 @@ class CurveBackend : public Backend {
     HostFixedBase<FPP> vk_fixed_;   // host tables of [Ql][Qr][Qm][Qo][S3] for the [lin] combination (host_msm.h)
     std::vector<Slot*> slots_;
     // The context's streams: as many as it may run at a time (max 16), whichever of its slots lead.  A stream per SLOT - 32 slots
-    // for gangs of two - put 23 hardware queues to work within 150 ms and starved some of them for up to 90 ms.
+    // for gangs of two - put 23 hardware queues to work within 150 ms and starved some of them for up to 90 ms (with the spinning
+    // waits of that build on top: profiles/r06_gang_sweep.txt).
     std::vector<hipStream_t> stream_pool_;
     SlotGate gate_;            // who proves on which slot; its busy count picks the load-dependent kernel forms (slot_gate.h)
     // Host inputs (apk_prove: the call the cgo shim makes): a caller takes one of `in_sets_` BEFORE it takes a
@@ -1676,8 +1677,10 @@ class CurveBackend : public Backend {
         CHK(set_sort_lds_limits());
         // proving slots
         int nslots = d->slots > 0 ? d->slots : 1;
-        // more than 16 concurrently active streams collapse the throughput (24: -25 %, 32: -40 %, 48: -55 % at 2^17); callers
-        // beyond the cap wait for a slot, which also hides their host-side gaps
+        // 16 concurrently active streams are the optimum at 2^17 (round 6, sleeping waits: 12 -> 542, 16 -> 549, 20 -> 544, 24 -> 518
+        // proofs/s; the collapse rounds 2-5 measured beyond 16 - 24: -25 %, 32: -40 % - was mostly the cgroup freezing a process
+        // with more spinning proving threads than its 16-CPU quota); callers beyond the cap wait for a slot, which also hides
+        // their host-side gaps - or, on small circuits, join a gang
         static const int max_slots = env_int("APK_MAX_SLOTS", 16, 1, 64);
         // Gangs: a context asked for more slots than it may run streams lets up to gang_cap_ proofs share a stream (gang.h).
         // APK_GANG: 1 = never, 2..4 = members per stream; default by size (choose_gang).  The operands of a merged launch must fit

@@ -3,7 +3,7 @@
 //
 // Why: small circuits are latency-bound under load and the device has about 16 useful hardware queues.  At BLS12-381 2^14 a
 // commitment batch is 0.8 M bucket additions for 1 024 SIMDs, its reduction tail a chain of ~36 dependent point operations on a few
-// hundred waves; 16 such streams issue ~56 % of what the SIMDs could, and more streams fall off a cliff (20: -12 %).  A gang makes
+// hundred waves; 16 such streams issue ~56 % of what the SIMDs could, and more streams add little (32: +4.5 %).  A gang makes
 // every MSM / NTT launch of a stream G times as wide at the same number of launches and streams.
 //
 // How: the members stay ordinary apk_prove* callers, each running the unchanged prover on its own workspace (Slot).  What they

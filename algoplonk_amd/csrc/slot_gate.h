@@ -1,8 +1,8 @@
 // Which proving slot a caller gets, how many are taken, and who proves together: the piece of the backend's host-side threading that
 // has no GPU in it, kept on its own so that the sanitizer tier (tools/san/host_hammer.cpp, `make SAN=thread`) runs exactly this code.
 //
-// A context has `n` slots (one workspace each) and runs up to `max_streams` HIP streams at a time (more than ~16 active streams fall
-// off a cliff on this device: DESIGN.md section 9).  A caller takes a slot; callers beyond the slots wait their turn (SURVEY.md
+// A context has `n` slots (one workspace each) and runs up to `max_streams` HIP streams at a time (16 is the measured optimum at
+// 2^17; more cost a few percent: profiles/r06_gang_sweep.txt).  A caller takes a slot; callers beyond the slots wait their turn (SURVEY.md
 // section 8b: "safe to call concurrently from several goroutines").  The busy count is what the load-dependent kernel forms are
 // chosen from (backend_impl.h run_msm_body / run_ntt_batch / tail_fill).
 //

@@ -16,7 +16,8 @@
  * There is NO CPU fallback: every compute entry point fails with APK_ERR_HIP when no gfx950 device is
  * usable.  The oracle under oracle/ is test infrastructure and is never linked into this library.
  *
- * Runtime environment: a context runs up to 16 proofs concurrently, one HIP stream each.  ROCm maps streams onto
+ * Runtime environment: a context runs up to 16 HIP streams at a time - one proof each, or (circuits up to 2^16, more callers
+ * than streams) a gang of two to four proofs that share a stream and its launches.  ROCm maps streams onto
  * GPU_MAX_HW_QUEUES hardware queues (default 4), read ONCE when the HIP runtime initialises; with 4 the streams serialise
  * (-20 % proofs/s measured).  The library therefore sets GPU_MAX_HW_QUEUES=24 when it is loaded, unless the variable is
  * already set.  A host process that initialises HIP BEFORE loading libapk (another GPU library, torch ...) must export

@@ -8,15 +8,13 @@ p=d["paths_under_load"]
 print("$1 2^$2 gang=$3 inflight=$4 $5: %.1f proofs/s  lone %.3f ms  gang_proofs %d/%d msm_batches %d ok=%s cpu=%s" % (d["value"], d["proof_latency_ms"], p["gang_proofs"], p["proofs"], p["msm_batches"], d["proofs_under_load_match_lone_proofs"], d.get("host_cpu_timed_region")))
 PY
 }
-run bls12_381 15 1 32
-run bls12_381 15 4 32
-run bls12_381 15 4 64
-run bls12_381 16 1 32
-run bls12_381 16 2 32
-run bls12_381 17 1 32
-run bls12_381 17 2 32
-run bn254 14 1 32
-run bn254 14 4 32
-run bn254 14 4 64
-run bn254 12 1 32
-run bn254 12 4 64
+run bn254 17 1 32
+run bn254 17 1 32 APK_MAX_SLOTS=20
+run bn254 17 1 32 APK_MAX_SLOTS=24
+run bn254 17 1 32 "APK_MAX_SLOTS=32 GPU_MAX_HW_QUEUES=40"
+run bn254 17 1 32 APK_MAX_SLOTS=12
+run bls12_381 14 1 32 APK_MAX_SLOTS=16
+run bls12_381 14 1 32 APK_MAX_SLOTS=24
+run bls12_381 14 1 32 "APK_MAX_SLOTS=32 GPU_MAX_HW_QUEUES=40"
+run bls12_381 14 4 64 "APK_MAX_SLOTS=24"
+run bls12_381 14 4 64 "APK_MAX_SLOTS=32 GPU_MAX_HW_QUEUES=40"
