@@ -225,6 +225,8 @@ class CurveBackend : public Backend {
     // NTT tables hold w * R' (R' = 2^261, the radix of the tile arithmetic: kernels_ntt.h); tw_n_ = omega^i in gnark's radix
     // is what the grand product and the permutation columns read
     DevBuf tw_n_, twu_n_, twi_n_, tw_4n_, twi_4n_, coset_pre_, coset_post_inv_, scales_;  // scales_: [1/n, 1/(4n)]
+    DevBuf twu_n_x_, twi_n_x_, tw_4n_x_, twi_4n_x_;   // the four transform tables once more as FeU records (ntt_pass_kernel<.., TWU>); built with APK_NTT_TWU=1 (default 0: measured neutral)
+    bool ntt_twu_ = false;
     DevBuf x4_, l0_4_;
     DevBuf s_lag_[3], ql_c_, qr_c_, qm_c_, qo_c_, qk_c_, s_c_[3], qcp_c_[APK_MAX_COMMITMENTS];
     DevBuf qk_lag_trace_;
@@ -366,6 +368,7 @@ class CurveBackend : public Backend {
         if (count < 1 || count > NTT_ARGS_MAX) { set_error("ntt: batch of %d", count); return APK_ERR_ARG; }
         const int log_n = (which ? (int)log_n_ + 2 : (int)log_n_) - sub_log;
         const Fr* tw = which ? (inverse ? ptr<Fr>(twi_4n_) : ptr<Fr>(tw_4n_)) : (inverse ? ptr<Fr>(twi_n_) : ptr<Fr>(twu_n_));
+        if (ntt_twu_) tw = which ? (inverse ? ptr<Fr>(twi_4n_x_) : ptr<Fr>(tw_4n_x_)) : (inverse ? ptr<Fr>(twi_n_x_) : ptr<Fr>(twu_n_x_));
         // small transforms are latency-bound: 512-element tiles (18 KiB LDS) give >= 256 workgroups at 2^17.  Large ones were
         // assumed bandwidth-bound (2048-element tiles, fewest passes) until round 3 measured them: at 2^21 / 2^23 the 72 KiB tile
         // leaves two workgroups = 2 waves per SIMD on a CU, the pass runs at 6.9 cycles per VALU instruction and 1.9 TB/s - bound
@@ -418,7 +421,8 @@ class CurveBackend : public Backend {
                 if (threads > (uint32_t)NTT_THREADS) threads = NTT_THREADS;
             }
             if (thr_env) threads = (uint32_t)thr_env;
-            ntt_pass_kernel<FRP><<<grid, threads, lds, st>>>(nb, tw, pre, post, scale, a);
+            if (ntt_twu_) ntt_pass_kernel<FRP, true><<<grid, threads, lds, st>>>(nb, tw, pre, post, scale, a);
+            else ntt_pass_kernel<FRP, false><<<grid, threads, lds, st>>>(nb, tw, pre, post, scale, a);
             KCHK();
             t0 += s;
         }
@@ -1630,7 +1634,9 @@ class CurveBackend : public Backend {
         const size_t fn = (size_t)n_ * sizeof(Fr), f4 = (size_t)n4_ * sizeof(Fr);
         CHK(tw_n_.alloc(fn / 2)); CHK(twi_n_.alloc(fn / 2)); CHK(tw_4n_.alloc(f4 / 2)); CHK(twi_4n_.alloc(f4 / 2));
         const Fr ru = fr_u64(32);   // R'/R = 2^5: x R -> x R'
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<FRP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<FRP, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(((size_t)1 << NTT_TILE_LOG) * sizeof(FeU<FRP>))));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<FRP, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(((size_t)1 << NTT_TILE_LOG) * sizeof(FeU<FRP>))));
         CHK(twu_n_.alloc(fn / 2));
         CHK(powers(st, ptr<Fr>(tw_n_), n_ / 2, omega_, Fr::one()));
@@ -1638,6 +1644,16 @@ class CurveBackend : public Backend {
         CHK(powers(st, ptr<Fr>(twi_n_), n_ / 2, omega_inv_, ru));
         CHK(powers(st, ptr<Fr>(tw_4n_), n4_ / 2, omega4_, ru));
         CHK(powers(st, ptr<Fr>(twi_4n_), n4_ / 2, omega4_inv_, ru));
+        if (env_int("APK_NTT_TWU", 0, 0, 1)) {     // measured neutral (profiles/r06_ntt_twiddles.txt): off
+            struct { DevBuf* in; DevBuf* out; uint32_t count; } tabs[4] = {{&twu_n_, &twu_n_x_, n_ / 2}, {&twi_n_, &twi_n_x_, n_ / 2},
+                                                                            {&tw_4n_, &tw_4n_x_, n4_ / 2}, {&twi_4n_, &twi_4n_x_, n4_ / 2}};
+            for (auto& t : tabs) {
+                CHK(t.out->alloc((size_t)t.count * sizeof(FeU<FRP>)));
+                unpack_table_kernel<FRP><<<cdiv(t.count, 256), 256, 0, st>>>(ptr<Fr>(*t.in), ptr<FeU<FRP>>(*t.out), t.count);
+                KCHK();
+            }
+            ntt_twu_ = true;
+        }
         CHK(coset_pre_.alloc((size_t)(n_ + 4) * sizeof(Fr)));
         CHK(powers(st, ptr<Fr>(coset_pre_), n_ + 4, shift_, ru));
         CHK(coset_post_inv_.alloc(f4));

@@ -55,7 +55,9 @@ struct NttPassArgs {
 // 171 mads + ~150 other instructions.
 //
 // tw[j] = w^j * R' for j < N/2 (w = omega or omega^-1); pre / post / scale tables likewise in R' form
-template <class FR>
+// TWU (round 6): the twiddle table holds the elements already in the tile's unsaturated-limb form (FeU, 36 bytes: `tw` then points at
+// FeU<FR> records) - a butterfly's twiddle costs a 36-byte load instead of a 32-byte load + ~18 instructions of unpacking.
+template <class FR, bool TWU = false>
 __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, const Fe<FR>* __restrict__ tw,
                                                                const Fe<FR>* __restrict__ pre,   // or null
                                                                const Fe<FR>* __restrict__ post,  // or null
@@ -67,6 +69,11 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, cons
     static_assert(Fu::HEADROOM >= 64, "values reach (4 + 2 log2 N) p < 64 p over the stages of a transform (N <= 2^29)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Fu* sm = reinterpret_cast<Fu*>(smem_raw);
+    const Fu* __restrict__ twu = reinterpret_cast<const Fu*>(tw);
+    auto twiddle = [&](uint32_t idx) -> Fu {
+        if constexpr (TWU) return twu[idx];
+        else { Fr w = tw[idx]; return Fu::unpack(w.l); }
+    };
     Fr* __restrict__ out = reinterpret_cast<Fr*>(nb.out[blockIdx.y]);
     const Fr* __restrict__ in = reinterpret_cast<const Fr*>(nb.in[blockIdx.y]);
     Fu* __restrict__ wide = reinterpret_cast<Fu*>(nb.wide[blockIdx.y]);
@@ -140,8 +147,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, cons
                 continue;
             }
             if (t != 0) {   // stage t: exponent imod * N / 2^(t+1); stage 0 has unit twiddles and fresh operands (below 2p)
-                Fr w = tw[(imod << (a.log_n - 1 - t)) << a.tw_shift];
-                const Fu w1 = Fu::unpack(w.l);
+                const Fu w1 = twiddle((imod << (a.log_n - 1 - t)) << a.tw_shift);
                 x1 = Fu::mul_nr(w1, x1);
                 x3 = Fu::mul_nr(w1, x3);
             }
@@ -152,12 +158,10 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, cons
             // stage t+1: exponents imod * N / 2^(t+2) and that + N/4
             const uint32_t k2 = imod << (a.log_n - 2 - t);
             {
-                Fr w = tw[(k2 + (1u << (a.log_n - 2))) << a.tw_shift];
-                y3 = Fu::mul_nr(Fu::unpack(w.l), y3);
+                y3 = Fu::mul_nr(twiddle((k2 + (1u << (a.log_n - 2))) << a.tw_shift), y3);
             }
             if (t != 0) {
-                Fr w = tw[k2 << a.tw_shift];
-                y2 = Fu::mul_nr(Fu::unpack(w.l), y2);
+                y2 = Fu::mul_nr(twiddle(k2 << a.tw_shift), y2);
                 sm[e00] = Fu::add_n(y0, y2);
                 sm[e10] = Fu::template sub_k<2>(y0, y2);
             } else {   // w2 = 1: y2 = x2 + x3 is below 4p, not a fresh product
@@ -187,7 +191,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, cons
             Fu v = sm[e1];
             // no product in stage 0 (unit twiddles; the operands are fresh, i.e. below 2p as the difference needs) and for zero
             // operands (the first two stages of the zero-padded 4n transforms) - both are wave-uniform in practice
-            if (t != 0 && !v.is_zero()) { Fr w = tw[tidx]; v = Fu::mul_nr(Fu::unpack(w.l), v); }
+            if (t != 0 && !(padded && v.is_zero())) v = Fu::mul_nr(twiddle(tidx), v);
             sm[e0] = Fu::add_n(u, v);
             sm[e1] = Fu::template sub_k<2>(u, v);
         }
@@ -207,6 +211,15 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttBatch nb, cons
         v.pack(o.l);
         out[idx] = o;
     }
+}
+
+// table[i] (Fe, the radix R' twiddles) -> FeU records for the TWU form of the pass kernel
+template <class FR>
+__global__ void __launch_bounds__(256) unpack_table_kernel(const Fe<FR>* __restrict__ in, FeU<FR>* __restrict__ out, uint32_t count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Fe<FR> v = in[i];
+    out[i] = FeU<FR>::unpack(v.l);
 }
 
 // tw[j] = w^j, j < count: each thread exponentiates its block start then walks

@@ -781,12 +781,14 @@ print("SHA", hashlib.sha256(MarshalProof(plonk.Prove(ccs, pk, w, blinding(cv, 3)
                        # round 5: the host's [lin] combination - GLV halves, fixed-base tables of the VK points, the [H] part ahead of
                        # the evaluations, parked threads - against the full-length one-pass Straus form it replaced
                        {"APK_HOST_LINCOMB_THREADS": "3"}, {"APK_HOST_GLV": "0", "APK_HOST_FIXED": "0", "APK_LIN_EARLY_H": "0"}, {"APK_ZERO_COPY": "0"},
-                       {"APK_HOST_GLV": "0"}, {"APK_HOST_FIXED": "0", "APK_LIN_EARLY_H": "0", "APK_HOST_LINCOMB_THREADS": "4"}]),
+                       {"APK_HOST_GLV": "0"}, {"APK_HOST_FIXED": "0", "APK_LIN_EARLY_H": "0", "APK_HOST_LINCOMB_THREADS": "4"},
+                       # round 6: twiddle tables kept as unsaturated-limb records, alone and with the radix-4 steps; the stream waits' forms
+                       {"APK_NTT_TWU": "1"}, {"APK_NTT_TWU": "1", "APK_NTT_RADIX4": "1"}, {"APK_SYNC_BLOCKING": "2"}, {"APK_SYNC_BLOCKING": "1"}]),
     ("bls12-381", 10, 12, [{"APK_MSM_LEAN_TAIL": "1", "APK_NTT_RADIX4": "1"}, {"APK_MSM_SORT2": "1"},
                            {"APK_MSM_SORT2": "1", "APK_MSM_PART_PBLOG": "3", "APK_MSM_PART_SMALL_SCAN": "0"},
                            {"APK_MSM_COMBINE_QUAD": "1", "APK_MSM_LEAN_TAIL": "0"}, {"APK_MSM_COMBINE_QUAD": "0", "APK_MSM_LEAN_TAIL": "0"},
                            {"APK_HOST_LINCOMB_THREADS": "1"}, {"APK_HOST_GLV": "0", "APK_HOST_FIXED": "0", "APK_LIN_EARLY_H": "0"},
-                           {"APK_HOST_FIXED": "0"}, {"APK_ZERO_COPY": "0"}]),
+                           {"APK_HOST_FIXED": "0"}, {"APK_ZERO_COPY": "0"}, {"APK_NTT_TWU": "1", "APK_NTT_RADIX4": "1"}, {"APK_SYNC_BLOCKING": "2"}]),
 ])
 def test_run_time_variants_give_the_same_bytes(gpu, cname, log_n, window, variants):
     """The forms the library picks at run time - lean tail kernels when other proofs are in flight (sixteen-lane row/column
