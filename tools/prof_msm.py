@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Small driver for profiler runs: one context at BN254 2^log_n, then a few single MSMs and proofs.
 usage: python tools/prof_msm.py [log_n] [msms] [proofs] [bn254|bls12_381]
-APK_PROF_SLOTS=k: proving slots of the context (1).  APK_PROF_FACTS=file: what the run did (sizes, MSMs, pairs, window, table bytes) as JSON, for tools/pmc_summary.py --json."""
+APK_PROF_SLOTS=k: proving slots of the context (1).  APK_PROF_STATS=1: the proofs run with the library's HIP-event statistics on (as
+bench.py's roofline pass does) and the average msm_accumulate_kernel launch time by those events is printed - under rocprofv3 the same
+run then gives the profiler's average for the same launches (profiles/rNN_kernel_trace_*_lone_proofs.txt).  APK_PROF_FACTS=file: what the run did (sizes, MSMs, pairs, window, table bytes) as JSON, for tools/pmc_summary.py --json."""
 import ctypes as C
 import json
 import os
@@ -31,8 +33,15 @@ out = C.create_string_buffer(2 * cv.fp_bytes)
 for _ in range(n_msm):
     check(lib.apk_msm_g1_device(pk.ctx, 0, d[0], n, out))
 pr = _lib.Proof()
+if os.environ.get("APK_PROF_STATS") == "1":
+    pk.enable_stats(True)
+    pk.stats(reset=True)
 for _ in range(n_proofs):
     check(lib.apk_prove_device(pk.ctx, d[0], d[1], d[2], cv.fr_vector(wl.witness.public), cv.fr_vector(wl.blinding), None, C.byref(pr)))
+if os.environ.get("APK_PROF_STATS") == "1":
+    st = pk.stats(reset=True)
+    print("HIP events: %d msm_accumulate_kernel launches of the proofs, avg %.4f ms, %.1f pairs per launch" %
+          (st.msm_accumulate_launches, st.msm_accumulate_ms / max(st.msm_accumulate_launches, 1), st.msm_pairs / max(st.msm_accumulate_launches, 1)))
 if os.environ.get("APK_PROF_FACTS"):
     c = pk.msm_window                                    # what the context chose (or APK_MSM_WINDOW)
     windows = (cv.r.bit_length() + 1 + c - 1) // c

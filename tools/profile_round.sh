@@ -16,8 +16,8 @@ python tools/rocprof_summary.py $O/${TAG}_kt1/r_results.db > $O/${TAG}_kernel_tr
 grep '"metric"' $O/${TAG}_kt1.log | tail -1 > $O/${TAG}_kernel_trace_bn254_2p17_benchline.json
 # ... and twelve lone proofs and nothing else (tools/prof_msm.py): the population bench.py's HIP-event statistics time - the average
 # msm_accumulate_kernel duration of THIS table is the one to hold against the line's roofline.avg_launch_ms
-APK_PROF_SLOTS=32 timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_ktlone -o r -- python tools/prof_msm.py 17 0 12 > $O/${TAG}_ktlone.log 2>&1
-python tools/rocprof_summary.py $O/${TAG}_ktlone/r_results.db > $O/${TAG}_kernel_trace_bn254_2p17_lone_proofs.txt
+APK_PROF_SLOTS=32 APK_PROF_STATS=1 timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_ktlone -o r -- python tools/prof_msm.py 17 0 48 > $O/${TAG}_ktlone.log 2>&1
+(grep "HIP events" $O/${TAG}_ktlone.log; python tools/rocprof_summary.py $O/${TAG}_ktlone/r_results.db) > $O/${TAG}_kernel_trace_bn254_2p17_lone_proofs.txt
 rm -rf $O/${TAG}_ktlone
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_kt24 -o r -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --no-oracle-check --no-host-inputs > $O/${TAG}_kt24.log 2>&1
 python tools/rocprof_summary.py $O/${TAG}_kt24/r_results.db > $O/${TAG}_kernel_trace_bn254_2p17_saturated.txt
