@@ -576,7 +576,9 @@ def roofline_from_stats(args, cv, st, pmc, issue=None):
         c = window_bits(args)
         windows = (cv.r.bit_length() + 1 + c - 1) // c
         adds_per_s = pairs_per_launch * windows / (acc_avg_ms * 1e-3)
-        roofline["valu"] = {"bucket_additions_per_s": round(adds_per_s / 1e9, 3), "unit": "G additions/s", "windows": windows}
+        roofline["valu"] = {"bucket_additions_per_s": round(adds_per_s / 1e9, 3), "unit": "G additions/s", "windows": windows,
+                            "scope": "ONE msm_accumulate_kernel launch of a lone proof (HIP events): a small circuit's lone launch cannot fill the device; "
+                                     "the loaded device against its issue rate is roofline.valu_under_load"}
         if pmc and pmc.get("valu_instructions_per_addition") and issue:
             # the kernel's real ceiling: VALU issue.  Both factors are of THIS run: VALU instructions per bucket addition and lane
             # from the SQ_INSTS_VALU pass above, wall time per wave instruction and SIMD from tools/ubench/valu_rates --json
