@@ -82,3 +82,18 @@ def test_cpu_baseline_counts_the_cores_it_is_granted(tmp_path, monkeypatch):
     monkeypatch.setattr(bench_cpu.os, "sched_getaffinity", lambda pid: set(range(256)))
     n, info = bench_cpu.effective_cores()
     assert n == 16 and info["visible_cpus"] == 256 and info["cgroup_cpu_max"] == "1600000 100000"
+
+
+def test_proof_algorithmic_bytes_follow_the_survey():
+    """bench.proof_algorithmic_bytes = SURVEY.md section 8d's derivation: BN254 2^17 without BSB22 is 10 n 96 B of MSM (126 MB) +
+    (12 n + 13 4n) 64 B of transforms (537 MB) + 14 4n 32 B of quotient pass (235 MB) + 50 MB = 0.95 GB; a BSB22 commitment adds one
+    MSM, one pair of transforms and two vectors of the quotient pass; BLS12-381 pairs are 128 B."""
+    import bench
+    from algoplonk_amd import ecc
+    a = bench.proof_algorithmic_bytes(ecc.BN254, 17, 0)
+    assert (a["msm"], a["ntt"], a["quotient"], a["misc"]) == (125829120, 536870912, 234881024, 50000000) and a["total"] == 947581056
+    b = bench.proof_algorithmic_bytes(ecc.BLS12_381, 21, 1)
+    n = 1 << 21
+    assert b["msm"] == 11 * n * 128 and b["ntt"] == (13 * n + 14 * 4 * n) * 64 and b["quotient"] == 16 * 4 * n * 32 and b["misc"] == 50000000 * 16
+    assert bench.default_witnesses(bench.parse_args([])) == 16 and bench.default_witnesses(bench.parse_args(["--log-n", "21", "--inflight", "8"])) == 2
+    assert bench.default_witnesses(bench.parse_args(["--inflight", "1"])) == 1
